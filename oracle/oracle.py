@@ -1,0 +1,206 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package `autoforce_amd` must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+FLAGS_SESOAP = 7  # gaussian | nnl | normalise
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    src = os.path.join(_HERE, "sgpr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_neighbors.restype = C.c_int64
+    return _LIB
+
+
+def _opt(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def ylm(lmax, xyz, grad=True):
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    n = len(xyz)
+    L1 = lmax + 1
+    Y = np.zeros((L1, L1, n))
+    dY = np.zeros((L1, L1, n, 3)) if grad else None
+    lib().orc_ylm(C.c_int(lmax), C.c_int(n), _opt(xyz), _opt(Y), _opt(dY))
+    return (Y, dY) if grad else Y
+
+
+def descriptor(lmax, nmax, rc, r, slots, units, S, flags=FLAGS_SESOAP, G=None):
+    """p[S,S,D] (and dE/dr[nn,3] for a given G = dE/dp)."""
+    r = np.ascontiguousarray(r, np.float64).reshape(-1, 3)
+    nn = len(r)
+    slots = np.ascontiguousarray(slots, np.int32)
+    units = np.ascontiguousarray(units, np.float64)
+    D = (nmax + 1) ** 2 * (lmax + 1)
+    p = np.zeros((S, S, D))
+    dr = None
+    if G is not None:
+        G = np.ascontiguousarray(G, np.float64)
+        dr = np.zeros((nn, 3))
+    lib().orc_descriptor(C.c_int(lmax), C.c_int(nmax), C.c_double(rc), C.c_int(flags), C.c_int(S),
+                         C.c_int(nn), _opt(r), _opt(slots), _opt(units), _opt(p), _opt(G), _opt(dr))
+    return p if G is None else (p, dr)
+
+
+def neighbors(pos, cell, pbc, rc):
+    pos = np.ascontiguousarray(pos, np.float64)
+    cell = np.ascontiguousarray(cell, np.float64).reshape(3, 3)
+    pbc = np.ascontiguousarray(np.asarray(pbc, bool).astype(np.int32))
+    N = len(pos)
+    ptr = np.zeros(N + 1, np.int64)
+    tot = lib().orc_neighbors(C.c_int(N), _opt(pos), _opt(cell), _opt(pbc), C.c_double(rc), _opt(ptr), None, None)
+    j = np.zeros(tot, np.int32)
+    off = np.zeros((tot, 3), np.int32)
+    lib().orc_neighbors(C.c_int(N), _opt(pos), _opt(cell), _opt(pbc), C.c_double(rc), _opt(ptr), _opt(j), _opt(off))
+    return ptr, j, off
+
+
+def default_radii(species):
+    """DefaultRadii (descriptor/sesoap.py:84-99): H -> 0.5, everything else 1.0."""
+    return np.array([0.5 if int(z) == 1 else 1.0 for z in species])
+
+
+def inducing_descriptors(lmax, nmax, rc, species, ind_z, ind_ptr, ind_nbr_z, ind_nbr_r, radii=None):
+    species = [int(z) for z in species]
+    radii = default_radii(species) if radii is None else np.asarray(radii, float)
+    S = len(species)
+    D = (nmax + 1) ** 2 * (lmax + 1)
+    m = len(ind_z)
+    Pm = np.zeros((m, S, S, D))
+    nnm = np.zeros(m, np.int32)
+    for q in range(m):
+        a, b = int(ind_ptr[q]), int(ind_ptr[q + 1])
+        nnm[q] = b - a
+        if b > a:
+            slots = np.array([species.index(int(z)) for z in ind_nbr_z[a:b]], np.int32)
+            Pm[q] = descriptor(lmax, nmax, rc, ind_nbr_r[a:b], slots, radii[slots], S)
+    return Pm, nnm
+
+
+def kernel_matrix(z1, nn1, P1, z2, nn2, P2, eta):
+    n1, n2 = len(z1), len(z2)
+    P1 = np.ascontiguousarray(P1, np.float64).reshape(n1, -1)
+    P2 = np.ascontiguousarray(P2, np.float64).reshape(n2, -1)
+    K = np.zeros((n1, n2))
+    lib().orc_kernel_matrix(C.c_int(n1), _opt(np.ascontiguousarray(z1, np.int32)), _opt(np.ascontiguousarray(nn1, np.int32)),
+                            _opt(P1), C.c_int(n2), _opt(np.ascontiguousarray(z2, np.int32)),
+                            _opt(np.ascontiguousarray(nn2, np.int32)), _opt(P2), C.c_int(P1.shape[1]),
+                            C.c_double(eta), _opt(K))
+    return K
+
+
+def frame(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mu, choli=None, radii=None,
+          want_p=True):
+    species = np.ascontiguousarray(species, np.int32)
+    radii = default_radii(species) if radii is None else np.ascontiguousarray(radii, np.float64)
+    numbers = np.ascontiguousarray(numbers, np.int32)
+    pos = np.ascontiguousarray(pos, np.float64)
+    cell = np.ascontiguousarray(cell, np.float64).reshape(3, 3)
+    ptr, j, off = nl
+    ptr = np.ascontiguousarray(ptr, np.int64)
+    j = np.ascontiguousarray(j, np.int32)
+    off = np.ascontiguousarray(off, np.int32)
+    N, m, S = len(numbers), len(ind_z), len(species)
+    D = (nmax + 1) ** 2 * (lmax + 1)
+    Pm = np.ascontiguousarray(Pm, np.float64).reshape(m, -1)
+    P = np.zeros((N, S, S, D)) if want_p else None
+    K = np.zeros((N, m))
+    E = C.c_double(0)
+    F = np.zeros((N, 3))
+    dcell = np.zeros((3, 3))
+    stress = np.zeros(6)
+    beta = np.zeros(N) if choli is not None else None
+    rc_ = lib().orc_frame(C.c_int(lmax), C.c_int(nmax), C.c_double(rc), C.c_double(eta), C.c_int(S), _opt(species),
+                          _opt(radii), C.c_int(N), _opt(numbers), _opt(pos), _opt(cell), _opt(ptr), _opt(j), _opt(off),
+                          C.c_int(m), _opt(np.ascontiguousarray(ind_z, np.int32)), _opt(np.ascontiguousarray(nnm, np.int32)),
+                          _opt(Pm), _opt(np.ascontiguousarray(mu, np.float64)),
+                          _opt(None if choli is None else np.ascontiguousarray(choli, np.float64)),
+                          _opt(P), _opt(K), C.byref(E), _opt(F), _opt(dcell), _opt(stress), _opt(beta))
+    if rc_:
+        raise RuntimeError("orc_frame: a neighbour species is missing from the species table")
+    return dict(p=P, cov=K, energy=E.value, forces=F, dcell=dcell, stress=stress, beta=beta)
+
+
+def jitcholesky(M):
+    M = np.ascontiguousarray(M, np.float64)
+    n = len(M)
+    L = np.zeros((n, n))
+    ridge = C.c_double(0)
+    rc_ = lib().orc_jitcholesky(C.c_int(n), _opt(M), _opt(L), C.byref(ridge))
+    if rc_:
+        raise RuntimeError("cholesky was not successful!")  # algebra.py:45-46
+    return L, ridge.value
+
+
+def tril_inverse(L):
+    L = np.ascontiguousarray(L, np.float64)
+    Li = np.zeros_like(L)
+    lib().orc_tril_inverse(C.c_int(len(L)), _opt(L), _opt(Li))
+    return Li
+
+
+def regression(M, K, Y, noise0=0.01):
+    M = np.ascontiguousarray(M, np.float64)
+    K = np.ascontiguousarray(K, np.float64)
+    Y = np.ascontiguousarray(Y, np.float64)
+    m = len(M)
+    mu, choli, L = np.zeros(m), np.zeros((m, m)), np.zeros((m, m))
+    ridge, sigma = C.c_double(0), C.c_double(0)
+    rc_ = lib().orc_regression(C.c_int(m), _opt(M), C.c_int(len(K)), _opt(K), _opt(Y), C.c_double(noise0),
+                               _opt(mu), _opt(choli), _opt(L), C.byref(ridge), C.byref(sigma))
+    if rc_:
+        raise RuntimeError("cholesky was not successful!")
+    return dict(mu=mu, choli=choli, L=L, ridge=ridge.value, sigma=sigma.value)
+
+
+def vscale(M, mu, ind_z, species):
+    M = np.ascontiguousarray(M, np.float64)
+    out = np.zeros(len(species))
+    lib().orc_vscale(C.c_int(len(M)), _opt(M), _opt(np.ascontiguousarray(mu, np.float64)),
+                     _opt(np.ascontiguousarray(ind_z, np.int32)), C.c_int(len(species)),
+                     _opt(np.ascontiguousarray(species, np.int32)), _opt(out))
+    return out
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def distribute(numbers, world_size, loads=None, total=None):
+    """Distributer.__call__ (descriptor/atoms.py:235-246): each atom goes to the rank with the
+    smallest (total load, per-species load, rank id).  Returns (ranks, loads, total)."""
+    loads = {} if loads is None else loads
+    total = [0] * world_size if total is None else total
+    ranks = []
+    for z in numbers:
+        z = int(z)
+        if z not in loads:
+            loads[z] = [0] * world_size
+        rank = min(range(world_size), key=lambda r: (total[r], loads[z][r], r))
+        ranks.append(rank)
+        loads[z][rank] += 1
+        total[rank] += 1
+    return np.array(ranks, np.int32), loads, total

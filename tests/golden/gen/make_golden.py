@@ -1,0 +1,546 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (read-only)
+from /root/reference in the build container.  Nothing from the reference is copied: the
+fixtures are inputs + the reference's outputs (numpy arrays).
+
+Run (build container only; /root/reference does not exist on the GPU box):
+    python tests/golden/gen/make_golden.py
+
+The reference needs `ase` and `mpi4py`, both absent here; tests/golden/gen/stubs/ holds
+empty stand-ins (our own code) for the handful of names touched at import time.  The
+periodic neighbour list (ASE's job in the reference, descriptor/atoms.py:348-363) is
+replaced by the brute-force builder below; it defines the pair rule |r| < rc, bothways,
+no self-interaction but self-images kept (SURVEY.md §8c "parity unpinned at this boundary").
+
+Reference call sites exercised (file:line under /root/reference/theforce):
+  descriptor/ylm.py:113-225            Ylm.forward (incl. the near-z shear, :10-23)
+  descriptor/sesoap.py:161-260         SeSoap.forward (value + analytic grad)
+  descriptor/soap.py:488-525           the repo's only numeric KAT (AbsSeriesSoap)
+  descriptor/atoms.py:365-382          Local construction, r = xyz[n]-xyz[a]+off@cell
+  similarity/universal.py:109-122      get_func, similarity/similarity.py:94-103 lone_atoms
+  regression/gppotential.py:63-84      EnergyForceKernel.energy_energy
+  calculator/active.py:548-611         E, autograd forces, cell gradient, stress
+  calculator/active.py:781-804         covloss; gppotential.py:644-649 vscale
+  regression/algebra.py:29-47          jitcholesky
+  regression/gppotential.py:1204-1339  _regression(optimize=False)
+  descriptor/atoms.py:228-246          Distributer
+"""
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.dirname(HERE)
+sys.path[:0] = [os.path.join(HERE, "stubs"), "/root/reference"]
+
+import torch  # noqa: E402
+import theforce  # noqa: E402,F401  (sets fp64 default)
+from theforce.descriptor.atoms import Distributer, Local  # noqa: E402
+from theforce.descriptor.cutoff import PolyCut  # noqa: E402
+from theforce.descriptor.sesoap import DefaultRadii, SeSoap  # noqa: E402
+from theforce.descriptor.soap import AbsSeriesSoap  # noqa: E402
+from theforce.descriptor.ylm import Ylm  # noqa: E402
+from theforce.regression.algebra import jitcholesky  # noqa: E402
+from theforce.regression.gppotential import (  # noqa: E402
+    AutoMean,
+    EnergyForceKernel,
+    _regression,
+)
+from theforce.regression.kernel import White  # noqa: E402
+from theforce.similarity.sesoap import SeSoapKernel  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+# ----------------------------------------------------------------------------- helpers
+def brute_force_nl(pos, cell, pbc, rc):
+    """All (i, j, off) with |x_j - x_i + off@cell| < rc, (j,off) != (i,0). Sorted by (i, j, off)."""
+    n = len(pos)
+    cell = np.asarray(cell, float)
+    if np.abs(np.linalg.det(cell)) > 1e-12:
+        inv = np.linalg.inv(cell)
+        heights = 1.0 / np.linalg.norm(inv, axis=0)  # V / |a_j x a_k|
+    else:
+        heights = np.full(3, np.inf)
+    frac_span = np.zeros(3)
+    if np.all(np.isfinite(heights)):
+        f = pos @ np.linalg.inv(cell)
+        frac_span = f.max(0) - f.min(0)
+    nmax = [
+        int(np.ceil(rc / heights[k] + frac_span[k])) if pbc[k] else 0 for k in range(3)
+    ]
+    shifts = [
+        (a, b, c)
+        for a in range(-nmax[0], nmax[0] + 1)
+        for b in range(-nmax[1], nmax[1] + 1)
+        for c in range(-nmax[2], nmax[2] + 1)
+    ]
+    I, J, O = [], [], []
+    for s in shifts:
+        t = np.array(s, float) @ cell
+        d = pos[None, :, :] + t - pos[:, None, :]
+        r = np.sqrt((d**2).sum(-1))
+        m = r < rc
+        if s == (0, 0, 0):
+            m &= ~np.eye(n, dtype=bool)
+        i, j = np.nonzero(m)
+        I.append(i)
+        J.append(j)
+        O.append(np.tile(np.array(s, np.int32), (len(i), 1)))
+    I = np.concatenate(I)
+    J = np.concatenate(J)
+    O = np.concatenate(O)
+    order = np.lexsort((O[:, 2], O[:, 1], O[:, 0], J, I))
+    I, J, O = I[order], J[order], O[order]
+    ptr = np.zeros(n + 1, np.int64)
+    np.add.at(ptr, I + 1, 1)
+    ptr = np.cumsum(ptr)
+    return ptr, J.astype(np.int32), O.astype(np.int32)
+
+
+def make_kernel(lmax=3, nmax=3, eta=4, rc=6.0):
+    kern = SeSoapKernel(lmax, nmax, eta, rc, radii=DefaultRadii())
+    return kern, EnergyForceKernel([kern])
+
+
+def dense_p(kern, loc, species):
+    """p-hat of a Local as dense [S,S,D] over the model species table (zeros for absent).
+    The COO block with indices (ab[0], ab[1]) = (beta, alpha) holds sum_m c[alpha,n]c*[beta,n']
+    flattened [n,n',l] (sesoap.py:165-171,195-203); we store out[ab[0]-slot, ab[1]-slot]."""
+    v = kern.saved(loc, "value")
+    S = len(species)
+    D = kern.descriptor.dim
+    out = np.zeros((S, S, D))
+    if v is None:
+        return out
+    v = v.coalesce()
+    idx = v.indices().numpy()
+    val = v.values().detach().numpy()
+    zs = list(species)
+    for k in range(idx.shape[1]):
+        out[zs.index(idx[0, k]), zs.index(idx[1, k])] = val[k]
+    return out
+
+
+def frame_outputs(name, numbers, pos, cell, pbc, ind, mu, lmax=3, nmax=3, eta=4, rc=6.0):
+    """Push one frame through the reference path; `ind` = list of (Zc, Znbr[], r[][3])."""
+    kern, efk = make_kernel(lmax, nmax, eta, rc)
+    ptr, J, O = brute_force_nl(pos, cell, pbc, rc)
+    xyz = torch.tensor(pos, requires_grad=True)
+    lll = torch.tensor(cell, requires_grad=True)
+    locs = []
+    N = len(numbers)
+    for a in range(N):
+        n = J[ptr[a] : ptr[a + 1]].astype(np.int64)
+        off = O[ptr[a] : ptr[a + 1]]
+        cells = (torch.from_numpy(off[..., None].astype(float)) * lll).sum(dim=1)
+        r = xyz[n] - xyz[a] + cells  # descriptor/atoms.py:367-368
+        loc = Local(a, n, numbers[a], numbers[n], r, off, efk.kernels, dont_save_grads=True)
+        loc.natoms = N
+        locs.append(loc)
+    X = []
+    for zc, zn, rr in ind:
+        k = len(zn)
+        loc = Local(
+            0,
+            np.arange(1, k + 1),
+            int(zc),
+            np.asarray(zn, dtype=np.int64),
+            torch.tensor(np.asarray(rr, float).reshape(k, 3)),
+            None,
+            efk.kernels,
+            dont_save_grads=True,
+        )
+        X.append(loc)
+    cov = efk(locs, X)
+    M = efk(X, X).detach()
+    mu_t = torch.tensor(mu)
+    E = (cov @ mu_t).sum()
+    F = -torch.autograd.grad(E, xyz, retain_graph=True, allow_unused=True)[0]
+    (dcell,) = torch.autograd.grad(E, lll, allow_unused=True)
+    if dcell is None:
+        dcell = torch.zeros_like(lll)
+    # active.py:604-610
+    stress1 = -(F[:, None] * xyz[..., None]).sum(dim=0)
+    stress2 = (dcell[:, None] * lll[..., None]).sum(dim=0)
+    # ase Atoms.get_volume raises ValueError only for a rank-deficient cell -> volume = -2 (active.py:606-609)
+    vol = abs(np.linalg.det(cell)) if abs(np.linalg.det(cell)) > 0 else -2.0
+    stress = ((stress1 + stress2).detach().numpy() / vol).flat[[0, 4, 8, 5, 2, 1]]
+    L, ridge = jitcholesky(M)
+    choli = L.inverse().contiguous()
+    # active.py:781-804 (normalized kernel) + gppotential.py:644-649
+    b = choli @ cov.detach().t()
+    c = (b * b).sum(dim=0)
+    beta = (1 - c).clamp(min=0.0).sqrt()
+    indz = np.array([z for z, _, _ in ind])
+    mm = mu_t * (M @ mu_t)
+    species = sorted(set(int(z) for z in numbers) | set(int(z) for z in indz)
+                     | set(int(z) for _, zn, _ in ind for z in zn))
+    vscale = {int(z): float(mm[torch.from_numpy(indz == z)].sum() / (indz == z).sum())
+              for z in set(indz.tolist())}
+    vs = np.array([vscale.get(int(z), np.inf) for z in numbers])
+    with np.errstate(invalid="ignore"):
+        covloss = beta.numpy() * np.sqrt(vs)
+    P = np.stack([dense_p(kern, l, species) for l in locs])
+    Pm = np.stack([dense_p(kern, l, species) for l in X])
+    ind_ptr = np.cumsum([0] + [len(zn) for _, zn, _ in ind])
+    out = dict(
+        lmax=lmax, nmax=nmax, eta=eta, rc=rc,
+        numbers=np.asarray(numbers, np.int32), positions=pos, cell=cell,
+        pbc=np.asarray(pbc, bool), species=np.asarray(species, np.int32),
+        nl_ptr=ptr, nl_j=J, nl_off=O,
+        ind_z=indz.astype(np.int32), ind_ptr=ind_ptr.astype(np.int64),
+        ind_nbr_z=np.concatenate([np.asarray(zn, np.int32) for _, zn, _ in ind] + [np.zeros(0, np.int32)]),
+        ind_nbr_r=np.concatenate([np.asarray(rr, float).reshape(-1, 3) for _, _, rr in ind] + [np.zeros((0, 3))]),
+        mu=mu, p=P, p_ind=Pm, cov=cov.detach().numpy(), M=M.numpy(),
+        energy=float(E), forces=F.numpy(), dcell=dcell.numpy(), stress=stress,
+        L=L.numpy(), ridge=float(ridge), choli=choli.numpy(), beta=beta.numpy(),
+        vscale_z=np.array(sorted(vscale), np.int32),
+        vscale=np.array([vscale[z] for z in sorted(vscale)]), covloss=covloss,
+    )
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: N={N} m={len(ind)} <nn>={len(J)/N:.1f} E={float(E):.6f} |F|max={abs(F).max():.4f} "
+          f"ridge={float(ridge):.2e} sumF={abs(F.sum(0)).max():.1e}")
+    return out
+
+
+def env_of(pos, cell, pbc, rc, a, numbers):
+    ptr, J, O = brute_force_nl(pos, cell, pbc, rc)
+    n = J[ptr[a] : ptr[a + 1]]
+    r = pos[n] - pos[a] + O[ptr[a] : ptr[a + 1]].astype(float) @ cell
+    return int(numbers[a]), np.asarray(numbers)[n], r
+
+
+def inducing_from(rng, numbers, pos, cell, pbc, rc, m, noise=0.05):
+    """m LCEs drawn (species-proportionally, without replacement) from a frame, + noise."""
+    idx = rng.choice(len(numbers), size=m, replace=False)
+    ind = []
+    for a in idx:
+        zc, zn, r = env_of(pos, cell, pbc, rc, a, numbers)
+        r = r + noise * rng.normal(size=r.shape)
+        keep = np.linalg.norm(r, axis=1) < rc - 1e-3  # keep the env strictly inside rc
+        ind.append((zc, zn[keep], r[keep]))
+    return ind
+
+
+# ----------------------------------------------------------------------------- G1 Ylm
+def g1_ylm():
+    rng = np.random.default_rng(101)
+    out = {}
+    for lmax in (2, 3, 4):
+        a = rng.normal(size=(40, 3)) * np.array([1.0, 1.0, 1.0])
+        b = a.copy()
+        b[:6, 0] = 1e-3 * rng.normal(size=6) * np.abs(b[:6, 2])  # within the 0.01 cone
+        b[:6, 1] = 1e-3 * rng.normal(size=6) * np.abs(b[:6, 2])
+        b[5] = [0.0, 0.0, -1.3]  # exactly on -z
+        for tag, v in (("plain", a), ("nearz", b)):
+            xyz = torch.tensor(v)
+            Y, dY = Ylm(lmax)(xyz, grad=True)
+            out[f"l{lmax}_{tag}_xyz"] = v
+            out[f"l{lmax}_{tag}_Y"] = Y.numpy()
+            out[f"l{lmax}_{tag}_dY"] = dY.numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_ylm.npz"), **out)
+    print("g1_ylm done")
+
+
+# ----------------------------------------------------------------------------- G2 SeSoap
+def g2_sesoap():
+    rng = np.random.default_rng(202)
+    out = {}
+    cases = []
+
+    def env(nn, zs, scale=2.2):
+        r = rng.normal(size=(nn, 3)) * scale
+        d = np.linalg.norm(r, axis=1)
+        r[d > 5.9] *= (5.5 / d[d > 5.9])[:, None]
+        r[d < 0.8] *= (1.0 / d[d < 0.8])[:, None]
+        z = rng.choice(zs, size=nn)
+        return r, z.astype(np.int64)
+
+    cases.append(("s1", 3, 3) + env(40, [3]))
+    cases.append(("s2h", 3, 3) + env(30, [1, 8]))
+    cases.append(("s3", 3, 3) + env(45, [3, 15, 16]))
+    r, z = env(20, [3, 15, 16])
+    r[3] = [1e-4, -2e-4, 2.5]
+    cases.append(("s3_nearz", 3, 3, r, z))
+    r, z = env(1, [14])
+    cases.append(("single", 3, 3, r, z))
+    r, z = env(12, [14, 8])
+    r[0] = r[0] / np.linalg.norm(r[0]) * 6.5  # beyond the cutoff -> zero weight
+    cases.append(("beyond", 3, 3, r, z))
+    cases.append(("l2n2", 2, 2) + env(25, [3, 16]))
+    cases.append(("l4n2", 4, 2) + env(25, [3, 16]))
+    cases.append(("l3n4", 3, 4) + env(25, [29]))
+    names = []
+    for name, lmax, nmax, r, z in cases:
+        s = SeSoap(lmax, nmax, PolyCut(6.0), radii=DefaultRadii())
+        ab, p, _, dp, _ = s(torch.tensor(r), torch.tensor(z), grad=True, sparse_tensor=False)
+        names.append(name)
+        out[name + "_lmax"] = lmax
+        out[name + "_nmax"] = nmax
+        out[name + "_r"] = r
+        out[name + "_z"] = z.astype(np.int32)
+        out[name + "_ab"] = ab.numpy().astype(np.int32)  # (2, S^2): rows (ab[0], ab[1])
+        out[name + "_p"] = p.numpy()  # [S^2, D]
+        out[name + "_dp"] = dp.numpy()  # [S^2, D, nn, 3]
+        # un-normalised as well (pins nnl separately from the norm)
+        ab2, p2, _ = s(torch.tensor(r), torch.tensor(z), grad=False, normalize=False, sparse_tensor=False)
+        out[name + "_p_raw"] = p2.numpy()
+        # vector-Jacobian product by autograd (the force path's derivative, active.py:587-599)
+        G = rng.normal(size=tuple(p.shape))
+        x = torch.tensor(r, requires_grad=True)
+        _, pa, _ = s(x, torch.tensor(z), grad=False, sparse_tensor=False)
+        (pa * torch.tensor(G)).sum().backward()
+        out[name + "_G"] = G
+        out[name + "_vjp"] = x.grad.numpy()
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g2_sesoap.npz"), **out)
+    print("g2_sesoap done:", names)
+
+
+# ----------------------------------------------------------------------------- KAT
+def kat_absseries():
+    """descriptor/soap.py:488-525: inputs and the target tensor, plus what the reference
+    computes for them here (full precision)."""
+    xyz = np.array(
+        [
+            [0.175, 0.884, -0.87, 0.354, -0.082, 3.1],
+            [-0.791, 0.116, 0.19, -0.832, 0.184, 0.0],
+            [0.387, 0.761, 0.655, -0.528, 0.973, 0.0],
+        ]
+    ).T.copy()
+    target = np.array(
+        [
+            [[0.36174603, 0.39013356, 0.43448023], [0.39013356, 0.42074877, 0.46857549], [0.43448023, 0.46857549, 0.5218387]],
+            [[0.2906253, 0.30558356, 0.33600938], [0.30558356, 0.3246583, 0.36077952], [0.33600938, 0.36077952, 0.40524778]],
+            [[0.16241845, 0.18307552, 0.20443194], [0.18307552, 0.22340802, 0.26811937], [0.20443194, 0.26811937, 0.34109511]],
+        ]
+    )
+    s = AbsSeriesSoap(2, 2, PolyCut(3.0))
+    p, dp = s(torch.tensor(xyz))
+    p = p.permute(2, 0, 1).numpy()  # [l, n, n']
+    assert np.allclose(p, target, rtol=1e-5, atol=1e-8)
+    np.savez_compressed(os.path.join(OUT, "kat_absseries.npz"), xyz=xyz, target_lnn=target, p_lnn=p,
+                        dp=dp.numpy(), lmax=2, nmax=2, rc=3.0, unit=1.0)
+    print("kat_absseries: reference reproduces its own target")
+
+
+# ----------------------------------------------------------------------------- frames
+def rattle(rng, pos, sigma):
+    return pos + sigma * rng.normal(size=pos.shape)
+
+
+def frames():
+    # C1: 32-atom diamond Si, 8-atom cubic x (2,2,1): L_z = 5.431 < rc -> self images
+    rng = np.random.default_rng(0)
+    a = 5.431
+    basis = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
+                      [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]]) * a
+    pos = np.concatenate([basis + np.array([i, j, 0]) * a for i in range(2) for j in range(2)])
+    cell = np.diag([2 * a, 2 * a, a])
+    pos = rattle(rng, pos, 0.05)
+    numbers = np.full(32, 14)
+    rng1 = np.random.default_rng(1)
+    pos2 = rattle(rng1, pos, 0.10)
+    ind = inducing_from(rng1, numbers, pos2, cell, [True] * 3, 6.0, 16)
+    mu = np.random.default_rng(2).normal(size=16)
+    frame_outputs("g5_si32", numbers, pos, cell, [True] * 3, ind, mu)
+
+    # 3 species incl. H (radius 0.5), cubic 4^3 sites at 2.6 A
+    rng = np.random.default_rng(10)
+    g = np.stack(np.meshgrid(*[np.arange(4)] * 3, indexing="ij"), -1).reshape(-1, 3) * 2.6
+    pos = rattle(rng, g.astype(float), 0.15)
+    numbers = rng.permutation(np.array([1] * 16 + [8] * 24 + [40] * 24))
+    cell = np.eye(3) * 4 * 2.6
+    rng1 = np.random.default_rng(11)
+    pos2 = rattle(rng1, g.astype(float), 0.2)
+    ind = inducing_from(rng1, numbers, pos2, cell, [True] * 3, 6.0, 24)
+    mu = np.random.default_rng(12).normal(size=24)
+    frame_outputs("g5_mixed64", numbers, pos, cell, [True] * 3, ind, mu)
+
+    # triclinic, 2 species, positions deliberately outside the cell as well
+    rng = np.random.default_rng(20)
+    cell = np.array([[7.1, 0.0, 0.0], [2.3, 6.4, 0.0], [-1.1, 1.9, 8.2]])
+    f = rng.random((24, 3)) * 1.4 - 0.2
+    pos = f @ cell
+    # push apart atoms that are too close
+    for _ in range(200):
+        ptr, J, O = brute_force_nl(pos, cell, [True] * 3, 1.7)
+        if len(J) == 0:
+            break
+        i = np.repeat(np.arange(24), np.diff(ptr))
+        d = pos[J] - pos[i] + O.astype(float) @ cell
+        np.add.at(pos, i, -0.15 * d / np.linalg.norm(d, axis=1, keepdims=True))
+    numbers = rng.choice([3, 16], size=24)
+    rng1 = np.random.default_rng(21)
+    ind = inducing_from(rng1, numbers, rattle(rng1, pos, 0.1), cell, [True] * 3, 6.0, 12)
+    mu = np.random.default_rng(22).normal(size=12)
+    frame_outputs("g5_tric24", numbers, pos, cell, [True] * 3, ind, mu)
+
+    # non-periodic cluster with a lone atom; inducing set has a lone LCE of the same species
+    rng = np.random.default_rng(30)
+    pos = rng.normal(size=(14, 3)) * 2.0
+    for _ in range(200):
+        ptr, J, O = brute_force_nl(pos, np.zeros((3, 3)), [False] * 3, 1.5)
+        if len(J) == 0:
+            break
+        i = np.repeat(np.arange(14), np.diff(ptr))
+        d = pos[J] - pos[i]
+        np.add.at(pos, i, -0.15 * d / np.linalg.norm(d, axis=1, keepdims=True))
+    pos = np.concatenate([pos, [[30.0, 0.0, 0.0], [0.0, -40.0, 0.0]]])  # two lone atoms
+    numbers = np.array([10] * 7 + [18] * 7 + [10, 18])
+    cell = np.zeros((3, 3))
+    rng1 = np.random.default_rng(31)
+    ind = inducing_from(rng1, numbers, rattle(rng1, pos, 0.1), cell, [False] * 3, 6.0, 8)
+    ind.append((10, np.zeros(0, np.int64), np.zeros((0, 3))))  # lone Ne LCE
+    mu = np.random.default_rng(32).normal(size=9)
+    frame_outputs("g5_cluster16", numbers, pos, cell, [False] * 3, ind, mu)
+
+    # mixed pbc slab (pbc in x,y only), 2 species, with a near-z neighbour pair (shear quirk)
+    rng = np.random.default_rng(40)
+    g = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(2), indexing="ij"), -1).reshape(-1, 3) * 2.9
+    pos = rattle(rng, g.astype(float), 0.1)
+    pos[1] = pos[0] + np.array([1e-3, -2e-3, 2.9])  # atom 1 almost exactly above atom 0
+    numbers = rng.choice([29, 47], size=18)
+    cell = np.diag([8.7, 8.7, 12.0])
+    rng1 = np.random.default_rng(41)
+    ind = inducing_from(rng1, numbers, rattle(rng1, pos, 0.1), cell, [True, True, False], 6.0, 10)
+    mu = np.random.default_rng(42).normal(size=10)
+    frame_outputs("g5_slab18_nearz", numbers, pos, cell, [True, True, False], ind, mu)
+
+    # small-basis variant (lmax=2, nmax=2, eta=2, rc=4.5) on the Si frame
+    rng = np.random.default_rng(0)
+    pos = np.concatenate([basis + np.array([i, j, 0]) * a for i in range(2) for j in range(2)])
+    pos = rattle(rng, pos, 0.05)
+    cell = np.diag([2 * a, 2 * a, a])
+    numbers = np.full(32, 14)
+    rng1 = np.random.default_rng(51)
+    ind = inducing_from(rng1, numbers, rattle(rng1, pos, 0.1), cell, [True] * 3, 4.5, 8)
+    mu = np.random.default_rng(52).normal(size=8)
+    frame_outputs("g5_si32_l2n2", numbers, pos, cell, [True] * 3, ind, mu, lmax=2, nmax=2, eta=2, rc=4.5)
+
+
+# ----------------------------------------------------------------------------- G7 regression
+def g7_regression():
+    out = {}
+    # jitcholesky: PD, and rank-deficient (ladder)
+    rng = np.random.default_rng(70)
+    A = rng.normal(size=(12, 12))
+    Mpd = A @ A.T + 0.5 * np.eye(12)
+    L, ridge = jitcholesky(torch.tensor(Mpd))
+    out["chol_pd_M"], out["chol_pd_L"], out["chol_pd_ridge"] = Mpd, L.numpy(), float(ridge)
+    B = rng.normal(size=(12, 4))
+    Msd = B @ B.T  # rank 4
+    Msd[5] = Msd[3]
+    Msd[:, 5] = Msd[:, 3]  # exact duplicate row/col (duplicate inducing point)
+    L, ridge = jitcholesky(torch.tensor(Msd))
+    out["chol_sd_M"], out["chol_sd_L"], out["chol_sd_ridge"] = Msd, L.numpy(), float(ridge)
+    ones = np.ones((30, 30))  # algebra.py:218-224 uses the all-ones matrix
+    L, ridge = jitcholesky(torch.tensor(ones))
+    out["chol_ones_L"], out["chol_ones_ridge"] = L.numpy(), float(ridge)
+
+    # _regression on a duck-typed model
+    rng = np.random.default_rng(71)
+    m, nd = 10, 3
+    natoms = [5, 7, 4]
+    Z = [rng.choice([3, 16], size=n) for n in natoms]
+    C = rng.normal(size=(m, 6))
+    M = C @ C.T / 6 + 0.3 * np.eye(m)
+    Ke = rng.normal(size=(nd, m))
+    Kf = rng.normal(size=(3 * sum(natoms), m))
+    Kv = rng.normal(size=(6 * nd, m))
+    en = rng.normal(size=nd) * 3
+    fr = [rng.normal(size=(n, 3)) for n in natoms]
+    st = [rng.normal(size=6) * 0.01 for _ in natoms]
+    vol = [100.0 + 10 * i for i in range(nd)]
+    w = {3: 0.3, 16: -0.2}
+
+    class _A:
+        def __init__(self, i):
+            self.target_forces = torch.tensor(fr[i])
+            self.target_stress = torch.tensor(st[i])
+            self._v = vol[i]
+            self._z = Z[i]
+
+        def get_volume(self):
+            return self._v
+
+        def counts(self):
+            u, c = np.unique(self._z, return_counts=True)
+            return {int(a): int(b) for a, b in zip(u, c)}
+
+    class _D(list):
+        target_energy = torch.tensor(en)
+
+        @property
+        def natoms(self):
+            return natoms
+
+        def counts(self):
+            tot = {}
+            for a in self:
+                for z, c in a.counts().items():
+                    tot[z] = tot.get(z, 0) + c
+            return tot
+
+    data = _D([_A(i) for i in range(nd)])
+    mean = AutoMean()
+    mean.set_data(data)
+    for z in w:
+        mean.weights[z] = torch.tensor(w[z])
+
+    def gp_mean(dat, forces=False):
+        return torch.stack([mean(a) for a in dat])
+
+    ns = SimpleNamespace(
+        ignore_forces=False, M=torch.tensor(M), Ke=torch.tensor(Ke), Kf=torch.tensor(Kf), Kv=torch.tensor(Kv),
+        X=[SimpleNamespace(number=3)] * m, data=data,
+        gp=SimpleNamespace(noise=White(signal=0.01, requires_grad=False), mean=gp_mean), mean=mean,
+    )
+    ns.K = torch.cat([ns.Ke, ns.Kf, ns.Kv])
+    _regression(ns, optimize=False)
+    out.update(reg_M=M, reg_Ke=Ke, reg_Kf=Kf, reg_Kv=Kv, reg_energies=en,
+               reg_forces=np.concatenate([f.reshape(-1) for f in fr]),
+               reg_virial=np.concatenate([s * v for s, v in zip(st, vol)]),
+               reg_mean=np.array([float(mean(a)) for a in data]),
+               reg_noise0=0.01, reg_mu=ns.mu.numpy(), reg_choli=ns.choli.numpy(),
+               reg_ridge=float(ns.ridge), reg_sigma=float(ns.scaled_noise["all"]))
+    np.savez_compressed(os.path.join(OUT, "g7_regression.npz"), **out)
+    print("g7_regression done; sigma =", ns.scaled_noise["all"], "ridge(sd) =", out["chol_sd_ridge"],
+          "ridge(ones) =", out["chol_ones_ridge"])
+
+
+# ----------------------------------------------------------------------------- G9 Distributer
+def g9_distributer():
+    rng = np.random.default_rng(90)
+    numbers = rng.choice([3, 15, 16], size=50, p=[0.375, 0.125, 0.5])
+    out = {"numbers": numbers.astype(np.int32)}
+    for ws in (1, 2, 4, 8):
+        d = Distributer(ws)
+        a = SimpleNamespace(numbers=numbers, ranks=None)
+        d(a)
+        out[f"ranks_{ws}"] = np.array(a.ranks, np.int32)
+        # second frame on the same (loaded) distributer, as in consecutive MD steps w/o unload
+        b = SimpleNamespace(numbers=numbers[::-1], ranks=None)
+        d(b)
+        out[f"ranks2_{ws}"] = np.array(b.ranks, np.int32)
+    np.savez_compressed(os.path.join(OUT, "g9_distributer.npz"), **out)
+    print("g9_distributer done")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "kat", "frames", "g7", "g9"]
+    if "g1" in which:
+        g1_ylm()
+    if "g2" in which:
+        g2_sesoap()
+    if "kat" in which:
+        kat_absseries()
+    if "frames" in which:
+        frames()
+    if "g7" in which:
+        g7_regression()
+    if "g9" in which:
+        g9_distributer()
