@@ -1,0 +1,96 @@
+"""ctypes binding of libsgpr_hip.so (C ABI: include/sgpr_hip.h).
+
+The HIP library is the product: there is NO CPU fallback.  Loading fails loudly if the shared
+object is missing, and every call raises `SgprError` on a non-zero status (e.g. no gfx950
+device).  Nothing here imports the test oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgpr_hip.so")
+
+OK, E_INVALID, E_NODEVICE, E_NOMODEL, E_SPECIES, E_NOT_PD, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class SgprError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsgpr_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+_vp, _i32, _i64, _dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+
+# name -> (restype, argtypes); must list every symbol include/sgpr_hip.h declares
+SIGNATURES = {
+    "sgpr_last_error": (C.c_char_p, []),
+    "sgpr_version": (C.c_int, []),
+    "sgpr_device_count": (C.c_int, []),
+    "sgpr_create": (C.c_int, [C.c_int, C.c_int, _dbl, _dbl, C.c_int, _vp, _vp, C.c_int, C.POINTER(_vp)]),
+    "sgpr_destroy": (None, [_vp]),
+    "sgpr_set_inducing": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "sgpr_get_kmm": (C.c_int, [_vp, _vp]),
+    "sgpr_get_inducing_descriptors": (C.c_int, [_vp, _vp]),
+    "sgpr_set_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sgpr_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
+    "sgpr_make_vscale": (C.c_int, [_vp, _vp]),
+    "sgpr_compute": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "sgpr_bind_system": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
+    "sgpr_packed_len": (_i64, [C.c_int]),
+    "sgpr_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sgpr_sync_check": (C.c_int, [_vp, _vp]),
+    "sgpr_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "sgpr_stress_from_virial": (C.c_int, [_vp, _vp, _vp]),
+    "sgpr_get_descriptors": (C.c_int, [_vp, _vp]),
+    "sgpr_get_neighbors": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sgpr_get_dims": (C.c_int, [_vp, _vp]),
+    "sgpr_profile": (C.c_int, [_vp, C.c_int]),
+    "sgpr_get_stage_times": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
+}
+
+
+def load():
+    """Load the shared library (no GPU needed to load; needed for every compute call)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with autoforce_amd/csrc/build.sh "
+                "(or __graft_entry__.build()).  There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise SgprError(code, load().sgpr_last_error().decode())
+    return code
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def device_count():
+    return load().sgpr_device_count()

@@ -1,0 +1,896 @@
+// api.hip — C ABI (include/sgpr_hip.h) and step orchestration of the gfx950 SGPR evaluator.
+//
+// One handle = one model on one GPU, one HIP stream.  A step is the fixed launch sequence
+//   gather -> nl_bin -> nl_build -> desc_fwd -> gemm<KERNEL> -> gemm<STORE> -> desc_bwd
+//          -> gemm<ROWSQ> -> finalize
+// which sgpr_step_dev captures once into a HIP graph and replays.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+#include "../../include/sgpr_hip.h"
+#include "sgpr_internal.h"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(SGPR_E_NODEVICE, "%s: %s", #x, hipGetErrorString(e_));    \
+    } while (0)
+
+static inline int rup(int x, int q) { return (x + q - 1) / q * q; }
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count, bool zero = true)
+    {
+        if (count > n || !p) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            n = 0;
+            if (hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return -1;
+            n = count;
+        }
+        if (zero && count) (void)hipMemset(p, 0, count * sizeof(T));
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+struct sgpr_model {
+    int lmax, nmax, S, device;
+    double eta, rc;
+    std::vector<int> species;
+    std::vector<double> radii;
+    hipStream_t stream = nullptr;
+    // packed layout
+    int D, Dc, Dpad, CS;
+    std::vector<PackEntry> h_pack;
+    DevBuf<PackEntry> d_pack;
+    DevBuf<double> d_radii;
+    // inducing set (device arrays in species-sorted order)
+    int m = 0, m_pad = 0, m_rows = 0;
+    std::vector<int> ind_perm;  // sorted -> caller
+    std::vector<int> ind_slot;  // sorted
+    std::vector<int> qoff;      // [S+1]
+    DevBuf<int> d_ind_slot, d_ind_nn, d_qoff;
+    DevBuf<double> d_Pm, d_PmT, d_pm_norm, d_M, d_mu, d_choli;
+    bool has_mu = false, has_choli = false, choli_lower = true;
+    std::vector<double> mean_w, vscale;
+    DevBuf<double> d_vs_sqrt;  // sqrt(vscale) per slot
+    // bound system
+    int N = 0, N_rows = 0, rank = 0, world = 1, cnt = 0, cnt_rows = 0;
+    int pbc[3] = {1, 1, 1};
+    std::vector<int> numbers, perm /*sorted->caller*/, slot_sorted, aoff /*local [S+1]*/;
+    double mean_energy = 0.0;
+    DevBuf<int> d_perm, d_slot, d_aoff, d_lslot /*local rows*/, d_lnn;
+    DevBuf<double> d_pos_in, d_cell_in, d_pos;
+    // neighbour list
+    int maxnn = 0, nn_max_seen = 0;
+    bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
+    DevBuf<char> d_grid;
+    DevBuf<int> d_bin_of, d_bin_start, d_bin_atoms, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    // per-step work arrays (local rows)
+    DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
+    DevBuf<int> d_shear;
+    int epart_len = 0, virpart_len = 0;
+    // graph
+    hipGraphExec_t gexec = nullptr;
+    const void *g_pos = nullptr, *g_cell = nullptr, *g_out = nullptr;
+    hipStream_t g_stream = nullptr;
+    bool use_graph = true;
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<std::string> stage_names;
+    std::vector<double> stage_ms;
+};
+
+// ---------------------------------------------------------------------------- small kernels
+__global__ void gather_pos_kernel(int N, const int *perm, const double *pos_in, double *pos, double *F6N, int n_zero,
+                                  double *csq, int cnt)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        const int c = perm[i];
+        pos[3 * i] = pos_in[3 * c];
+        pos[3 * i + 1] = pos_in[3 * c + 1];
+        pos[3 * i + 2] = pos_in[3 * c + 2];
+    }
+    for (int k = i; k < n_zero; k += gridDim.x * blockDim.x) F6N[k] = 0.0;
+    if (i < cnt) csq[i] = 0.0;
+}
+
+__global__ void transpose_kernel(int rows, int cols, const double *A, int lda, double *B, int ldb)
+{
+    __shared__ double t[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        const int r = r0 + k, c = c0 + threadIdx.x;
+        t[k][threadIdx.x] = (r < rows && c < cols) ? A[(size_t)r * lda + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+        const int c = c0 + k, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) B[(size_t)c * ldb + r] = t[threadIdx.x][k];
+    }
+}
+
+// packed = [F(3N) | beta(N) | E | virial(9)] in CALLER atom order
+__global__ void finalize_kernel(int N, int cnt, int first, int stride, const int *perm, const int *slot,
+                                const double *Fnbr, const double *Fself, const double *csq, int has_beta,
+                                const double *vs_sqrt, const double *Epart, int nE, const double *virpart, int nV,
+                                double mean_energy, double *packed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        const int c = perm[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) packed[3 * c + k] = Fnbr[3 * i + k] + Fself[3 * i + k];
+        double b = 0.0;
+        const int il = (i - first) / stride;
+        if (has_beta && i >= first && (i - first) % stride == 0 && il < cnt) {
+            const double v = 1.0 - csq[il];
+            b = sqrt(v > 0.0 ? v : 0.0) * vs_sqrt[slot[i]];
+        }
+        packed[3 * N + c] = b;
+    }
+    if (blockIdx.x == 0) {
+        __shared__ double red[256];
+        // energy, then the 9 virial components: tree reductions in a fixed order (deterministic)
+        for (int q = 0; q < 10; q++) {
+            double s = 0.0;
+            if (q == 0)
+                for (int k = threadIdx.x; k < nE; k += blockDim.x) s += Epart[k];
+            else
+                for (int k = threadIdx.x; k < nV; k += blockDim.x) s += virpart[(size_t)k * 9 + (q - 1)];
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+                if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) packed[4 * (size_t)N + q] = red[0] + (q == 0 ? mean_energy : 0.0);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- host tables
+void host_build_harm_coef(HarmCoef *hc)
+{
+    memset(hc, 0, sizeof(*hc));
+    hc->y00 = sqrt(1.0 / (4.0 * M_PI));  // descriptor/ylm.py:56
+    for (int l = 2; l <= SGPR_MAX_L; l++)
+        for (int m = 0; m < l - 1; m++) {
+            hc->al[l][m] = sqrt((4.0 * l * l - 1.0) / (l * l - m * m));                                  // :57-65
+            hc->bl[l][m] = -sqrt(((l - 1.0) * (l - 1.0) - m * m) / (4.0 * (l - 1.0) * (l - 1.0) - 1.0)); // :66-76
+        }
+    for (int l = 0; l <= SGPR_MAX_L; l++) hc->cl[l] = sqrt(2.0 * l + 1.0);              // :77
+    for (int l = 1; l <= SGPR_MAX_L; l++) hc->dl[l] = -sqrt(1.0 + 1.0 / (2.0 * l));      // :78-80
+}
+
+static double factorial(int n)
+{
+    double f = 1.0;
+    for (int i = 2; i <= n; i++) f *= i;
+    return f;
+}
+
+static void build_pack(sgpr_model *h)
+{
+    const int N1 = h->nmax + 1, L1 = h->lmax + 1, U = h->S * N1;
+    h->D = N1 * N1 * L1;
+    h->Dc = U * (U + 1) / 2 * L1;
+    h->Dpad = rup(h->Dc, 16);
+    h->CS = h->S * N1 * L1 * L1;
+    h->h_pack.assign(h->Dc, PackEntry());
+    for (int u = 0; u < U; u++)
+        for (int v = u; v < U; v++)
+            for (int l = 0; l < L1; l++) {
+                const int pair = u * U - (u * (u - 1)) / 2 + (v - u);
+                PackEntry &e = h->h_pack[pair * L1 + l];
+                const int n1 = u % N1, n2 = v % N1;
+                // descriptor/sesoap.py:116-128
+                const double a1 = 1.0 / ((2 * l + 1) * pow(2.0, 2 * n1 + l) * factorial(n1) * factorial(n1 + l));
+                const double a2 = 1.0 / ((2 * l + 1) * pow(2.0, 2 * n2 + l) * factorial(n2) * factorial(n2 + l));
+                e.u = (int16_t)u; e.v = (int16_t)v; e.l = (int16_t)l; e.pad = 0;
+                e.coef = sqrt(a1 * a2) * (u == v ? 1.0 : 1.4142135623730951);
+            }
+}
+
+static int slot_of(const sgpr_model *h, int z)
+{
+    for (int k = 0; k < h->S; k++)
+        if (h->species[k] == z) return k;
+    return -1;
+}
+
+// ---------------------------------------------------------------------------- ABI
+extern "C" const char *sgpr_last_error(void) { return g_err; }
+extern "C" int sgpr_version(void) { return 1000; }
+
+extern "C" int sgpr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, const int32_t *species_z,
+                           const double *radii, int device, sgpr_model **out)
+{
+    if (!out || !species_z || S < 1 || S > SGPR_MAX_S) return fail(SGPR_E_INVALID, "sgpr_create: bad species table (S=%d)", S);
+    if (!(rc > 0.0) || !(eta > 0.0)) return fail(SGPR_E_INVALID, "sgpr_create: rc and eta must be positive");
+    const bool ok = (lmax == 3 && nmax == 3) || (lmax == 2 && nmax == 2) || (lmax == 4 && nmax == 4 && S <= 4);
+    if (!ok) return fail(SGPR_E_UNSUPPORTED, "sgpr_create: (lmax,nmax,S)=(%d,%d,%d) is not compiled in", lmax, nmax, S);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SGPR_E_NODEVICE, "no HIP device: libsgpr_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(SGPR_E_INVALID, "sgpr_create: device %d out of range", device);
+    HIPCHK(hipSetDevice(device));
+    sgpr_model *h = new sgpr_model();
+    h->lmax = lmax; h->nmax = nmax; h->eta = eta; h->rc = rc; h->S = S; h->device = device;
+    h->species.assign(species_z, species_z + S);
+    h->radii.assign(S, 1.0);
+    for (int k = 0; k < S; k++) h->radii[k] = radii ? radii[k] : (species_z[k] == 1 ? 0.5 : 1.0);  // sesoap.py:84-99
+    h->mean_w.assign(S, 0.0);
+    h->vscale.assign(S, 1.0);
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(SGPR_E_NODEVICE, "hipStreamCreate failed"); }
+    build_pack(h);
+    h->d_pack.alloc(h->Dc, false);
+    (void)hipMemcpy(h->d_pack.p, h->h_pack.data(), sizeof(PackEntry) * h->Dc, hipMemcpyHostToDevice);
+    h->d_radii.alloc(S, false);
+    (void)hipMemcpy(h->d_radii.p, h->radii.data(), sizeof(double) * S, hipMemcpyHostToDevice);
+    h->d_vs_sqrt.alloc(S, false);
+    std::vector<double> one(S, 1.0);
+    (void)hipMemcpy(h->d_vs_sqrt.p, one.data(), sizeof(double) * S, hipMemcpyHostToDevice);
+    HarmCoef hc;
+    host_build_harm_coef(&hc);
+    upload_harm_coef(hc);
+    h->d_grid.alloc(256);
+    h->d_stat.alloc(4);
+    h->d_bin_start.alloc(8200);
+    h->d_cell_in.alloc(9);
+    *out = h;
+    return SGPR_OK;
+}
+
+static void drop_graph(sgpr_model *h)
+{
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    h->gexec = nullptr;
+}
+
+extern "C" void sgpr_destroy(sgpr_model *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    drop_graph(h);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
+                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_bin_atoms, &h->d_wrap, &h->d_nn,
+                         &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear};
+    for (auto b : ib) b->release();
+    DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
+                            &h->d_vs_sqrt, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C,
+                            &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed};
+    for (auto b : db) b->release();
+    h->d_pack.release();
+    h->d_grid.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row_slot, const int *row_nn,
+                           const int *row_off, double *Kout, double *Aw, const double *mu, double *Epart,
+                           hipStream_t st)
+{
+    GemmParams g = {};
+    g.M = M; g.N = h->m; g.K = h->Dpad;
+    g.lda = h->Dpad; g.ldb = h->Dpad; g.ldc = h->m_pad;
+    g.A = A; g.B = h->d_Pm.p; g.C = Kout;
+    g.S = h->S; g.row_off = row_off; g.col_off = h->d_qoff.p; g.k_off = nullptr;
+    g.eta = h->eta; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
+    g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
+    launch_gemm_nt(g, EPI_KERNEL, st);
+}
+
+extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const int64_t *nbr_ptr,
+                                 const int32_t *nbr_z, const double *nbr_r)
+{
+    if (!h || m < 0 || (m > 0 && (!zc || !nbr_ptr))) return fail(SGPR_E_INVALID, "sgpr_set_inducing: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    drop_graph(h);
+    h->has_mu = h->has_choli = false;
+    h->m = m;
+    h->m_pad = rup(std::max(m, 1), 16);
+    h->m_rows = rup(std::max(m, 1), 64);
+    std::vector<int> slot(m);
+    for (int q = 0; q < m; q++) {
+        slot[q] = slot_of(h, zc[q]);
+        if (slot[q] < 0) return fail(SGPR_E_SPECIES, "inducing LCE %d: Z=%d is not in the species table", q, zc[q]);
+    }
+    h->ind_perm.resize(m);
+    std::iota(h->ind_perm.begin(), h->ind_perm.end(), 0);
+    std::stable_sort(h->ind_perm.begin(), h->ind_perm.end(), [&](int a, int b) { return slot[a] < slot[b]; });
+    h->ind_slot.resize(m);
+    h->qoff.assign(h->S + 1, 0);
+    std::vector<int64_t> ptr(m + 1, 0);
+    std::vector<int> eslot;
+    std::vector<double> er;
+    std::vector<int> nn(h->m_rows, 1), dslot(h->m_rows, -2);
+    for (int k = 0; k < m; k++) {
+        const int q = h->ind_perm[k];
+        h->ind_slot[k] = slot[q];
+        dslot[k] = slot[q];
+        h->qoff[slot[q] + 1]++;
+        const int64_t a = nbr_ptr[q], b = nbr_ptr[q + 1];
+        nn[k] = (int)(b - a);
+        for (int64_t e = a; e < b; e++) {
+            const int s = slot_of(h, nbr_z[e]);
+            if (s < 0) return fail(SGPR_E_SPECIES, "inducing LCE %d: neighbour Z=%d is not in the species table", q, nbr_z[e]);
+            eslot.push_back(s);
+            er.push_back(nbr_r[3 * e]); er.push_back(nbr_r[3 * e + 1]); er.push_back(nbr_r[3 * e + 2]);
+        }
+        ptr[k + 1] = (int64_t)eslot.size();
+    }
+    for (int s = 0; s < h->S; s++) h->qoff[s + 1] += h->qoff[s];
+    if (h->d_ind_slot.alloc(h->m_rows) || h->d_ind_nn.alloc(h->m_rows) || h->d_qoff.alloc(h->S + 1) ||
+        h->d_Pm.alloc((size_t)h->m_rows * h->Dpad) || h->d_PmT.alloc((size_t)rup(h->Dpad, 64) * h->m_pad) ||
+        h->d_pm_norm.alloc(h->m_rows) || h->d_M.alloc((size_t)h->m_rows * h->m_pad) || h->d_mu.alloc(h->m_pad) ||
+        h->d_choli.alloc((size_t)h->m_rows * h->m_pad))
+        return fail(SGPR_E_NODEVICE, "hipMalloc failed (inducing set)");
+    HIPCHK(hipMemcpy(h->d_ind_slot.p, dslot.data(), sizeof(int) * h->m_rows, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_ind_nn.p, nn.data(), sizeof(int) * h->m_rows, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_qoff.p, h->qoff.data(), sizeof(int) * (h->S + 1), hipMemcpyHostToDevice));
+    if (m == 0) return SGPR_OK;
+    DevBuf<int64_t> d_ptr;
+    DevBuf<int> d_eslot;
+    DevBuf<double> d_er;
+    if (d_ptr.alloc(m + 1, false) || d_eslot.alloc(eslot.size(), false) || d_er.alloc(er.size(), false))
+        return fail(SGPR_E_NODEVICE, "hipMalloc failed (inducing environments)");
+    HIPCHK(hipMemcpy(d_ptr.p, ptr.data(), sizeof(int64_t) * (m + 1), hipMemcpyHostToDevice));
+    if (!eslot.empty()) {
+        HIPCHK(hipMemcpy(d_eslot.p, eslot.data(), sizeof(int) * eslot.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_er.p, er.data(), sizeof(double) * er.size(), hipMemcpyHostToDevice));
+    }
+    DescParams dp = {};
+    dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = m; dp.Nall = m; dp.first = 0; dp.stride = 1;
+    dp.maxnn = 0; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
+    const int rcd = launch_descriptor_forward_env(dp, d_ptr.p, d_eslot.p, d_er.p, h->d_radii.p, h->d_pack.p,
+                                                  h->d_Pm.p, h->d_pm_norm.p, h->stream);
+    if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel for (lmax,nmax,S)=(%d,%d,%d) not compiled in", h->lmax, h->nmax, h->S);
+    hipLaunchKernelGGL(transpose_kernel, dim3((h->Dpad + 31) / 32, (m + 31) / 32), dim3(32, 8), 0, h->stream, m,
+                       h->Dpad, h->d_Pm.p, h->Dpad, h->d_PmT.p, h->m_pad);
+    // K_mm (regression/gppotential.py:506): same kernel epilogue, no weights
+    gemm_kernel_pm(h, h->d_Pm.p, m, h->d_ind_slot.p, h->d_ind_nn.p, h->d_qoff.p, h->d_M.p, nullptr, nullptr, nullptr,
+                   h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    d_ptr.release(); d_eslot.release(); d_er.release();
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_kmm(sgpr_model *h, double *M)
+{
+    if (!h || !M) return fail(SGPR_E_INVALID, "sgpr_get_kmm: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int m = h->m;
+    std::vector<double> buf((size_t)h->m_rows * h->m_pad);
+    HIPCHK(hipMemcpy(buf.data(), h->d_M.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    for (int a = 0; a < m; a++)
+        for (int b = 0; b < m; b++) M[(size_t)h->ind_perm[a] * m + h->ind_perm[b]] = buf[(size_t)a * h->m_pad + b];
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_inducing_descriptors(sgpr_model *h, double *P)
+{
+    if (!h || !P) return fail(SGPR_E_INVALID, "sgpr_get_inducing_descriptors: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t row = (size_t)h->S * h->S * h->D;
+    DevBuf<double> d;
+    if (d.alloc(row * std::max(h->m, 1))) return fail(SGPR_E_NODEVICE, "hipMalloc failed");
+    launch_unpack_descriptors(h->m, h->S, h->lmax, h->nmax, h->Dc, h->Dpad, h->d_pack.p, h->d_Pm.p, d.p, h->stream);
+    std::vector<double> buf(row * h->m);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(buf.data(), d.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < h->m; k++) memcpy(P + row * h->ind_perm[k], buf.data() + row * k, sizeof(double) * row);
+    d.release();
+    return SGPR_OK;
+}
+
+static void upload_vscale(sgpr_model *h)
+{
+    std::vector<double> s(h->S);
+    for (int k = 0; k < h->S; k++) s[k] = sqrt(h->vscale[k]);
+    (void)hipMemcpy(h->d_vs_sqrt.p, s.data(), sizeof(double) * h->S, hipMemcpyHostToDevice);
+}
+
+extern "C" int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, const double *vscale,
+                                const double *choli)
+{
+    if (!h || !mu) return fail(SGPR_E_INVALID, "sgpr_set_weights: bad arguments");
+    if (h->m <= 0) return fail(SGPR_E_NOMODEL, "sgpr_set_weights: no inducing set");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int m = h->m;
+    std::vector<double> mus(h->m_pad, 0.0);
+    for (int k = 0; k < m; k++) mus[k] = mu[h->ind_perm[k]];
+    HIPCHK(hipMemcpy(h->d_mu.p, mus.data(), sizeof(double) * h->m_pad, hipMemcpyHostToDevice));
+    h->has_mu = true;
+    for (int k = 0; k < h->S; k++) {
+        h->mean_w[k] = mean_w ? mean_w[k] : 0.0;
+        h->vscale[k] = vscale ? vscale[k] : 1.0;
+    }
+    upload_vscale(h);
+    if (choli) {
+        std::vector<double> c((size_t)h->m_rows * h->m_pad, 0.0);
+        for (int a = 0; a < m; a++)
+            for (int b = 0; b < m; b++)
+                c[(size_t)a * h->m_pad + b] = choli[(size_t)h->ind_perm[a] * m + h->ind_perm[b]];
+        // K_mm is block-diagonal by species, so L and L^-1 have no cross-species entries and the
+        // stable species sort keeps each block lower-triangular.  A caller may still hand over
+        // a general matrix: detect, and only then give up the triangular trimming.
+        bool lower = true;
+        for (int a = 0; a < m && lower; a++)
+            for (int b = a + 1; b < m; b++)
+                if (c[(size_t)a * h->m_pad + b] != 0.0) { lower = false; break; }
+        h->has_choli = true;
+        h->choli_lower = lower;
+        HIPCHK(hipMemcpy(h->d_choli.p, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+    } else
+        h->has_choli = false;
+    // the mean term depends on the bound system (rank 0 carries it)
+    h->mean_energy = 0.0;
+    if (h->rank == 0)
+    for (int z : h->numbers) {
+        const int s = slot_of(h, z);
+        if (s >= 0) h->mean_energy += h->mean_w[s];
+    }
+    drop_graph(h);
+    return SGPR_OK;
+}
+
+// ---------------------------------------------------------------------------- system binding
+static int alloc_work(sgpr_model *h)
+{
+    if (h->N <= 0) return 0;
+    const int cr = h->cnt_rows;
+    int bad = 0;
+    bad |= h->d_Pn.alloc((size_t)cr * h->Dpad);
+    bad |= h->d_norm.alloc(cr);
+    bad |= h->d_C.alloc((size_t)std::max(h->cnt, 1) * h->CS);
+    bad |= h->d_shear.alloc(cr);
+    bad |= h->d_W.alloc((size_t)cr * h->Dpad);
+    bad |= h->d_csq.alloc(cr);
+    bad |= h->d_F.alloc((size_t)6 * h->N);
+    h->virpart_len = (h->cnt + 3) / 4 * 4;
+    bad |= h->d_virpart.alloc((size_t)std::max(h->virpart_len, 1) * 9);
+    bad |= h->d_packed.alloc((size_t)4 * h->N + 10);
+    if (h->m > 0) {
+        bad |= h->d_K.alloc((size_t)cr * h->m_pad);   // zero-filled: off-species entries are never written
+        bad |= h->d_Aw.alloc((size_t)cr * h->m_pad);
+        h->epart_len = ((h->m + 63) / 64) * ((std::max(h->cnt, 1) + 63) / 64);
+        bad |= h->d_Epart.alloc(h->epart_len);
+    } else
+        h->epart_len = 0;
+    return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (work arrays)") : 0;
+}
+
+static int ensure_nl(sgpr_model *h, int maxnn)
+{
+    if (maxnn <= h->maxnn && h->d_nbr_j.p) return 0;
+    h->maxnn = maxnn;
+    drop_graph(h);
+    int bad = 0;
+    bad |= h->d_nbr_j.alloc((size_t)h->N * maxnn, false);
+    bad |= h->d_nbr_shift.alloc((size_t)h->N * maxnn, false);
+    return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (neighbour list, maxnn=%d)", maxnn) : 0;
+}
+
+extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, const int32_t *pbc, int rank, int world)
+{
+    if (!h || N < 0 || (N > 0 && !numbers) || world < 1 || rank < 0 || rank >= world)
+        return fail(SGPR_E_INVALID, "sgpr_bind_system: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    std::vector<int> slot(N);
+    for (int i = 0; i < N; i++) {
+        slot[i] = slot_of(h, numbers[i]);
+        if (slot[i] < 0) return fail(SGPR_E_SPECIES, "atom %d: Z=%d is not in the model's species table", i, numbers[i]);
+    }
+    h->N = N; h->rank = rank; h->world = world;
+    h->N_rows = rup(std::max(N, 1), 64);
+    for (int k = 0; k < 3; k++) h->pbc[k] = pbc ? (pbc[k] != 0) : 1;
+    h->numbers.assign(numbers, numbers + N);
+    h->perm.resize(N);
+    std::iota(h->perm.begin(), h->perm.end(), 0);
+    std::stable_sort(h->perm.begin(), h->perm.end(), [&](int a, int b) { return slot[a] < slot[b]; });
+    h->slot_sorted.resize(N);
+    for (int i = 0; i < N; i++) h->slot_sorted[i] = slot[h->perm[i]];
+    // this rank's share: sorted atoms rank, rank+world, ... (per-species round robin, the
+    // reference's Distributer policy, descriptor/atoms.py:235-246)
+    h->cnt = N > rank ? (N - rank + world - 1) / world : 0;
+    h->cnt_rows = rup(std::max(h->cnt, 1), 64);
+    h->aoff.assign(h->S + 1, 0);
+    std::vector<int> lslot(h->cnt_rows, -1), lnn(h->cnt_rows, 1);
+    for (int il = 0; il < h->cnt; il++) {
+        const int s = h->slot_sorted[rank + il * world];
+        lslot[il] = s;
+        h->aoff[s + 1]++;
+    }
+    for (int s = 0; s < h->S; s++) h->aoff[s + 1] += h->aoff[s];
+    h->mean_energy = 0.0;
+    if (rank == 0)
+        for (int i = 0; i < N; i++) h->mean_energy += h->mean_w[slot[i]];
+    int bad = 0;
+    bad |= h->d_perm.alloc(std::max(N, 1), false);
+    bad |= h->d_slot.alloc(h->N_rows, false);
+    bad |= h->d_aoff.alloc(h->S + 1, false);
+    bad |= h->d_lslot.alloc(h->cnt_rows, false);
+    bad |= h->d_lnn.alloc(h->cnt_rows, false);
+    bad |= h->d_pos_in.alloc((size_t)3 * std::max(N, 1));
+    bad |= h->d_pos.alloc((size_t)3 * std::max(N, 1));
+    bad |= h->d_bin_of.alloc(std::max(N, 1));
+    bad |= h->d_bin_atoms.alloc(std::max(N, 1));
+    bad |= h->d_wrap.alloc((size_t)3 * std::max(N, 1));
+    bad |= h->d_nn.alloc(std::max(N, 1));
+    if (bad) return fail(SGPR_E_NODEVICE, "hipMalloc failed (system arrays)");
+    if (N > 0) {
+        HIPCHK(hipMemcpy(h->d_perm.p, h->perm.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+        std::vector<int> ss(h->N_rows, -1);
+        std::copy(h->slot_sorted.begin(), h->slot_sorted.end(), ss.begin());
+        HIPCHK(hipMemcpy(h->d_slot.p, ss.data(), sizeof(int) * h->N_rows, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(h->d_aoff.p, h->aoff.data(), sizeof(int) * (h->S + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_lslot.p, lslot.data(), sizeof(int) * h->cnt_rows, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_lnn.p, lnn.data(), sizeof(int) * h->cnt_rows, hipMemcpyHostToDevice));
+    h->maxnn = 0;
+    h->d_nbr_j.release();
+    h->d_nbr_shift.release();
+    h->warm = false;
+    return alloc_work(h);
+}
+
+extern "C" int64_t sgpr_packed_len(int N) { return 4 * (int64_t)N + 10; }
+
+// ---------------------------------------------------------------------------- one step
+static void stamp(sgpr_model *h, const char *name, hipStream_t st)
+{
+    if (!h->profile) return;
+    const size_t k = h->stage_names.size();
+    if (h->ev.size() <= k + 1) {
+        while (h->ev.size() <= k + 1) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            h->ev.push_back(e);
+        }
+    }
+    h->stage_names.push_back(name);
+    (void)hipEventRecord(h->ev[k + 1], st);
+}
+
+static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell_dev, double *packed_dev,
+                        hipStream_t st)
+{
+    const int N = h->N, cnt = h->cnt;
+    if (h->profile) {
+        h->stage_names.clear();
+        if (h->ev.empty()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            h->ev.push_back(e);
+        }
+        (void)hipEventRecord(h->ev[0], st);
+    }
+    const int nz = 6 * N;
+    hipLaunchKernelGGL(gather_pos_kernel, dim3((std::max(N, cnt) + 255) / 256), dim3(256), 0, st, N, h->d_perm.p,
+                       pos_dev, h->d_pos.p, h->d_F.p, nz, h->d_csq.p, cnt);
+    stamp(h, "gather", st);
+    NlParams np = {};
+    np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
+    for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
+    launch_neighbor_list(np, h->d_pos.p, cell_dev, h->rc, h->d_grid.p, h->d_bin_of.p, h->d_bin_start.p,
+                         h->d_bin_atoms.p, h->d_wrap.p, h->d_nn.p, h->d_lnn.p, h->d_nbr_j.p, h->d_nbr_shift.p,
+                         h->d_stat.p, st);
+    stamp(h, "neighbor_list", st);
+    DescParams dp = {};
+    dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
+    dp.stride = h->world; dp.maxnn = h->maxnn; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
+    int rcd = launch_descriptor_forward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
+                                        h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
+                                        h->d_C.p, h->d_shear.p, st);
+    if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
+    stamp(h, "descriptor_fwd", st);
+    const bool predict = h->m > 0 && h->has_mu && cnt > 0;
+    if (h->m > 0 && cnt > 0) {
+        gemm_kernel_pm(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->d_aoff.p, h->d_K.p, h->d_Aw.p,
+                       h->has_mu ? h->d_mu.p : nullptr, h->d_Epart.p, st);
+        stamp(h, "gemm_knm", st);
+    }
+    if (predict) {
+        GemmParams g = {};
+        g.M = cnt; g.N = h->Dpad; g.K = h->m_pad;
+        g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = h->Dpad;
+        g.A = h->d_Aw.p; g.B = h->d_PmT.p; g.C = h->d_W.p;
+        g.S = h->S; g.row_off = h->d_aoff.p; g.col_off = nullptr; g.k_off = h->d_qoff.p;
+        launch_gemm_nt(g, EPI_STORE, st);
+        stamp(h, "gemm_w", st);
+        rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
+                                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
+                                         h->d_C.p, h->d_shear.p, h->d_W.p, h->d_F.p, h->d_virpart.p, st);
+        if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
+        stamp(h, "descriptor_bwd", st);
+    }
+    const bool beta = h->m > 0 && h->has_choli && cnt > 0;
+    if (beta) {
+        GemmParams g = {};
+        g.M = cnt; g.N = h->m; g.K = h->m_pad;
+        g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = 0;
+        g.A = h->d_K.p; g.B = h->d_choli.p; g.C = nullptr;
+        g.S = h->S; g.row_off = h->d_aoff.p; g.col_off = nullptr; g.k_off = h->d_qoff.p;
+        g.tri = h->choli_lower ? 1 : 0;
+        g.rowsq = h->d_csq.p;
+        launch_gemm_nt(g, EPI_ROWSQ, st);
+        stamp(h, "gemm_covloss", st);
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256), dim3(256), 0, st, N, cnt, h->rank,
+                       h->world, h->d_perm.p, h->d_slot.p, h->d_F.p, h->d_F.p + 3 * (size_t)N, h->d_csq.p,
+                       beta ? 1 : 0, h->d_vs_sqrt.p, h->d_Epart.p, predict ? h->epart_len : 0, h->d_virpart.p,
+                       predict ? h->virpart_len : 0, h->mean_energy, packed_dev);
+    stamp(h, "finalize", st);
+    return SGPR_OK;
+}
+
+// run eagerly, synchronise, grow the neighbour capacity until nothing overflowed
+static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_dev, double *packed_dev,
+                       hipStream_t st)
+{
+    if (h->maxnn == 0) {
+        const int rc_ = ensure_nl(h, 64);
+        if (rc_) return rc_;
+    }
+    for (int attempt = 0; attempt < 6; attempt++) {
+        const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st);
+        if (rc_) return rc_;
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        int stat[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(stat, h->d_stat.p, sizeof(stat), hipMemcpyDeviceToHost));
+        if (stat[0] <= h->maxnn) {
+            h->nn_max_seen = stat[0];
+            return SGPR_OK;
+        }
+        if (stat[0] > 100000) return fail(SGPR_E_OVERFLOW, "neighbour count %d is unreasonable", stat[0]);
+        const int rc2 = ensure_nl(h, rup(stat[0] + stat[0] / 8 + 4, 8));
+        if (rc2) return rc2;
+    }
+    return fail(SGPR_E_OVERFLOW, "neighbour capacity kept overflowing");
+}
+
+extern "C" int sgpr_stress_from_virial(const double *v, const double *cell, double *stress6)
+{
+    if (!v || !cell || !stress6) return fail(SGPR_E_INVALID, "sgpr_stress_from_virial: bad arguments");
+    const double *c = cell;
+    double vol = fabs(c[0] * (c[4] * c[8] - c[5] * c[7]) - c[1] * (c[3] * c[8] - c[5] * c[6]) +
+                      c[2] * (c[3] * c[7] - c[4] * c[6]));
+    if (!(vol > 0.0)) vol = -2.0;  // calculator/active.py:606-609
+    const int voigt[6] = {0, 4, 8, 5, 2, 1};  // calculator/active.py:574
+    for (int k = 0; k < 6; k++) stress6[k] = v[voigt[k]] / vol;
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
+                            const double *cell, const int32_t *pbc, int rank, int world, double *energy,
+                            double *forces, double *stress, double *beta, double *cov)
+{
+    if (!h || N < 0 || !numbers || !positions || !cell) return fail(SGPR_E_INVALID, "sgpr_compute: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    bool same = (N == h->N && rank == h->rank && world == h->world && (int)h->numbers.size() == N);
+    if (same)
+        for (int i = 0; i < N && same; i++) same = h->numbers[i] == numbers[i];
+    if (same && pbc)
+        for (int k = 0; k < 3; k++) same = same && (h->pbc[k] == (pbc[k] != 0));
+    if (!same) {
+        const int rc_ = sgpr_bind_system(h, N, numbers, pbc, rank, world);
+        if (rc_) return rc_;
+    }
+    if (N == 0) {
+        if (energy) *energy = 0.0;
+        if (stress) memset(stress, 0, sizeof(double) * 6);
+        return SGPR_OK;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_pos_in.p, positions, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_cell_in.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
+    const int rc_ = run_checked(h, h->d_pos_in.p, h->d_cell_in.p, h->d_packed.p, h->stream);
+    if (rc_) return rc_;
+    h->warm = true;
+    std::vector<double> out((size_t)4 * N + 10);
+    HIPCHK(hipMemcpy(out.data(), h->d_packed.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+    if (forces) memcpy(forces, out.data(), sizeof(double) * 3 * N);
+    if (beta) memcpy(beta, out.data() + 3 * (size_t)N, sizeof(double) * N);
+    if (energy) *energy = out[4 * (size_t)N];
+    if (stress) sgpr_stress_from_virial(out.data() + 4 * (size_t)N + 1, cell, stress);
+    if (cov && h->m > 0) {
+        memset(cov, 0, sizeof(double) * (size_t)N * h->m);
+        std::vector<double> kb((size_t)h->cnt_rows * h->m_pad);
+        HIPCHK(hipMemcpy(kb.data(), h->d_K.p, sizeof(double) * kb.size(), hipMemcpyDeviceToHost));
+        for (int il = 0; il < h->cnt; il++) {
+            const int c = h->perm[h->rank + il * h->world];
+            for (int q = 0; q < h->m; q++) cov[(size_t)c * h->m + h->ind_perm[q]] = kb[(size_t)il * h->m_pad + q];
+        }
+    }
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell_dev, double *packed_dev,
+                             void *stream)
+{
+    if (!h || !positions_dev || !cell_dev || !packed_dev) return fail(SGPR_E_INVALID, "sgpr_step_dev: bad arguments");
+    if (h->N <= 0) return fail(SGPR_E_INVALID, "sgpr_step_dev: call sgpr_bind_system first");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (!h->warm) {
+        // first step after (re)binding: eager, synchronised, sizes the neighbour capacity
+        const int rc_ = run_checked(h, positions_dev, cell_dev, packed_dev, st);
+        if (rc_) return rc_;
+        h->warm = true;
+        return SGPR_OK;
+    }
+    if (!h->use_graph || h->profile) return enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+    if (!h->gexec || h->g_pos != positions_dev || h->g_cell != cell_dev || h->g_out != packed_dev || h->g_stream != st) {
+        drop_graph(h);
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+        const hipError_t e = hipStreamEndCapture(st, &graph);
+        if (rc_) { if (graph) (void)hipGraphDestroy(graph); return rc_; }
+        if (e != hipSuccess) return fail(SGPR_E_NODEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        const hipError_t e2 = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e2 != hipSuccess) { h->gexec = nullptr; return fail(SGPR_E_NODEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e2)); }
+        h->g_pos = positions_dev; h->g_cell = cell_dev; h->g_out = packed_dev; h->g_stream = st;
+    }
+    HIPCHK(hipGraphLaunch(h->gexec, st));
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_sync_check: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    int stat[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(stat, h->d_stat.p, sizeof(stat), hipMemcpyDeviceToHost));
+    if (stat[0] > h->maxnn) {
+        const int need = stat[0];
+        h->warm = false;  // next step re-sizes eagerly
+        (void)ensure_nl(h, rup(need + need / 8 + 4, 8));
+        return fail(SGPR_E_OVERFLOW, "neighbour capacity exceeded (%d); results of the last steps are invalid", need);
+    }
+    h->nn_max_seen = stat[0];
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
+{
+    if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
+    if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
+    return fail(SGPR_E_INVALID, "sgpr_set_option: unknown option %s", name);
+}
+
+// ---------------------------------------------------------------------------- inspection
+extern "C" int sgpr_get_descriptors(sgpr_model *h, double *P)
+{
+    if (!h || !P) return fail(SGPR_E_INVALID, "sgpr_get_descriptors: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t row = (size_t)h->S * h->S * h->D;
+    DevBuf<double> d;
+    if (d.alloc(row * std::max(h->cnt, 1))) return fail(SGPR_E_NODEVICE, "hipMalloc failed");
+    launch_unpack_descriptors(h->cnt, h->S, h->lmax, h->nmax, h->Dc, h->Dpad, h->d_pack.p, h->d_Pn.p, d.p, h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> buf(row * std::max(h->cnt, 1));
+    HIPCHK(hipMemcpy(buf.data(), d.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    memset(P, 0, sizeof(double) * row * h->N);
+    for (int il = 0; il < h->cnt; il++)
+        memcpy(P + row * h->perm[h->rank + il * h->world], buf.data() + row * il, sizeof(double) * row);
+    d.release();
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_neighbors(sgpr_model *h, int64_t *ptr, int32_t *j, int32_t *off)
+{
+    if (!h || !ptr) return fail(SGPR_E_INVALID, "sgpr_get_neighbors: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N = h->N;
+    std::vector<int> nn(N), nj((size_t)N * h->maxnn), ns((size_t)N * h->maxnn);
+    HIPCHK(hipMemcpy(nn.data(), h->d_nn.p, sizeof(int) * N, hipMemcpyDeviceToHost));
+    std::vector<int> inv(N);
+    for (int g = 0; g < N; g++) inv[h->perm[g]] = g;
+    ptr[0] = 0;
+    for (int c = 0; c < N; c++) {
+        const int g = inv[c];
+        const bool mine = g >= h->rank && (g - h->rank) % h->world == 0;
+        ptr[c + 1] = ptr[c] + (mine ? nn[g] : 0);
+    }
+    if (!j || !off) return SGPR_OK;
+    if (h->maxnn > 0) {
+        HIPCHK(hipMemcpy(nj.data(), h->d_nbr_j.p, sizeof(int) * nj.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ns.data(), h->d_nbr_shift.p, sizeof(int) * ns.size(), hipMemcpyDeviceToHost));
+    }
+    for (int c = 0; c < N; c++) {
+        const int g = inv[c];
+        for (int64_t t = 0; t < ptr[c + 1] - ptr[c]; t++) {
+            const size_t e = (size_t)g * h->maxnn + t;
+            j[ptr[c] + t] = h->perm[nj[e]];
+            const int code = ns[e];
+            off[3 * (ptr[c] + t)] = (int)(int8_t)(code & 0xff);
+            off[3 * (ptr[c] + t) + 1] = (int)(int8_t)((code >> 8) & 0xff);
+            off[3 * (ptr[c] + t) + 2] = (int)(int8_t)((code >> 16) & 0xff);
+        }
+    }
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_dims(sgpr_model *h, int32_t *out)
+{
+    if (!h || !out) return fail(SGPR_E_INVALID, "sgpr_get_dims: bad arguments");
+    out[0] = h->m; out[1] = h->S; out[2] = h->D; out[3] = h->Dc; out[4] = h->maxnn; out[5] = h->N;
+    out[6] = h->nn_max_seen; out[7] = h->Dpad;
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_profile(sgpr_model *h, int on)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_profile: bad arguments");
+    h->profile = on != 0;
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_stage_times(sgpr_model *h, double *ms, int cap, char *names, int names_cap)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_get_stage_times: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int n = (int)h->stage_names.size();
+    std::string all;
+    for (int k = 0; k < n; k++) {
+        float t = 0.f;
+        if (hipEventSynchronize(h->ev[k + 1]) == hipSuccess) (void)hipEventElapsedTime(&t, h->ev[k], h->ev[k + 1]);
+        if (ms && k < cap) ms[k] = t;
+        all += h->stage_names[k];
+        if (k + 1 < n) all += ";";
+    }
+    if (names && names_cap > 0) {
+        strncpy(names, all.c_str(), names_cap - 1);
+        names[names_cap - 1] = 0;
+    }
+    return n;
+}
+
+#include "solve.inc"

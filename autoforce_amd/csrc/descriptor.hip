@@ -1,0 +1,605 @@
+// descriptor.hip — per-atom SeSoap descriptor, forward and reverse, hand-written for gfx950.
+//
+// What it computes (reference: descriptor/sesoap.py:161-260, descriptor/ylm.py:113-190,
+// descriptor/cutoff.py:20-48, similarity/universal.py:100-107; reverse pass = the derivative
+// torch.autograd takes at calculator/active.py:587-599):
+//   x_j = r_j/u_j, d_j = |x_j|, g_j = [u d < rc](1 - u d/rc)^2 exp(-d^2/2), f_nj = g_j d_j^(2n)
+//   c[s][n][lm] = sum_{j in species s} f_nj R_lm(x~_j)      (x~ = sheared x, ylm.py:10-23)
+//   p[u][v][l]  = nnl sum_m c[u][l,m] c[v][l,m],  p^ = p/(|p|+eps)
+// Mapping: ONE WAVE64 PER ATOM.  Neighbours are processed in tiles of 64 (lane = neighbour),
+// staged in LDS; the c accumulation runs with lane = (n,lm) output slot (64 slots for the
+// default lmax=nmax=3) reading the staged tile; the power spectrum and its norm are formed
+// in-wave (DPP/shuffle reduction) and the packed row is written coalesced.
+//
+// Solid harmonics are evaluated in Cartesian form (polynomials in x,y,z): R_l0 = q_l0,
+// R_lm^c = sqrt2 q_lm Re(x+iy)^m, R_lm^s = sqrt2 q_lm Im(x+iy)^m with the reference's
+// recurrence coefficients for q (ylm.py:57-77,146-159).  Only sum_m c c* enters any output,
+// so this real basis is equivalent to the reference's packed complex layout.
+#include "sgpr_internal.h"
+
+__constant__ HarmCoef c_hc;
+
+void upload_harm_coef(const HarmCoef &hc) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_hc), &hc, sizeof(HarmCoef)); }
+
+#define SQRT2 1.4142135623730951
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- solid harmonics
+template <int LMAX>
+struct Harm {
+    static constexpr int L1 = LMAX + 1, LL = L1 * L1;
+    double A[L1], B[L1], q[L1][L1];
+    double x, y, z, rho;
+
+    __device__ __forceinline__ void eval(double x_, double y_, double z_, double *Y)
+    {
+        x = x_; y = y_; z = z_;
+        rho = x * x + y * y + z * z;
+        A[0] = 1.0; B[0] = 0.0;
+#pragma unroll
+        for (int m = 1; m <= LMAX; m++) {
+            A[m] = x * A[m - 1] - y * B[m - 1];
+            B[m] = y * A[m - 1] + x * B[m - 1];
+        }
+        q[0][0] = c_hc.y00;
+#pragma unroll
+        for (int l = 1; l <= LMAX; l++) {
+#pragma unroll
+            for (int m = 0; m <= l - 2; m++)
+                q[l][m] = c_hc.al[l][m] * (z * q[l - 1][m] + rho * c_hc.bl[l][m] * q[l - 2][m]);
+            q[l][l - 1] = c_hc.cl[l] * z * q[l - 1][l - 1];
+            q[l][l] = c_hc.dl[l] * q[l - 1][l - 1];
+        }
+#pragma unroll
+        for (int l = 0; l <= LMAX; l++) {
+            Y[l * l] = q[l][0];
+#pragma unroll
+            for (int m = 1; m <= l; m++) {
+                Y[l * l + 2 * m - 1] = SQRT2 * q[l][m] * A[m];
+                Y[l * l + 2 * m] = SQRT2 * q[l][m] * B[m];
+            }
+        }
+    }
+
+    // reverse pass of eval(): gY = dE/dY  ->  (gx,gy,gz) = dE/d(x,y,z); eval() must have run.
+    __device__ __forceinline__ void backward(const double *gY, double &gx, double &gy, double &gz)
+    {
+        double gq[L1][L1], gA[L1], gB[L1];
+#pragma unroll
+        for (int m = 0; m <= LMAX; m++) { gA[m] = 0.0; gB[m] = 0.0; }
+#pragma unroll
+        for (int l = 0; l <= LMAX; l++) {
+            gq[l][0] = gY[l * l];
+#pragma unroll
+            for (int m = 1; m <= l; m++) {
+                const double gc = SQRT2 * gY[l * l + 2 * m - 1], gs = SQRT2 * gY[l * l + 2 * m];
+                gq[l][m] = gc * A[m] + gs * B[m];
+                gA[m] += q[l][m] * gc;
+                gB[m] += q[l][m] * gs;
+            }
+        }
+        double gzz = 0.0, grho = 0.0;
+#pragma unroll
+        for (int l = LMAX; l >= 1; l--) {
+            gq[l - 1][l - 1] += c_hc.dl[l] * gq[l][l];
+            gzz += c_hc.cl[l] * q[l - 1][l - 1] * gq[l][l - 1];
+            gq[l - 1][l - 1] += c_hc.cl[l] * z * gq[l][l - 1];
+#pragma unroll
+            for (int m = 0; m <= l - 2; m++) {
+                const double g = c_hc.al[l][m] * gq[l][m];
+                gzz += q[l - 1][m] * g;
+                grho += c_hc.bl[l][m] * q[l - 2][m] * g;
+                gq[l - 1][m] += z * g;
+                gq[l - 2][m] += rho * c_hc.bl[l][m] * g;
+            }
+        }
+        double gxx = 0.0, gyy = 0.0;
+#pragma unroll
+        for (int m = LMAX; m >= 1; m--) {
+            gxx += gA[m] * A[m - 1] + gB[m] * B[m - 1];
+            gyy += -gA[m] * B[m - 1] + gB[m] * A[m - 1];
+            gA[m - 1] += x * gA[m] + y * gB[m];
+            gB[m - 1] += -y * gA[m] + x * gB[m];
+        }
+        gx = gxx + 2.0 * x * grho;
+        gy = gyy + 2.0 * y * grho;
+        gz = gzz + 2.0 * z * grho;
+    }
+};
+
+// ---------------------------------------------------------------- kernel arguments
+struct DescArgs {
+    int N, first, stride, maxnn, S, Dc, Dpad, CS;
+    double rc;
+    const double *pos;      // [Nall][3] (sorted order)
+    const double *cell;     // [9]
+    const int *slot;        // [Nall]
+    const double *radii;    // [S]
+    const int *nn;          // [Nall]
+    const int *nbr_j;       // [Nall][maxnn]
+    const int *nbr_shift;   // [Nall][maxnn]
+    const int64_t *env_ptr; // ENV mode: [N+1]
+    const int *env_slot;    // ENV mode
+    const double *env_r;    // ENV mode [..][3]
+    const PackEntry *pack;  // [Dc]
+    double *Pn;             // [N][Dpad]
+    double *norm;           // [N]
+    double *C;              // [N][CS]
+    int *shear;             // [N]
+    const double *W;        // backward: [N][Dpad]
+    double *Fnbr;           // backward: [Nall][3] (atomic)
+    double *Fself;          // backward: [Nall][3] (plain store, one writer)
+    double *vir_part;       // backward: [gridDim][4 waves][9]
+};
+
+// neighbour t of atom (global sorted index gi / local index ia): displacement, species slot
+template <bool ENV>
+__device__ __forceinline__ void load_neighbor(const DescArgs &a, int gi, int ia, int t, const double *pi,
+                                              const double *cell, double r[3], int &s, int &j)
+{
+    if constexpr (ENV) {
+        const int64_t e = a.env_ptr[ia] + t;
+        r[0] = a.env_r[3 * e]; r[1] = a.env_r[3 * e + 1]; r[2] = a.env_r[3 * e + 2];
+        s = a.env_slot[e];
+        j = -1;
+    } else {
+        const size_t e = (size_t)gi * a.maxnn + t;
+        j = a.nbr_j[e];
+        const int code = a.nbr_shift[e];
+        const double s0 = (double)(int)(int8_t)(code & 0xff);
+        const double s1 = (double)(int)(int8_t)((code >> 8) & 0xff);
+        const double s2 = (double)(int)(int8_t)((code >> 16) & 0xff);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            r[k] = a.pos[3 * (size_t)j + k] - pi[k] + (s0 * cell[k] + s1 * cell[3 + k] + s2 * cell[6 + k]);
+        s = a.slot[j];
+    }
+}
+
+// radial weights f_n = g d^(2n) (and dg/dd for the reverse pass)
+template <int NMAX>
+__device__ __forceinline__ void radial(double d, double u, double rc, double *f, double &g, double &dg)
+{
+    const double ud = u * d;
+    const double step = ud < rc ? 1.0 : 0.0;
+    const double qq = 1.0 - ud / rc;
+    const double cut = step * qq * qq;
+    const double dcut = step * (-2.0 * qq / rc) * u;
+    const double ex = exp(-0.5 * d * d);
+    g = cut * ex;
+    dg = dcut * ex - d * g;
+    const double rho = d * d;
+    double pw = g;
+#pragma unroll
+    for (int n = 0; n <= NMAX; n++) { f[n] = pw; pw *= rho; }
+}
+
+template <int LMAX, int NMAX>
+struct WaveLds {
+    static constexpr int L1 = LMAX + 1, N1 = NMAX + 1, LL = L1 * L1, LLP = LL + 1, NSLOT = N1 * LL;
+    // doubles per wave for the neighbour tile
+    static constexpr int TILE_D = 64 * 3 + 64 * N1 + 64 * LLP;
+};
+
+// =========================================================================== forward
+template <int LMAX, int NMAX, int ST, bool ENV>
+__global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
+{
+    using WL = WaveLds<LMAX, NMAX>;
+    constexpr int N1 = WL::N1, LL = WL::LL, LLP = WL::LLP, NSLOT = WL::NSLOT;
+    constexpr int SPL = (NSLOT + 63) / 64;
+    extern __shared__ double smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ia = blockIdx.x * 4 + wave;
+    if (ia >= a.N) return;
+    const int gi = a.first + ia * a.stride;
+    const int perwave = WL::TILE_D + ST * NSLOT + 64 / 2;  // + 64 ints
+    double *xs = smem + (size_t)wave * perwave;  // [64][3]
+    double *fl = xs + 64 * 3;                    // [64][N1]
+    double *Yl = fl + 64 * N1;                   // [64][LLP]
+    double *cl = Yl + 64 * LLP;                  // [ST][NSLOT]
+    int *sl = (int *)(cl + ST * NSLOT);          // [64]
+
+    int nn;
+    double pi[3] = {0, 0, 0}, cell[9];
+    if constexpr (ENV) {
+        nn = (int)(a.env_ptr[ia + 1] - a.env_ptr[ia]);
+    } else {
+        nn = a.nn[gi];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pi[k] = a.pos[3 * (size_t)gi + k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) cell[k] = a.cell[k];
+    }
+
+    // pass 0: does any neighbour sit inside the z cone? (ylm.py:10-23; whole environment shears)
+    bool near = false;
+    for (int t0 = 0; t0 < nn; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < nn) {
+            double r[3]; int s, j;
+            load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
+            const double u = a.radii[s];
+            const double tol = SGPR_TINY_ANGLE * fabs(r[2] / u);
+            near |= (fabs(r[0] / u) < tol) && (fabs(r[1] / u) < tol);
+        }
+    }
+    const bool shear = __any(near);
+    const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
+
+    double acc[ST][SPL];
+#pragma unroll
+    for (int s = 0; s < ST; s++)
+#pragma unroll
+        for (int k = 0; k < SPL; k++) acc[s][k] = 0.0;
+
+    for (int t0 = 0; t0 < nn; t0 += 64) {
+        const int t = t0 + lane;
+        const int cnt = min(64, nn - t0);
+        wave_sync();
+        if (t < nn) {
+            double r[3]; int s, j;
+            load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
+            const double u = a.radii[s];
+            const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
+            const double d = sqrt(x * x + y * y + z * z);
+            double f[N1], g, dg;
+            radial<NMAX>(d, u, a.rc, f, g, dg);
+            double Y[LL];
+            Harm<LMAX> h;
+            h.eval(x, y - ang * z, ang * y + z, Y);
+#pragma unroll
+            for (int n = 0; n < N1; n++) fl[lane * N1 + n] = f[n];
+#pragma unroll
+            for (int k = 0; k < LL; k++) Yl[lane * LLP + k] = Y[k];
+            sl[lane] = s;
+        }
+        wave_sync();
+        // lane = output slot (n,lm): c[s][slot] += f[t][n] * Y[t][lm]
+        for (int tt = 0; tt < cnt; tt++) {
+            const int s = __builtin_amdgcn_readfirstlane(sl[tt]);
+#pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                if (SPL * 64 == NSLOT || slot < NSLOT) {
+                    const double v = fl[tt * N1 + slot / LL] * Yl[tt * LLP + slot % LL];
+#pragma unroll
+                    for (int q = 0; q < ST; q++)
+                        if (s == q) acc[q][k] += v;
+                }
+            }
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < ST; s++)
+#pragma unroll
+        for (int k = 0; k < SPL; k++) {
+            const int slot = lane + 64 * k;
+            if (SPL * 64 == NSLOT || slot < NSLOT) {
+                cl[s * NSLOT + slot] = acc[s][k];
+                if (a.C && s < a.S) a.C[(size_t)ia * a.CS + s * NSLOT + slot] = acc[s][k];
+            }
+        }
+    wave_sync();
+    // packed power spectrum: entry e=(u<=v,l): coef * sum_{lm in l} c[u][lm] c[v][lm]
+    double nrm2 = 0.0;
+    constexpr int UMAX = ST * N1;
+    constexpr int MAXE = ((UMAX * (UMAX + 1)) / 2 * (LMAX + 1) + 8 + 63) / 64;  // covers Dpad
+    double pv[MAXE];
+#pragma unroll
+    for (int k = 0; k < MAXE; k++) {
+        const int e = lane + 64 * k;
+        pv[k] = 0.0;
+        if (e < a.Dc) {
+            const PackEntry pe = a.pack[e];
+            const double *cu = cl + (pe.u / N1) * NSLOT + (pe.u % N1) * LL + pe.l * pe.l;
+            const double *cv = cl + (pe.v / N1) * NSLOT + (pe.v % N1) * LL + pe.l * pe.l;
+            double sacc = 0.0;
+            for (int mm = 0; mm < 2 * pe.l + 1; mm++) sacc += cu[mm] * cv[mm];
+            pv[k] = sacc * pe.coef;
+            nrm2 += pv[k] * pv[k];
+        }
+    }
+    nrm2 = wave_sum(nrm2);
+    const double nrm = sqrt(nrm2);
+    const double inv = nn > 0 ? 1.0 / (nrm + SGPR_EPS) : 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXE; k++) {
+        const int e = lane + 64 * k;
+        if (e < a.Dpad) a.Pn[(size_t)ia * a.Dpad + e] = e < a.Dc ? pv[k] * inv : 0.0;
+    }
+    if (lane == 0) {
+        a.norm[ia] = nn > 0 ? nrm : 0.0;
+        if (a.shear) a.shear[ia] = shear ? 1 : 0;
+    }
+}
+
+// =========================================================================== backward
+// Per atom: G~ = dE/dp^ (packed, from the W GEMM) -> dE/dp -> dE/dc -> per-neighbour dE/dr_j
+// -> forces (F_j -= dE/dr_j, F_i += sum_j dE/dr_j) and the virial sum_j r_j (x) dE/dr_j.
+template <int LMAX, int NMAX, int ST>
+__global__ __launch_bounds__(256) void desc_bwd_kernel(DescArgs a)
+{
+    using WL = WaveLds<LMAX, NMAX>;
+    constexpr int N1 = WL::N1, LL = WL::LL, NSLOT = WL::NSLOT;
+    constexpr int SPL = (NSLOT + 63) / 64;
+    extern __shared__ double smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ia = blockIdx.x * 4 + wave;
+    const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
+    const int perwave = 2 * ST * NSLOT + a.Dpad;
+    double *cl = smem + (size_t)wave * perwave;  // [ST][NSLOT]  c
+    double *dcl = cl + ST * NSLOT;               // [ST][NSLOT]  dE/dc
+    double *gl = dcl + ST * NSLOT;               // [Dpad]       dE/dp~ * coef * (1 or 2)
+    double vir[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) vir[k] = 0.0;
+    double fself[3] = {0, 0, 0};
+    const bool active = ia < a.N;
+    const int gi = a.first + (active ? ia : 0) * a.stride;
+    const int nn = active ? a.nn[gi] : 0;
+    const double nrm = active ? a.norm[ia] : 0.0;
+    if (active && nn > 0 && nrm > 0.0) {
+        const double sden = nrm + SGPR_EPS;
+        // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
+        const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
+        double pw = 0.0;
+        for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
+        pw = wave_sum(pw);
+        const double corr = pw * sden / nrm;
+        for (int e = lane; e < a.Dc; e += 64) {
+            const PackEntry pe = a.pack[e];
+            gl[e] = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+        }
+#pragma unroll
+        for (int s = 0; s < ST; s++)
+#pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                if (SPL * 64 == NSLOT || slot < NSLOT)
+                    cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+            }
+        wave_sync();
+        // dE/dc[u][lm] = sum_v G[pair(u,v)][l] c[v][lm]
+#pragma unroll
+        for (int s = 0; s < ST; s++)
+#pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                if (SPL * 64 == NSLOT || slot < NSLOT) {
+                    const int n = slot / LL, lm = slot % LL;
+                    int l = 0;
+#pragma unroll
+                    for (int q = 1; q <= LMAX; q++) l += (lm >= q * q) ? 1 : 0;
+                    const int u = s * N1 + n;
+                    double d = 0.0;
+                    for (int v = 0; v < Ur; v++) {
+                        const int lo = min(u, v), hi = max(u, v);
+                        const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
+                        d += gl[pair * (LMAX + 1) + l] * cl[(v / N1) * NSLOT + (v % N1) * LL + lm];
+                    }
+                    dcl[s * NSLOT + slot] = d;
+                }
+            }
+        wave_sync();
+        const bool shear = a.shear[ia] != 0;
+        const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
+        double pi[3], cell[9];
+#pragma unroll
+        for (int k = 0; k < 3; k++) pi[k] = a.pos[3 * (size_t)gi + k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) cell[k] = a.cell[k];
+        for (int t0 = 0; t0 < nn; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < nn) {
+                double r[3]; int s, j;
+                load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
+                const double u = a.radii[s];
+                const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
+                const double d = sqrt(x * x + y * y + z * z);
+                double f[N1], g, dg;
+                radial<NMAX>(d, u, a.rc, f, g, dg);
+                double Y[LL], gY[LL];
+                Harm<LMAX> h;
+                h.eval(x, y - ang * z, ang * y + z, Y);
+                const double *dc = dcl + s * NSLOT;
+                double dEdd = 0.0;
+#pragma unroll
+                for (int k = 0; k < LL; k++) gY[k] = 0.0;
+                const double rho = d * d;
+                double rpow = 1.0;  // rho^n
+#pragma unroll
+                for (int n = 0; n < N1; n++) {
+                    double dEdf = 0.0;
+#pragma unroll
+                    for (int k = 0; k < LL; k++) {
+                        const double dck = dc[n * LL + k];
+                        dEdf += dck * Y[k];
+                        gY[k] += f[n] * dck;
+                    }
+                    // d f_n/dd = dg rho^n + g 2n d^(2n-1)
+                    const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow / d : 0.0);
+                    dEdd += dEdf * dfn;
+                    rpow *= rho;
+                }
+                double gxs, gys, gzs;
+                h.backward(gY, gxs, gys, gzs);
+                // inverse shear (ylm.py:203-213) + radial part, then 1/u
+                double gr[3];
+                gr[0] = (gxs + dEdd * x / d) / u;
+                gr[1] = (gys + ang * gzs + dEdd * y / d) / u;
+                gr[2] = (-ang * gys + gzs + dEdd * z / d) / u;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    fself[k] += gr[k];
+                    unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
+                }
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) vir[3 * p + q] += r[p] * gr[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) fself[k] = wave_sum(fself[k]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) vir[k] = wave_sum(vir[k]);
+    if (lane == 0) {
+        if (active)
+#pragma unroll
+            for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] = fself[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) a.vir_part[((size_t)blockIdx.x * 4 + wave) * 9 + k] = vir[k];
+    }
+}
+
+// =========================================================================== unpack (tests)
+__global__ void unpack_kernel(int n, int S, int L1, int N1, int Dc, int Dpad, const PackEntry *pack,
+                              const double *Pp, double *Pd)
+{
+    const int i = blockIdx.x;
+    const int D = N1 * N1 * L1;
+    for (int e = threadIdx.x; e < Dc; e += blockDim.x) {
+        const PackEntry pe = pack[e];
+        const int su = pe.u / N1, nu = pe.u % N1, sv = pe.v / N1, nv = pe.v % N1;
+        const double v = Pp[(size_t)i * Dpad + e] / (pe.u == pe.v ? 1.0 : SQRT2);
+        // reference layout: block [sb][sa] holds sum_m c[sa][n1] c[sb][n2] at [n1][n2][l]
+        double *base = Pd + (size_t)i * S * S * D;
+        base[((size_t)sv * S + su) * D + (nu * N1 + nv) * L1 + pe.l] = v;
+        base[((size_t)su * S + sv) * D + (nv * N1 + nu) * L1 + pe.l] = v;
+    }
+}
+
+void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,
+                               const double *Pp, double *Pdense, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(unpack_kernel, dim3(n), dim3(128), 0, st, n, S, lmax + 1, nmax + 1, Dc, Dpad, pack, Pp, Pdense);
+}
+
+// =========================================================================== dispatch
+template <int LMAX, int NMAX, int ST>
+static size_t fwd_lds_bytes()
+{
+    using WL = WaveLds<LMAX, NMAX>;
+    return sizeof(double) * 4 * (size_t)(WL::TILE_D + ST * WL::NSLOT + 32);
+}
+
+template <int LMAX, int NMAX, int ST, bool ENV>
+static int run_fwd(const DescArgs &a, hipStream_t st)
+{
+    if (a.N <= 0) return 0;
+    const size_t lds = fwd_lds_bytes<LMAX, NMAX, ST>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)desc_fwd_kernel<LMAX, NMAX, ST, ENV>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((desc_fwd_kernel<LMAX, NMAX, ST, ENV>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+    return 0;
+}
+
+template <int LMAX, int NMAX, int ST>
+static int run_bwd(const DescArgs &a, hipStream_t st)
+{
+    if (a.N <= 0) return 0;
+    using WL = WaveLds<LMAX, NMAX>;
+    const size_t lds = sizeof(double) * 4 * (size_t)(2 * ST * WL::NSLOT + a.Dpad);
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
+        (void)hipFuncSetAttribute((const void *)desc_bwd_kernel<LMAX, NMAX, ST>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = lds;
+    }
+    hipLaunchKernelGGL((desc_bwd_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+    return 0;
+}
+
+static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ? 4 : 8; }
+
+#define DISPATCH_LNS(FN, ...)                                                              \
+    do {                                                                                   \
+        const int stv = st_of(p.S);                                                        \
+        if (p.lmax == 3 && p.nmax == 3) {                                                  \
+            if (stv == 1) return FN(3, 3, 1, __VA_ARGS__);                                  \
+            if (stv == 2) return FN(3, 3, 2, __VA_ARGS__);                                  \
+            if (stv == 3) return FN(3, 3, 3, __VA_ARGS__);                                  \
+            if (stv == 4) return FN(3, 3, 4, __VA_ARGS__);                                  \
+            return FN(3, 3, 8, __VA_ARGS__);                                                \
+        }                                                                                  \
+        if (p.lmax == 2 && p.nmax == 2) {                                                  \
+            if (stv <= 2) return FN(2, 2, 2, __VA_ARGS__);                                  \
+            if (stv <= 4) return FN(2, 2, 4, __VA_ARGS__);                                  \
+            return FN(2, 2, 8, __VA_ARGS__);                                                \
+        }                                                                                  \
+        if (p.lmax == 4 && p.nmax == 4) {                                                  \
+            if (stv <= 2) return FN(4, 4, 2, __VA_ARGS__);                                  \
+            if (stv <= 4) return FN(4, 4, 4, __VA_ARGS__);                                  \
+        }                                                                                  \
+        return -6;                                                                         \
+    } while (0)
+
+static DescArgs make_args(const DescParams &p)
+{
+    DescArgs a = {};
+    a.N = p.N; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
+    a.rc = p.rc;
+    return a;
+}
+
+#define FWD_NL(L, N, S, a, st) run_fwd<L, N, S, false>(a, st)
+#define FWD_ENV(L, N, S, a, st) run_fwd<L, N, S, true>(a, st)
+#define BWD(L, N, S, a, st) run_bwd<L, N, S>(a, st)
+
+int launch_descriptor_forward(const DescParams &p, const double *pos, const double *cell, const int *slot,
+                              const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
+                              const PackEntry *pack, double *Pn, double *norm, double *C, int *shear,
+                              hipStream_t st)
+{
+    DescArgs a = make_args(p);
+    a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
+    a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = Pn; a.norm = norm; a.C = C; a.shear = shear;
+    DISPATCH_LNS(FWD_NL, a, st);
+}
+
+int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, const int *env_slot,
+                                  const double *env_r, const double *radii, const PackEntry *pack, double *Pn,
+                                  double *norm, hipStream_t st)
+{
+    DescArgs a = make_args(p);
+    a.env_ptr = env_ptr; a.env_slot = env_slot; a.env_r = env_r; a.radii = radii; a.pack = pack;
+    a.Pn = Pn; a.norm = norm; a.C = nullptr; a.shear = nullptr;
+    DISPATCH_LNS(FWD_ENV, a, st);
+}
+
+int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell, const int *slot,
+                               const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
+                               const PackEntry *pack, const double *Pn, const double *norm, const double *C,
+                               const int *shear, const double *W, double *F, double *virial, hipStream_t st)
+{
+    DescArgs a = make_args(p);
+    a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
+    a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = (double *)Pn; a.norm = (double *)norm; a.C = (double *)C;
+    a.shear = (int *)shear; a.W = W;
+    // F points at [Fnbr | Fself], virial at the per-wave partial array (see api.hip)
+    a.Fnbr = F;
+    a.Fself = F + 3 * (size_t)p.Nall;
+    a.vir_part = virial;
+    DISPATCH_LNS(BWD, a, st);
+}

@@ -1,0 +1,322 @@
+// linalg.hip — dense solve side of the SGPR model on the device (gfx950).
+//
+//   jitcholesky  regression/algebra.py:29-47     (ladder driven from api.hip::sgpr_solve)
+//   choli = L^-1 regression/gppotential.py:1234
+//   mu           regression/gppotential.py:1255-1263: Householder QR least squares of
+//                [K; sigma L^T] mu = [Y; 0]
+// Blocked right-looking Cholesky, NB = 64: panel kernel (diagonal block factorised in LDS by
+// every workgroup, one 64-row panel block solved per workgroup) + trailing update on the
+// fp64 MFMA GEMM (gemm.hip, EPI_SUBLOWER).
+#include <algorithm>
+
+#include "sgpr_internal.h"
+
+#define NB 64
+
+__global__ void add_diag_kernel(int m, const double *A, int ld, double ridge, double *out)
+{
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && j < m) out[(size_t)i * ld + j] = A[(size_t)i * ld + j] + (i == j ? ridge : 0.0);
+}
+
+void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, hipStream_t st)
+{
+    if (m <= 0) return;
+    hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256, m), dim3(256), 0, st, m, A, ld, ridge, out);
+}
+
+// One panel step at column k0.  Workgroup 0 factorises and stores the diagonal block;
+// workgroup b >= 1 computes rows [k0+nb+(b-1)*64, +64) of L21 = A21 L11^-T.
+__global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int ld, int k0, int *info)
+{
+    __shared__ double D[NB][NB + 1];
+    __shared__ double P[NB][NB + 1];
+    __shared__ int failed;
+    const int tid = threadIdx.x;
+    const int nb = min(NB, m - k0);
+    if (*info != 0) return;
+    if (tid == 0) failed = 0;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        if (tid == 0) {
+            const double d = D[j][j];
+            if (!(d > 0.0)) failed = j + 1;  // LAPACK potrf: leading minor not positive definite
+            D[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        if (failed) break;
+        const double djj = D[j][j];
+        for (int i = j + 1 + tid; i < nb; i += 256) D[i][j] /= djj;
+        __syncthreads();
+        // trailing update of the lower triangle: D[i][k] -= D[i][j] D[k][j], j < k <= i
+        const int t = nb - j - 1;
+        for (int e = tid; e < t * t; e += 256) {
+            const int i = j + 1 + e / t, k = j + 1 + e % t;
+            if (k <= i) D[i][k] -= D[i][j] * D[k][j];
+        }
+        __syncthreads();
+    }
+    if (failed) {
+        if (tid == 0 && blockIdx.x == 0) atomicCAS(info, 0, k0 + failed);
+        return;
+    }
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int i = e / nb, j = e % nb;
+            A[(size_t)(k0 + i) * ld + k0 + j] = j <= i ? D[i][j] : 0.0;
+        }
+        // zero the strictly-upper part right of the diagonal block (rows k0..k0+nb)
+        for (int i = 0; i < nb; i++)
+            for (int j = k0 + nb + tid; j < m; j += 256) A[(size_t)(k0 + i) * ld + j] = 0.0;
+        return;
+    }
+    const int r0 = k0 + nb + (blockIdx.x - 1) * NB;
+    const int nr = min(NB, m - r0);
+    if (nr <= 0) return;
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e / NB, j = e % NB;
+        P[i][j] = (i < nr && j < nb) ? A[(size_t)(r0 + i) * ld + k0 + j] : 0.0;
+    }
+    __syncthreads();
+    if (tid < nr) {
+        for (int j = 0; j < nb; j++) {
+            double v = P[tid][j];
+            for (int k = 0; k < j; k++) v -= P[tid][k] * D[j][k];
+            P[tid][j] = v / D[j][j];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nr * nb; e += 256) {
+        const int i = e / nb, j = e % nb;
+        A[(size_t)(r0 + i) * ld + k0 + j] = P[i][j];
+    }
+}
+
+int launch_cholesky_lower(int m, double *A, int ld, int *info, hipStream_t st)
+{
+    (void)hipMemsetAsync(info, 0, sizeof(int), st);
+    for (int k0 = 0; k0 < m; k0 += NB) {
+        const int nb = std::min(NB, m - k0);
+        const int below = m - k0 - nb;
+        const int nblk = 1 + (below + NB - 1) / NB;
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk), dim3(256), 0, st, m, A, ld, k0, info);
+        if (below > 0) {
+            // A22 -= L21 L21^T on the MFMA GEMM (lower tiles only)
+            GemmParams g = {};
+            g.M = below; g.N = below; g.K = (nb + 15) / 16 * 16;
+            g.lda = ld; g.ldb = ld; g.ldc = ld;
+            g.A = A + (size_t)(k0 + nb) * ld + k0;
+            g.B = g.A;
+            g.C = A + (size_t)(k0 + nb) * ld + (k0 + nb);
+            launch_gemm_nt(g, EPI_SUBLOWER, st);
+        }
+    }
+    return 0;
+}
+
+// Li = L^-1, one workgroup per 64-column block: block forward substitution
+//   X_i = L_ii^-1 (I_ic - sum_{c<=k<i} L_ik X_k)
+__global__ __launch_bounds__(256) void tril_inverse_kernel(int m, const double *L, int ld, double *Li)
+{
+    __shared__ double Ls[NB][NB + 1];
+    __shared__ double Xs[NB][NB + 1];
+    __shared__ double Ts[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int cb = blockIdx.x;
+    const int c0 = cb * NB;
+    const int nc = min(NB, m - c0);
+    const int nblk = (m + NB - 1) / NB;
+    const int ty = tid / 16, tx = tid % 16;  // 16x16 threads, 4x4 outputs each
+    // zero the block rows above the diagonal
+    for (int i = 0; i < c0; i++)
+        for (int j = tid; j < nc; j += 256) Li[(size_t)i * ld + c0 + j] = 0.0;
+    for (int ib = cb; ib < nblk; ib++) {
+        const int r0 = ib * NB, nr = min(NB, m - r0);
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+        for (int kb = cb; kb < ib; kb++) {
+            const int k0 = kb * NB;
+            __syncthreads();
+            for (int e = tid; e < NB * NB; e += 256) {
+                const int i = e / NB, j = e % NB;
+                Ls[i][j] = (i < nr) ? L[(size_t)(r0 + i) * ld + k0 + j] : 0.0;
+                Xs[i][j] = (j < nc) ? Li[(size_t)(k0 + i) * ld + c0 + j] : 0.0;
+            }
+            __syncthreads();
+            for (int k = 0; k < NB; k++) {
+                double a4[4], b4[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) a4[a] = Ls[ty * 4 + a][k];
+#pragma unroll
+                for (int b = 0; b < 4; b++) b4[b] = Xs[k][tx * 4 + b];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) acc[a][b] += a4[a] * b4[b];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int i = ty * 4 + a, j = tx * 4 + b;
+                Ts[i][j] = ((ib == cb && i == j) ? 1.0 : 0.0) - acc[a][b];
+            }
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            Ls[i][j] = (i < nr && j < nr) ? L[(size_t)(r0 + i) * ld + r0 + j] : (i == j ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < NB) {
+            for (int r = 0; r < nr; r++) {
+                double v = Ts[r][tid];
+                for (int k = 0; k < r; k++) v -= Ls[r][k] * Xs[k][tid];
+                Xs[r][tid] = v / Ls[r][r];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nr * nc; e += 256) {
+            const int i = e / nc, j = e % nc;
+            Li[(size_t)(r0 + i) * ld + c0 + j] = Xs[i][j];
+        }
+        __threadfence_block();
+    }
+}
+
+void launch_tril_inverse(int m, const double *L, int ld, double *Li, hipStream_t st)
+{
+    if (m <= 0) return;
+    hipLaunchKernelGGL(tril_inverse_kernel, dim3((m + NB - 1) / NB), dim3(256), 0, st, m, L, ld, Li);
+}
+
+// ------------------------------------------------------------------ Householder QR least squares
+// scal[0] = 2/(v.v), w[0..cols) zeroed; v stored for rows >= k; A[k][k] <- R_kk; y updated.
+__global__ __launch_bounds__(1024) void qr_house_kernel(int rows, int cols, int k, double *A, double *y, double *v,
+                                                         double *w, double *scal)
+{
+    __shared__ double red[1024];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = k + tid; i < rows; i += 1024) {
+        const double a = A[(size_t)i * cols + k];
+        s += a * a;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const double nrm = sqrt(red[0]);
+    __syncthreads();
+    const double akk = A[(size_t)k * cols + k];
+    const double alpha = akk > 0.0 ? -nrm : nrm;
+    double vv = 0.0, vy = 0.0;
+    for (int i = k + tid; i < rows; i += 1024) {
+        const double vi = A[(size_t)i * cols + k] - (i == k ? alpha : 0.0);
+        v[i] = vi;
+        vv += vi * vi;
+        vy += vi * y[i];
+    }
+    red[tid] = vv;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    vv = red[0];
+    __syncthreads();
+    red[tid] = vy;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    vy = red[0];
+    const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
+    for (int i = k + tid; i < rows; i += 1024) y[i] -= sc * vy * v[i];
+    for (int j = tid; j < cols; j += 1024) w[j] = 0.0;
+    if (tid == 0) {
+        scal[0] = sc;
+        A[(size_t)k * cols + k] = alpha;
+    }
+}
+
+// w[j] += sum_{i in chunk} v_i A[i][j], j > k
+__global__ __launch_bounds__(256) void qr_dot_kernel(int rows, int cols, int k, const double *A, const double *v,
+                                                     double *w, int rchunk)
+{
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = k + 1 + blockIdx.x * 64 + tx;
+    const int i0 = k + blockIdx.y * rchunk;
+    const int i1 = min(rows, i0 + rchunk);
+    double s = 0.0;
+    if (j < cols)
+        for (int i = i0 + ty; i < i1; i += 4) s += v[i] * A[(size_t)i * cols + j];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && j < cols) unsafeAtomicAdd(&w[j], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+// A[i][j] -= scal v_i w_j for i >= k (i > k for the column k itself is left as is), j > k
+__global__ __launch_bounds__(256) void qr_update_kernel(int rows, int cols, int k, double *A, const double *v,
+                                                        const double *w, const double *scal, int rchunk)
+{
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = k + 1 + blockIdx.x * 64 + tx;
+    const int i0 = k + blockIdx.y * rchunk;
+    const int i1 = min(rows, i0 + rchunk);
+    if (j >= cols) return;
+    const double sw = scal[0] * w[j];
+    for (int i = i0 + ty; i < i1; i += 4) A[(size_t)i * cols + j] -= sw * v[i];
+}
+
+__global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const double *A, const double *y, double *x)
+{
+    __shared__ double red[1024];
+    __shared__ double xs[2048];
+    const int tid = threadIdx.x;
+    for (int k = cols - 1; k >= 0; k--) {
+        double s = 0.0;
+        for (int j = k + 1 + tid; j < cols; j += 1024) s += A[(size_t)k * cols + j] * xs[j];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            xs[k] = (y[k] - red[0]) / A[(size_t)k * cols + k];
+            x[k] = xs[k];
+        }
+        __syncthreads();
+    }
+}
+
+int launch_lstsq_qr(int rows, int cols, double *A, double *y, double *x, double *work, hipStream_t st)
+{
+    if (cols > 2048 || rows < cols) return -1;
+    double *v = work, *w = work + rows, *scal = w + cols;
+    for (int k = 0; k < cols; k++) {
+        hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, rows, cols, k, A, y, v, w, scal);
+        const int ncol = cols - k - 1;
+        if (ncol > 0) {
+            const int nrow = rows - k;
+            const int rchunk = 256;
+            dim3 grid((ncol + 63) / 64, (nrow + rchunk - 1) / rchunk);
+            hipLaunchKernelGGL(qr_dot_kernel, grid, dim3(256), 0, st, rows, cols, k, A, v, w, rchunk);
+            hipLaunchKernelGGL(qr_update_kernel, grid, dim3(256), 0, st, rows, cols, k, A, v, w, scal, rchunk);
+        }
+    }
+    hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, A, y, x);
+    return 0;
+}

@@ -1,0 +1,123 @@
+// sgpr_internal.h — shared declarations of the gfx950 SGPR evaluator (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#define SGPR_MAX_S 8        // species slots supported by the compiled kernels
+#define SGPR_MAX_L 4        // lmax supported
+#define SGPR_MAX_N 4        // nmax supported
+#define SGPR_EPS 2.220446049250313e-16  // torch.finfo(float64).eps (descriptor/sesoap.py:250)
+#define SGPR_TINY_ANGLE 1e-2            // descriptor/ylm.py:10
+
+// Coefficients of the solid-harmonic recurrences (descriptor/ylm.py:57-77), fp64, host-built.
+struct HarmCoef {
+    double y00;
+    double al[SGPR_MAX_L + 1][SGPR_MAX_L + 1];
+    double bl[SGPR_MAX_L + 1][SGPR_MAX_L + 1];
+    double cl[SGPR_MAX_L + 1];
+    double dl[SGPR_MAX_L + 1];
+};
+
+// Packed power-spectrum layout.  u = s*(nmax+1)+n indexes (species, radial) channels,
+// U = S*(nmax+1).  p[u][v][l] is symmetric in (u,v) (descriptor/sesoap.py:195-203), so the
+// device keeps only u<=v, scaled by sqrt(2) off the diagonal: dot products and norms of
+// packed rows equal those of the reference's dense S*S*(nmax+1)^2*(lmax+1) rows.
+// Entry e = pair(u,v)*(lmax+1)+l ; pair(u,v) = u*U - u*(u-1)/2 + (v-u).
+struct PackEntry {
+    int16_t u, v;   // channel indices, u <= v
+    int16_t l;      // angular index
+    int16_t pad;
+    double coef;    // nnl[n_u][n_v][l] * (u==v ? 1 : sqrt(2))
+};
+
+struct DevModel;  // defined in api.hip
+
+// ---- launchers (each enqueues on `st`, never synchronises) -------------------------------
+struct NlParams {
+    int N;            // all atoms (binned)
+    int first, stride, count; // lists are built for sorted atoms first + k*stride, k < count
+    int pbc[3];
+    int maxnn;        // capacity per atom
+};
+
+// scratch: grid (>= 128 B), bin_of[N], bin_start[8193], bin_atoms[N], wrap[N][3], stat[4]
+void launch_neighbor_list(const NlParams &p, const double *pos, const double *cell, double rc, void *grid,
+                          int *bin_of, int *bin_start, int *bin_atoms, int *wrap, int *nn /*[N] by sorted index*/,
+                          int *nn_local /*[count]*/, int *nbr_j, int *nbr_shift, int *stat, hipStream_t st);
+
+struct DescParams {
+    int lmax, nmax, S;
+    int N;            // atoms in this launch
+    int Nall;         // all atoms of the frame
+    int first, stride; // local atom ia <-> sorted global index first + ia*stride (rank, world)
+    int maxnn;
+    int Dc, Dpad;     // packed row length and padded stride
+    int CS;           // c stride per atom = S*(nmax+1)*(lmax+1)^2
+    double rc;
+};
+
+int launch_descriptor_forward(const DescParams &p, const double *pos, const double *cell,
+                              const int *slot /*[Nall]*/, const double *radii, const int *nn,
+                              const int *nbr_j, const int *nbr_shift, const PackEntry *pack,
+                              double *Pn /*[N][Dpad]*/, double *norm /*[N]*/, double *C /*[N][CS]*/,
+                              int *shear /*[N]*/, hipStream_t st);
+
+// explicit-environment form for the inducing set: CSR of neighbour vectors instead of a NL
+int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, const int *env_slot,
+                                  const double *env_r, const double *radii, const PackEntry *pack,
+                                  double *Pn, double *norm, hipStream_t st);
+
+int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell,
+                               const int *slot, const double *radii, const int *nn, const int *nbr_j,
+                               const int *nbr_shift, const PackEntry *pack, const double *Pn,
+                               const double *norm, const double *C, const int *shear,
+                               const double *W /*[N][Dpad] dE/dp-hat*/, double *F /*[Nall][3]*/,
+                               double *virial /*[9]*/, hipStream_t st);
+
+// Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
+void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,
+                               const double *Pp, double *Pdense, hipStream_t st);
+
+// ---- fp64 MFMA GEMM family (C = A * B^T, both operands row-major with K contiguous) --------
+enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3 };
+
+struct GemmParams {
+    int M, N, K;          // C is M x N, reduction K
+    int lda, ldb, ldc;
+    const double *A, *B;
+    double *C;
+    // species structure (sorted operands): row r of A belongs to species block
+    // rowblk(r); tiles outside the allowed ranges are skipped / their K loop trimmed.
+    int S;
+    const int *row_off;   // [S+1] offsets of species blocks along M  (device)
+    const int *col_off;   // [S+1] offsets of species blocks along N  (device), may be null
+    const int *k_off;     // [S+1] offsets of species blocks along K  (device), may be null
+    int tri;              // EPI_ROWSQ: B is lower-triangular (k <= col)
+    // EPI_KERNEL extras
+    double eta;
+    const double *mu;     // [N]
+    const int *row_nn;    // [M] neighbour counts (lone-atom term), may be null => all > 0
+    const int *col_nn;    // [N]
+    double *Aw;           // [M][ldc]  mu_q * eta * dot^(eta-1) (masked)
+    double *Esum;         // [grid blocks] per-block energy partials (plain stores), may be null
+    const int *row_slot;  // [M] species slot per row (EPI_KERNEL)
+    const int *col_slot;  // [N] species slot per column
+    // EPI_ROWSQ extras
+    double *rowsq;        // [M] accumulators (atomicAdd)
+};
+void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st);
+
+// ---- dense solve side ---------------------------------------------------------------------
+// All on one stream, m x m row-major with leading dimension ld.
+int launch_cholesky_lower(int m, double *A /*in: M+ridge I, out: L (lower, upper zeroed)*/, int ld,
+                          int *info /*device: 0 ok else failing pivot+1*/, hipStream_t st);
+void launch_tril_inverse(int m, const double *L, int ld, double *Li, hipStream_t st);
+void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, hipStream_t st);
+int launch_lstsq_qr(int rows, int cols, double *A /*[rows][cols] overwritten*/, double *y /*[rows] overwritten*/,
+                    double *x /*[cols]*/, double *work, hipStream_t st);
+
+void host_build_harm_coef(HarmCoef *hc);
+void upload_harm_coef(const HarmCoef &hc);

@@ -1,0 +1,188 @@
+"""Host-side mirror of the reference's model objects for the SGPR predict/solve hot path.
+
+  Local      <- theforce/descriptor/atoms.py:36-55   (one local chemical environment, LCE)
+  SGPRModel  <- theforce/regression/gppotential.py:453-1175 PosteriorPotential state
+               (X, M, mu, choli, ridge, _vscale, mean) + the default kernel of
+               theforce/calculator/active.py:28-38 (SeSoapKernel(lmax,nmax,exponent,cutoff,
+               radii=DefaultRadii())).
+All numerics run in libsgpr_hip.so (HIP, gfx950) through the C ABI; this file only marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f64, i32, i64, ptr
+
+
+class Local:
+    """An LCE: central atomic number, neighbour numbers `b` and displacement vectors `r`
+    (= x_j - x_i + off.cell), as theforce/descriptor/atoms.py:36-55 (`number`, `_b`, `_r`)."""
+
+    def __init__(self, number, b, r):
+        self.number = int(number)
+        self._b = i32(b).reshape(-1)
+        self._r = f64(r).reshape(-1, 3)
+        if len(self._b) != len(self._r):
+            raise ValueError("Local: len(b) != len(r)")
+
+    def __repr__(self):
+        return f"Local(Z={self.number}, nn={len(self._b)})"
+
+
+def default_radii(species):
+    """DefaultRadii (theforce/descriptor/sesoap.py:84-99): 0.5 for H, else 1.0."""
+    return np.array([0.5 if int(z) == 1 else 1.0 for z in species])
+
+
+class SGPRModel:
+    def __init__(self, lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, radii=None, device=0):
+        if species is None or len(species) == 0:
+            raise ValueError("SGPRModel needs the species table (atomic numbers the model may meet)")
+        self.lmax, self.nmax, self.exponent, self.cutoff = int(lmax), int(nmax), float(exponent), float(cutoff)
+        self.species = [int(z) for z in species]
+        self.radii = default_radii(self.species) if radii is None else f64(radii)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        lib = _lib.load()
+        check(lib.sgpr_create(self.lmax, self.nmax, self.exponent, self.cutoff, len(self.species),
+                              ptr(i32(self.species)), ptr(f64(self.radii)), self.device, C.byref(self._h)))
+        self.X = []
+        self.mu = None
+        self.choli = None
+        self.ridge = 0.0
+        self.sigma = None
+        self.mean = {z: 0.0 for z in self.species}  # AutoMean weights (gppotential.py:200-231)
+        self._vscale = {}
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().sgpr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ------------------------------------------------------------------ inducing set
+    def set_inducing(self, X):
+        """model.X = inducing LCEs; builds descriptors and K_mm on the device
+        (gppotential.py:484-509 set_data: self.M = kern(X, X))."""
+        self.X = list(X)
+        m = len(self.X)
+        zc = i32([x.number for x in self.X])
+        nptr = i64(np.concatenate([[0], np.cumsum([len(x._b) for x in self.X])]))
+        nz = i32(np.concatenate([x._b for x in self.X] + [np.zeros(0, np.int32)]))
+        nr = f64(np.concatenate([x._r for x in self.X] + [np.zeros((0, 3))]))
+        check(_lib.load().sgpr_set_inducing(self._h, m, ptr(zc), ptr(nptr), ptr(nz), ptr(nr)))
+        self.mu = None
+        self.choli = None
+
+    @property
+    def m(self):
+        return len(self.X)
+
+    @property
+    def M(self):
+        out = np.zeros((self.m, self.m))
+        check(_lib.load().sgpr_get_kmm(self._h, ptr(out)))
+        return out
+
+    @property
+    def dims(self):
+        out = np.zeros(8, np.int32)
+        check(_lib.load().sgpr_get_dims(self._h, ptr(out)))
+        return dict(m=int(out[0]), S=int(out[1]), D=int(out[2]), Dc=int(out[3]), maxnn=int(out[4]), N=int(out[5]),
+                    nn_max=int(out[6]), Dpad=int(out[7]))
+
+    def inducing_descriptors(self):
+        S, D = len(self.species), (self.nmax + 1) ** 2 * (self.lmax + 1)
+        out = np.zeros((self.m, S, S, D))
+        check(_lib.load().sgpr_get_inducing_descriptors(self._h, ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ weights
+    def _table(self, d, default):
+        return f64([d.get(z, default) if d is not None else default for z in self.species])
+
+    def set_weights(self, mu, mean=None, vscale=None, choli=None):
+        """Install mu / AutoMean weights / _vscale / choli (gppotential.py:548-605,644-649)."""
+        self.mu = f64(mu).copy()
+        if mean is not None:
+            self.mean.update({int(z): float(w) for z, w in mean.items()})
+        if vscale is not None:
+            self._vscale = {int(z): float(v) for z, v in vscale.items()}
+        self.choli = None if choli is None else f64(choli).copy()
+        vs = f64([self._vscale.get(z, np.inf) for z in self.species]) if self._vscale else None
+        check(_lib.load().sgpr_set_weights(self._h, ptr(self.mu), ptr(self._table(self.mean, 0.0)), ptr(vs),
+                                           ptr(self.choli)))
+
+    def solve(self, K, Y, noise=0.01):
+        """make_munu (gppotential.py:548-605 -> _regression :1204-1339, optimize=False) on the
+        device: jitcholesky(M), choli = L^-1, mu = lstsq([K; sigma L^T], [Y; 0])."""
+        K = f64(K).reshape(-1, self.m)
+        Y = f64(Y).reshape(-1)
+        mu, choli = np.zeros(self.m), np.zeros((self.m, self.m))
+        ridge, sigma = C.c_double(0), C.c_double(0)
+        code = _lib.load().sgpr_solve(self._h, len(K), ptr(K), ptr(Y), float(noise), ptr(mu), ptr(choli),
+                                      C.addressof(ridge), C.addressof(sigma))
+        if code == _lib.E_NOT_PD:
+            raise RuntimeError("cholesky was not successful!")  # theforce/regression/algebra.py:45-46
+        check(code)
+        self.mu, self.choli, self.ridge, self.sigma = mu, choli, ridge.value, sigma.value
+        self.make_vscale()
+        return mu
+
+    def make_vscale(self):
+        out = np.zeros(len(self.species))
+        check(_lib.load().sgpr_make_vscale(self._h, ptr(out)))
+        self._vscale = {z: float(v) for z, v in zip(self.species, out) if np.isfinite(v)}
+        return self._vscale
+
+    # ------------------------------------------------------------------ prediction
+    def predict(self, numbers, positions, cell, pbc, rank=0, world=1, cov=False, beta=True):
+        """One pass of the hot path (calculator/active.py:425-502): returns a dict with energy,
+        forces [N,3], stress [6], and optionally beta [N] (covloss) and cov [N,m]."""
+        numbers = i32(numbers)
+        N = len(numbers)
+        positions = f64(positions).reshape(N, 3)
+        cell = f64(np.asarray(cell, float).reshape(3, 3))
+        pbc = i32(np.asarray(pbc, bool).astype(np.int32))
+        E = C.c_double(0)
+        F = np.zeros((N, 3))
+        stress = np.zeros(6)
+        b = np.zeros(N) if beta else None
+        K = np.zeros((N, self.m)) if cov else None
+        check(_lib.load().sgpr_compute(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), rank, world,
+                                       C.addressof(E), ptr(F), ptr(stress), ptr(b), ptr(K)))
+        return dict(energy=E.value, forces=F, stress=stress, beta=b, cov=K)
+
+    def descriptors(self, N):
+        S, D = len(self.species), (self.nmax + 1) ** 2 * (self.lmax + 1)
+        out = np.zeros((N, S, S, D))
+        check(_lib.load().sgpr_get_descriptors(self._h, ptr(out)))
+        return out
+
+    def neighbors(self, N):
+        p = np.zeros(N + 1, np.int64)
+        check(_lib.load().sgpr_get_neighbors(self._h, ptr(p), None, None))
+        j = np.zeros(int(p[-1]), np.int32)
+        off = np.zeros((int(p[-1]), 3), np.int32)
+        check(_lib.load().sgpr_get_neighbors(self._h, ptr(p), ptr(j), ptr(off)))
+        return p, j, off
+
+    def profile(self, on=True):
+        check(_lib.load().sgpr_profile(self._h, int(bool(on))))
+
+    def stage_times(self):
+        ms = np.zeros(32)
+        names = C.create_string_buffer(1024)
+        n = _lib.load().sgpr_get_stage_times(self._h, ptr(ms), 32, C.addressof(names), 1024)
+        return dict(zip(names.value.decode().split(";"), ms[:n])) if n > 0 else {}

@@ -1,0 +1,179 @@
+/*
+ * sgpr_hip.h — C ABI of libsgpr_hip.so: MI355X-native (gfx950) SGPR force-field evaluator.
+ *
+ * Drop-in boundary for AutoForce's predict hot path.  The reference has no
+ * FFI for this path (it is pure Python/torch); each entry point below names the reference
+ * interface it replaces (file:line under /root/reference/theforce).  A Python `Calculator`
+ * binds these with ctypes (autoforce_amd/_lib.py; INTEGRATION.md shows the reference-side
+ * stub).  Conventions:
+ *   - every function returns an int status: 0 = ok, <0 = error (SGPR_E_*);
+ *     sgpr_last_error() returns a static message for the calling thread's last failure;
+ *   - all arrays are caller-allocated, row-major, fp64 / int32 unless stated;
+ *   - `*_dev` variants take DEVICE pointers and a HIP stream and never synchronise;
+ *     the plain variants take HOST pointers, copy, and synchronise before returning;
+ *   - a handle is thread-compatible (one thread at a time), not re-entrant;
+ *   - units: Angstrom, eV (as ASE), stress in eV/A^3, Voigt order xx,yy,zz,yz,xz,xy.
+ * There is no CPU fallback: every entry point fails with SGPR_E_NODEVICE if no gfx950
+ * device is usable.
+ */
+#ifndef SGPR_HIP_H
+#define SGPR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgpr_model sgpr_model;
+
+enum {
+    SGPR_OK = 0,
+    SGPR_E_INVALID = -1,   /* bad argument */
+    SGPR_E_NODEVICE = -2,  /* no usable HIP device / HIP runtime error */
+    SGPR_E_NOMODEL = -3,   /* inducing set / weights not set ("you forgot to assign a DFT calculator!", calculator/active.py:429-430) */
+    SGPR_E_SPECIES = -4,   /* an atomic number is missing from the model's species table */
+    SGPR_E_NOT_PD = -5,    /* "cholesky was not successful!" (regression/algebra.py:45-46) */
+    SGPR_E_UNSUPPORTED = -6, /* (lmax,nmax,S) combination not compiled in */
+    SGPR_E_OVERFLOW = -7   /* internal capacity exceeded after retry */
+};
+
+/* Static description of the last error on this thread. */
+const char *sgpr_last_error(void);
+
+/* Library/ABI version (major*1000+minor). */
+int sgpr_version(void);
+
+/* Number of usable gfx950 devices (0 if none; never initialises a context). */
+int sgpr_device_count(void);
+
+/*
+ * Create a model = kernel hyper-parameters + species table.
+ * Replaces: calculator/active.py:28-38 default_kernel(lmax,nmax,exponent,cutoff) ->
+ *   similarity/sesoap.py:10-24 SeSoapKernel(lmax,nmax,exponent,cutoff,radii=DefaultRadii())
+ *   and descriptor/sesoap.py:102-135 SeSoap.__init__ (nnl table, radii).
+ * species_z[S]: atomic numbers the model knows (the reference's 120-wide wildcard table,
+ *   sesoap.py:134, restricted to those that occur); radii[S]: length unit per species
+ *   (sesoap.py:84-99; DefaultRadii = 0.5 for H, 1.0 otherwise).
+ */
+int sgpr_create(int lmax, int nmax, double eta, double rc, int S, const int32_t *species_z,
+                const double *radii, int device, sgpr_model **out);
+void sgpr_destroy(sgpr_model *h);
+
+/*
+ * Set the inducing set X (m local chemical environments) and build their descriptors on
+ * the device, plus K_mm.
+ * Replaces: descriptor/atoms.py:36-59 Local(...).stage -> similarity/universal.py:100-107
+ *   precalculate for every x in model.X, and regression/gppotential.py:506 / :764-768
+ *   M = kern(X, X).
+ * zc[m] central atomic numbers; nbr_ptr[m+1] CSR offsets into nbr_z[] / nbr_r[][3]
+ * (neighbour atomic numbers and displacement vectors r_j - r_i, as Local._b / Local._r).
+ * The library sorts X by species internally; all m-sized inputs/outputs of this API stay in
+ * the CALLER's order.
+ */
+int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const int64_t *nbr_ptr,
+                      const int32_t *nbr_z, const double *nbr_r);
+
+/* K_mm in caller order, [m][m] (regression/gppotential.py:506 self.M). */
+int sgpr_get_kmm(sgpr_model *h, double *M);
+
+/* Dense p-hat of the inducing LCEs in the reference's layout [m][S][S][D],
+ * D=(nmax+1)^2(lmax+1), block [sb][sa] flattened [n][n'][l] (descriptor/sesoap.py:195-203,
+ * :254-258 COO block (species[b], species[a])). Test/inspection export. */
+int sgpr_get_inducing_descriptors(sgpr_model *h, double *P);
+
+/*
+ * Set the regression state used by prediction.
+ * Replaces: regression/gppotential.py:548-605 make_munu outputs (mu, choli),
+ *   :219-227 AutoMean weights, :644-649 _vscale.
+ * mu[m]; mean_w[S] per-species constant energy (may be NULL = 0); vscale[S] (may be NULL =
+ * 1; use +inf for species with no inducing point, calculator/active.py:795-800);
+ * choli[m][m] = L^-1 lower-triangular, caller order (may be NULL: beta is then not computed).
+ */
+int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, const double *vscale,
+                     const double *choli);
+
+/*
+ * Solve side on the device (regression/gppotential.py:1204-1339 _regression with
+ * optimize=False; regression/algebra.py:29-47 jitcholesky):
+ *   L, ridge = jitcholesky(K_mm); choli = L^-1; sigma = noise0*0.99*mean(diag K_mm);
+ *   mu = argmin |[K; sigma L^T] mu - [Y; 0]|, K = [Ke;Kf;Kv] (rows x m, caller order).
+ * On success installs mu/choli in the handle (as sgpr_set_weights) and returns them.
+ * Returns SGPR_E_NOT_PD when the jitter ladder is exhausted.
+ */
+int sgpr_solve(sgpr_model *h, int rows, const double *K, const double *Y, double noise0,
+               double *mu_out, double *choli_out, double *ridge_out, double *sigma_out);
+
+/* vscale[S] = mean_{q: Z_q = z} mu_q (K_mm mu)_q (regression/gppotential.py:644-649);
+ * +inf where a species has no inducing point. Installs it in the handle as well. */
+int sgpr_make_vscale(sgpr_model *h, double *vscale_out);
+
+/*
+ * One prediction = one MD step of the hot path.
+ * Replaces: calculator/active.py:425-502 ActiveCalculator.calculate ->
+ *   descriptor/atoms.py:384-413 TorchAtoms.update (neighbour list :348-363, Local :365-382,
+ *   descriptors sesoap.py:161-260), regression/gppotential.py:63-84 K_nm,
+ *   calculator/active.py:548-611 energy / autograd forces / stress, :781-804 covloss.
+ * Inputs (host): numbers[N], positions[N][3], cell[3][3] (rows = lattice vectors), pbc[3].
+ * shard: atoms are dealt to `world` ranks; this call evaluates rank `rank`'s share only and
+ *   returns PARTIAL sums (energy without the mean term on rank != 0, forces on all N atoms
+ *   from this rank's LCEs, beta zero outside the share) to be summed over ranks
+ *   (calculator/active.py:562,600-602,770-777).  world = 1 for a single process.
+ * Outputs (host, any may be NULL): energy[1]; forces[N][3]; stress[6]; beta[N] =
+ *   covloss (already scaled by sqrt(vscale)); cov[N][m] = K_nm rows in caller order (zero
+ *   rows outside the share).
+ */
+int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
+                 const double *cell, const int32_t *pbc, int rank, int world, double *energy,
+                 double *forces, double *stress, double *beta, double *cov);
+
+/*
+ * Device-resident form for MD loops and benchmarks: no host copies, no synchronisation.
+ * sgpr_bind_system fixes N, numbers, pbc and the sharding (host arrays; may be called again
+ * when they change); sgpr_step_dev consumes DEVICE positions[N][3] + cell[9] and fills the
+ * DEVICE buffer `packed` (length sgpr_packed_len(N) doubles):
+ *   packed[0..3N)      forces (partial over ranks)
+ *   packed[3N..4N)     beta   (this rank's share, 0 elsewhere)
+ *   packed[4N]         energy (partial; mean term added on rank 0 only)
+ *   packed[4N+1..+9)   virial sum_pairs r (x) dE/dr (partial), row-major 3x3
+ * i.e. exactly what one all-reduce(SUM) over ranks must combine (the reference's four
+ * collectives calculator/active.py:562,601,602,777 fused into one buffer).
+ * `stream` is a hipStream_t passed as void*.  The step is captured into a HIP graph on first
+ * use and replayed afterwards.
+ */
+int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, const int32_t *pbc, int rank,
+                     int world);
+int64_t sgpr_packed_len(int N);
+int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell_dev,
+                  double *packed_dev, void *stream);
+/* Synchronise `stream` (NULL = the handle's own) and verify that no step since the last
+ * check overflowed the neighbour-list capacity.  Returns SGPR_E_OVERFLOW if one did (those
+ * steps' results are invalid; capacity has been grown, the next step re-sizes eagerly). */
+int sgpr_sync_check(sgpr_model *h, void *stream);
+/* Options: "graph" = 0/1 (replay sgpr_step_dev from a captured HIP graph; default 1). */
+int sgpr_set_option(sgpr_model *h, const char *name, int value);
+/* stress[6] (Voigt, eV/A^3) from a (summed) packed buffer on the host:
+ * calculator/active.py:604-610, volume = |det cell| or -2 for a rank-deficient cell. */
+int sgpr_stress_from_virial(const double *virial9, const double *cell, double *stress6);
+
+/* Inspection/test exports for the last sgpr_compute / sgpr_step_dev on this handle.
+ * p: dense p-hat [N][S][S][D] in the reference layout (see sgpr_get_inducing_descriptors).
+ * nl: neighbour list in CSR form; call with j == NULL to get only ptr[N+1]. */
+int sgpr_get_descriptors(sgpr_model *h, double *P);
+int sgpr_get_neighbors(sgpr_model *h, int64_t *ptr, int32_t *j, int32_t *off);
+
+/* Model dimensions, out[8]: out[0]=m, out[1]=S, out[2]=D (dense per block), out[3]=Dc (packed
+ * row length used on the device), out[4]=neighbour capacity per atom, out[5]=N bound,
+ * out[6]=largest neighbour count seen at the last checked step, out[7]=padded row stride. */
+int sgpr_get_dims(sgpr_model *h, int32_t *out);
+
+/* Per-kernel device timings (ms) of the last profiled step; enables HIP-event timing
+ * around each stage when `on` != 0 (adds synchronisation: never leave on in production).
+ * names: semicolon-separated stage names; returns the number of stages. */
+int sgpr_profile(sgpr_model *h, int on);
+int sgpr_get_stage_times(sgpr_model *h, double *ms, int cap, char *names, int names_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGPR_HIP_H */
