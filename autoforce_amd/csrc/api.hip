@@ -89,7 +89,8 @@ struct sgpr_model {
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
     DevBuf<char> d_grid;
-    DevBuf<int> d_bin_of, d_bin_start, d_bin_atoms, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    DevBuf<int> d_bin_of, d_bin_start, d_b_idx, d_b_wrap, d_atoms_glob, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    DevBuf<double> d_b_pos;
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
     DevBuf<int> d_shear;
@@ -107,20 +108,6 @@ struct sgpr_model {
 };
 
 // ---------------------------------------------------------------------------- small kernels
-__global__ void gather_pos_kernel(int N, const int *perm, const double *pos_in, double *pos, double *F6N, int n_zero,
-                                  double *csq, int cnt)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) {
-        const int c = perm[i];
-        pos[3 * i] = pos_in[3 * c];
-        pos[3 * i + 1] = pos_in[3 * c + 1];
-        pos[3 * i + 2] = pos_in[3 * c + 2];
-    }
-    for (int k = i; k < n_zero; k += gridDim.x * blockDim.x) F6N[k] = 0.0;
-    if (i < cnt) csq[i] = 0.0;
-}
-
 __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, double *B, int ldb)
 {
     __shared__ double t[32][33];
@@ -156,22 +143,17 @@ __global__ void finalize_kernel(int N, int cnt, int first, int stride, const int
         packed[3 * N + c] = b;
     }
     if (blockIdx.x == 0) {
-        __shared__ double red[256];
-        // energy, then the 9 virial components: tree reductions in a fixed order (deterministic)
-        for (int q = 0; q < 10; q++) {
+        // energy + 9 virial components: one wave per component (fixed order: deterministic)
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int q = wave; q < 10; q += nw) {
             double s = 0.0;
             if (q == 0)
-                for (int k = threadIdx.x; k < nE; k += blockDim.x) s += Epart[k];
+                for (int k = lane; k < nE; k += 64) s += Epart[k];
             else
-                for (int k = threadIdx.x; k < nV; k += blockDim.x) s += virpart[(size_t)k * 9 + (q - 1)];
-            red[threadIdx.x] = s;
-            __syncthreads();
-            for (int o = blockDim.x / 2; o > 0; o >>= 1) {
-                if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) packed[4 * (size_t)N + q] = red[0] + (q == 0 ? mean_energy : 0.0);
-            __syncthreads();
+                for (int k = lane; k < nV; k += 64) s += virpart[(size_t)k * 9 + (q - 1)];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) packed[4 * (size_t)N + q] = s + (q == 0 ? mean_energy : 0.0);
         }
     }
 }
@@ -290,11 +272,11 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     drop_graph(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
-                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_bin_atoms, &h->d_wrap, &h->d_nn,
+                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_b_idx, &h->d_b_wrap, &h->d_atoms_glob, &h->d_wrap, &h->d_nn,
                          &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
-                            &h->d_vs_sqrt, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C,
+                            &h->d_vs_sqrt, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed};
     for (auto b : db) b->release();
     h->d_pack.release();
@@ -486,7 +468,7 @@ static int alloc_work(sgpr_model *h)
     bad |= h->d_W.alloc((size_t)cr * h->Dpad);
     bad |= h->d_csq.alloc(cr);
     bad |= h->d_F.alloc((size_t)6 * h->N);
-    h->virpart_len = (h->cnt + 3) / 4 * 4;
+    h->virpart_len = (h->cnt + 3) / 4;  // one partial per desc_bwd workgroup
     bad |= h->d_virpart.alloc((size_t)std::max(h->virpart_len, 1) * 9);
     bad |= h->d_packed.alloc((size_t)4 * h->N + 10);
     if (h->m > 0) {
@@ -555,7 +537,10 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_pos_in.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_pos.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_bin_of.alloc(std::max(N, 1));
-    bad |= h->d_bin_atoms.alloc(std::max(N, 1));
+    bad |= h->d_b_idx.alloc(std::max(N, 1));
+    bad |= h->d_b_wrap.alloc((size_t)3 * std::max(N, 1));
+    bad |= h->d_b_pos.alloc((size_t)3 * std::max(N, 1));
+    bad |= h->d_atoms_glob.alloc(N > 16384 ? N : 1);
     bad |= h->d_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_nn.alloc(std::max(N, 1));
     if (bad) return fail(SGPR_E_NODEVICE, "hipMalloc failed (system arrays)");
@@ -606,16 +591,13 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         }
         (void)hipEventRecord(h->ev[0], st);
     }
-    const int nz = 6 * N;
-    hipLaunchKernelGGL(gather_pos_kernel, dim3((std::max(N, cnt) + 255) / 256), dim3(256), 0, st, N, h->d_perm.p,
-                       pos_dev, h->d_pos.p, h->d_F.p, nz, h->d_csq.p, cnt);
-    stamp(h, "gather", st);
     NlParams np = {};
     np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
-    launch_neighbor_list(np, h->d_pos.p, cell_dev, h->rc, h->d_grid.p, h->d_bin_of.p, h->d_bin_start.p,
-                         h->d_bin_atoms.p, h->d_wrap.p, h->d_nn.p, h->d_lnn.p, h->d_nbr_j.p, h->d_nbr_shift.p,
-                         h->d_stat.p, st);
+    NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_start.p, h->d_b_idx.p, h->d_b_pos.p, h->d_b_wrap.p,
+                    h->d_wrap.p, h->d_stat.p, h->d_atoms_glob.p};
+    launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
+                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 6 * N, h->d_csq.p, cnt, st);
     stamp(h, "neighbor_list", st);
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;

@@ -459,13 +459,19 @@ __global__ __launch_bounds__(256) void desc_bwd_kernel(DescArgs a)
     for (int k = 0; k < 3; k++) fself[k] = wave_sum(fself[k]);
 #pragma unroll
     for (int k = 0; k < 9; k++) vir[k] = wave_sum(vir[k]);
+    // one virial partial per workgroup: the 4 waves meet in LDS (all waves reach this point)
+    __shared__ double vred[4][9];
     if (lane == 0) {
         if (active)
 #pragma unroll
             for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] = fself[k];
 #pragma unroll
-        for (int k = 0; k < 9; k++) a.vir_part[((size_t)blockIdx.x * 4 + wave) * 9 + k] = vir[k];
+        for (int k = 0; k < 9; k++) vred[wave][k] = vir[k];
     }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        a.vir_part[(size_t)blockIdx.x * 9 + threadIdx.x] =
+            vred[0][threadIdx.x] + vred[1][threadIdx.x] + vred[2][threadIdx.x] + vred[3][threadIdx.x];
 }
 
 // =========================================================================== unpack (tests)

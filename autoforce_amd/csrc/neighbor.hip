@@ -6,15 +6,19 @@
 // General triclinic cells, any pbc combination, atoms may sit outside the cell.
 //
 // Two launches:
-//   nl_bin_kernel   ONE workgroup (1024 threads): derives the bin grid from the cell
-//                   (device-resident, so NPT cells need no host round trip), bins all atoms
-//                   with LDS counters, scans, fills and index-sorts each bin (deterministic
-//                   neighbour order).
-//   nl_build_kernel one wave64 per atom: sweeps the (2R+1)^3 neighbouring bins, 64 candidates
-//                   at a time, ballot/popcount-compacts the hits into nbr_j/nbr_shift[i][:].
+//   nl_bin_kernel   ONE workgroup (1024 threads), everything in LDS: species-sort gather of the
+//                   caller's positions, bin grid derived from the (device-resident) cell, LDS
+//                   counters + scan + fill + per-bin index sort (deterministic order), then a
+//                   coalesced write of the binned copies (index, position, wrap) and the zeroing
+//                   of the step's accumulators.
+//   nl_build_kernel one wave64 per atom: the (2R+1)^3 neighbouring bins are flattened into one
+//                   candidate range (lane-parallel prefix over bins), swept 64 candidates at a
+//                   time from the binned copies (one coalesced load level), and the hits are
+//                   ballot/popcount-compacted into nbr_j/nbr_shift[i][:].
 #include "sgpr_internal.h"
 
-#define NL_MAX_BINS 8192
+#define NL_MAX_BINS 4096
+#define NL_LDS_ATOMS 16384
 
 struct NlGrid {
     double inv[9];   // inverse cell (columns = reciprocal vectors): frac = pos . inv
@@ -29,26 +33,46 @@ __device__ __forceinline__ double det3d(const double *h)
     return h[0] * (h[4] * h[8] - h[5] * h[7]) - h[1] * (h[3] * h[8] - h[5] * h[6]) + h[2] * (h[3] * h[7] - h[4] * h[6]);
 }
 
-__global__ __launch_bounds__(1024) void nl_bin_kernel(int N, const double *pos, const double *cell, int pbc0,
-                                                      int pbc1, int pbc2, double rc, NlGrid *grid, int *bin_of,
-                                                      int *bin_start /*[NL_MAX_BINS+1]*/, int *bin_atoms /*[N]*/,
-                                                      int *wrap /*[N][3]*/, int *stat /*[4]*/)
+struct BinArgs {
+    int N;
+    const int *perm;        // sorted -> caller (may be null: identity)
+    const double *pos_in;   // caller order
+    const double *cell;
+    int pbc[3];
+    double rc;
+    NlGrid *grid;
+    double *pos;            // [N][3] sorted order (out)
+    int *bin_start;         // [NL_MAX_BINS+1]
+    int *b_idx;             // [N] atom (sorted index) at binned slot k
+    double *b_pos;          // [N][3] its position
+    int *b_wrap;            // [N][3] its wrap (floor of the fractional coordinate)
+    int *bin_of;            // [N]
+    int *wrap;              // [N][3]
+    int *stat;              // [4]
+    double *zero_a; int n_zero_a;   // accumulators to clear for this step
+    double *zero_b; int n_zero_b;
+    int *atoms_glob;        // fallback storage when N > NL_LDS_ATOMS
+};
+
+__global__ __launch_bounds__(1024) void nl_bin_kernel(BinArgs a)
 {
     __shared__ int cnt[NL_MAX_BINS];
     __shared__ int start[NL_MAX_BINS + 1];
     __shared__ int part[1024];
     __shared__ NlGrid g;
+    extern __shared__ int atoms_lds[];
     const int tid = threadIdx.x;
+    const int N = a.N;
+    int *atoms = N <= NL_LDS_ATOMS ? atoms_lds : a.atoms_glob;
     if (tid == 0) {
-        const int pbc[3] = {pbc0, pbc1, pbc2};
         double h[9];
-        for (int k = 0; k < 9; k++) h[k] = cell[k];
+        for (int k = 0; k < 9; k++) h[k] = a.cell[k];
         const double dt = det3d(h);
         if (fabs(dt) > 1e-12) {
-            const double *a = h, *b = h + 3, *c = h + 6;
-            const double bc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
-            const double ca[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
-            const double ab[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const double *p = h, *q = h + 3, *r = h + 6;
+            const double bc[3] = {q[1] * r[2] - q[2] * r[1], q[2] * r[0] - q[0] * r[2], q[0] * r[1] - q[1] * r[0]};
+            const double ca[3] = {r[1] * p[2] - r[2] * p[1], r[2] * p[0] - r[0] * p[2], r[0] * p[1] - r[1] * p[0]};
+            const double ab[3] = {p[1] * q[2] - p[2] * q[1], p[2] * q[0] - p[0] * q[2], p[0] * q[1] - p[1] * q[0]};
             for (int k = 0; k < 3; k++) {
                 g.inv[3 * k + 0] = bc[k] / dt;
                 g.inv[3 * k + 1] = ca[k] / dt;
@@ -59,11 +83,11 @@ __global__ __launch_bounds__(1024) void nl_bin_kernel(int N, const double *pos, 
                                    V / sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
                                    V / sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
             for (int k = 0; k < 3; k++) {
-                if (pbc[k]) {
-                    int nb = (int)floor(hgt[k] / rc);
+                if (a.pbc[k]) {
+                    int nb = (int)floor(hgt[k] / a.rc);
                     nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
                     g.nb[k] = nb;
-                    g.rng[k] = (int)ceil(rc * nb / hgt[k]);
+                    g.rng[k] = (int)ceil(a.rc * nb / hgt[k]);
                 } else {
                     g.nb[k] = 1;  // open direction: one slab, no images
                     g.rng[k] = 0;
@@ -75,33 +99,36 @@ __global__ __launch_bounds__(1024) void nl_bin_kernel(int N, const double *pos, 
             for (int k = 0; k < 3; k++) { g.nb[k] = 1; g.rng[k] = 0; }
         }
         g.nbins = g.nb[0] * g.nb[1] * g.nb[2];
-        *grid = g;
-        stat[0] = 0;  // max neighbour count seen by the build kernel
+        *a.grid = g;
+        a.stat[0] = 0;  // max neighbour count seen by the build kernel
     }
+    for (int k = tid; k < a.n_zero_a; k += 1024) a.zero_a[k] = 0.0;
+    for (int k = tid; k < a.n_zero_b; k += 1024) a.zero_b[k] = 0.0;
     __syncthreads();
     const int nbins = g.nbins;
     for (int b = tid; b < nbins; b += 1024) cnt[b] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += 1024) {
-        const double x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
-        int bidx[3], w[3];
-        const int pbc[3] = {pbc0, pbc1, pbc2};
+        const int c = a.perm ? a.perm[i] : i;
+        const double x = a.pos_in[3 * c], y = a.pos_in[3 * c + 1], z = a.pos_in[3 * c + 2];
+        a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
+        int bidx[3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             double f = x * g.inv[k] + y * g.inv[3 + k] + z * g.inv[6 + k];
-            w[k] = 0;
+            int w = 0;
             bidx[k] = 0;
-            if (pbc[k] && g.nb[k] >= 1 && (g.inv[k] != 0.0 || g.inv[3 + k] != 0.0 || g.inv[6 + k] != 0.0)) {
+            if (a.pbc[k] && (g.inv[k] != 0.0 || g.inv[3 + k] != 0.0 || g.inv[6 + k] != 0.0)) {
                 const double fl = floor(f);
-                w[k] = (int)fl;
+                w = (int)fl;
                 f -= fl;
-                int b = (int)(f * g.nb[k]);
+                const int b = (int)(f * g.nb[k]);
                 bidx[k] = b >= g.nb[k] ? g.nb[k] - 1 : (b < 0 ? 0 : b);
             }
-            wrap[3 * i + k] = w[k];
+            a.wrap[3 * i + k] = w;
         }
         const int bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
-        bin_of[i] = bin;
+        a.bin_of[i] = bin;
         atomicAdd(&cnt[bin], 1);
     }
     __syncthreads();
@@ -130,37 +157,51 @@ __global__ __launch_bounds__(1024) void nl_bin_kernel(int N, const double *pos, 
     }
     if (tid == 0) start[nbins] = N;
     __syncthreads();
-    for (int b = tid; b <= nbins; b += 1024) bin_start[b] = start[b];
+    for (int b = tid; b <= nbins; b += 1024) a.bin_start[b] = start[b];
     for (int b = tid; b < nbins; b += 1024) cnt[b] = 0;
     __syncthreads();
     for (int i = tid; i < N; i += 1024) {
-        const int bin = bin_of[i];
+        const int bin = a.bin_of[i];  // written by this same thread above
         const int k = atomicAdd(&cnt[bin], 1);
-        bin_atoms[start[bin] + k] = i;
+        atoms[start[bin] + k] = i;
     }
     __threadfence_block();
     __syncthreads();
-    // index-sort each bin (insertion sort; bins hold ~rc^3 * density atoms)
+    // index-sort each bin (insertion sort; bins hold ~rc^3 * density atoms): deterministic lists
     for (int b = tid; b < nbins; b += 1024) {
         const int s = start[b], e = start[b + 1];
         for (int p = s + 1; p < e; p++) {
-            const int v = bin_atoms[p];
+            const int v = atoms[p];
             int q = p - 1;
-            while (q >= s && bin_atoms[q] > v) {
-                bin_atoms[q + 1] = bin_atoms[q];
+            while (q >= s && atoms[q] > v) {
+                atoms[q + 1] = atoms[q];
                 q--;
             }
-            bin_atoms[q + 1] = v;
+            atoms[q + 1] = v;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < N; k += 1024) {
+        const int i = atoms[k];
+        const int c = a.perm ? a.perm[i] : i;
+        a.b_idx[k] = i;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            a.b_pos[3 * k + q] = a.pos_in[3 * c + q];
+            a.b_wrap[3 * k + q] = a.wrap[3 * i + q];  // ordered by the fence + barrier above
         }
     }
 }
 
 __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int stride, int count, const double *pos,
                                                        const double *cell, double rc, const NlGrid *grid,
-                                                       const int *bin_of, const int *bin_start,
-                                                       const int *bin_atoms, const int *wrap, int maxnn, int *nn,
-                                                       int *nn_local, int *nbr_j, int *nbr_shift, int *stat)
+                                                       const int *bin_of, const int *bin_start, const int *b_idx,
+                                                       const double *b_pos, const int *b_wrap, const int *wrap,
+                                                       int maxnn, int *nn, int *nn_local, int *nbr_j,
+                                                       int *nbr_shift, int *stat)
 {
+    __shared__ int s_start[4][64], s_pref[4][65], s_code[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int il = blockIdx.x * 4 + wave;
     if (il >= count) return;
@@ -173,49 +214,72 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     const int wi0 = wrap[3 * i], wi1 = wrap[3 * i + 1], wi2 = wrap[3 * i + 2];
     const int bi = bin_of[i];
     const int b2 = bi % g.nb[2], b1 = (bi / g.nb[2]) % g.nb[1], b0 = bi / (g.nb[2] * g.nb[1]);
+    const int w0 = 2 * g.rng[0] + 1, w1 = 2 * g.rng[1] + 1, w2 = 2 * g.rng[2] + 1;
+    const int nbox = w0 * w1 * w2;
     int base = 0;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int o0 = -g.rng[0]; o0 <= g.rng[0]; o0++) {
-        const int t0 = b0 + o0;
-        const int c0 = (int)floor((double)t0 / g.nb[0]);
-        const int n0 = t0 - c0 * g.nb[0];
-        for (int o1 = -g.rng[1]; o1 <= g.rng[1]; o1++) {
-            const int t1 = b1 + o1;
-            const int c1 = (int)floor((double)t1 / g.nb[1]);
-            const int n1 = t1 - c1 * g.nb[1];
-            for (int o2 = -g.rng[2]; o2 <= g.rng[2]; o2++) {
-                const int t2 = b2 + o2;
-                const int c2 = (int)floor((double)t2 / g.nb[2]);
-                const int n2 = t2 - c2 * g.nb[2];
-                const int nbin = (n0 * g.nb[1] + n1) * g.nb[2] + n2;
-                const int s = bin_start[nbin], e = bin_start[nbin + 1];
-                for (int p0 = s; p0 < e; p0 += 64) {
-                    const int p = p0 + lane;
-                    bool hit = false;
-                    int j = 0, f0 = 0, f1 = 0, f2 = 0;
-                    if (p < e) {
-                        j = bin_atoms[p];
-                        f0 = c0 - wrap[3 * j] + wi0;
-                        f1 = c1 - wrap[3 * j + 1] + wi1;
-                        f2 = c2 - wrap[3 * j + 2] + wi2;
-                        const double dx = pos[3 * j] - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
-                        const double dy = pos[3 * j + 1] - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
-                        const double dz = pos[3 * j + 2] - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
-                        const double rr = sqrt(dx * dx + dy * dy + dz * dz);
-                        hit = rr < rc && !(j == i && f0 == 0 && f1 == 0 && f2 == 0);
-                    }
-                    const unsigned long long m = __ballot(hit);
-                    if (hit) {
-                        const int slot = base + __popcll(m & lt);
-                        if (slot < maxnn) {
-                            nbr_j[(size_t)i * maxnn + slot] = j;
-                            nbr_shift[(size_t)i * maxnn + slot] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16);
-                        }
-                    }
-                    base += __popcll(m);
+    for (int q0 = 0; q0 < nbox; q0 += 64) {
+        // lane -> one neighbouring bin (image-aware)
+        const int q = q0 + lane;
+        int cntb = 0, sb = 0, code = 0;
+        if (q < nbox) {
+            const int o2 = q % w2 - g.rng[2], o1 = (q / w2) % w1 - g.rng[1], o0 = q / (w2 * w1) - g.rng[0];
+            const int t0 = b0 + o0, t1 = b1 + o1, t2 = b2 + o2;
+            const int c0 = (int)floor((double)t0 / g.nb[0]), c1 = (int)floor((double)t1 / g.nb[1]),
+                      c2 = (int)floor((double)t2 / g.nb[2]);
+            const int nbin = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
+            sb = bin_start[nbin];
+            cntb = bin_start[nbin + 1] - sb;
+            code = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16);
+        }
+        int incl = cntb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int total = __shfl(incl, 63, 64);
+        s_start[wave][lane] = sb;
+        s_pref[wave][lane] = incl - cntb;
+        s_code[wave][lane] = code;
+        if (lane == 0) s_pref[wave][64] = total;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int c0 = 0; c0 < total; c0 += 64) {
+            const int c = c0 + lane;
+            bool hit = false;
+            int j = 0, f0 = 0, f1 = 0, f2 = 0;
+            if (c < total) {
+                // largest b with pref[b] <= c  (empty bins share a prefix value: take the last)
+                int lo = 0, hi = 63;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (s_pref[wave][mid] <= c) lo = mid; else hi = mid - 1;
+                }
+                const int k = s_start[wave][lo] + (c - s_pref[wave][lo]);
+                const int cd = s_code[wave][lo];
+                j = b_idx[k];
+                f0 = (int)(int8_t)(cd & 0xff) - b_wrap[3 * k] + wi0;
+                f1 = (int)(int8_t)((cd >> 8) & 0xff) - b_wrap[3 * k + 1] + wi1;
+                f2 = (int)(int8_t)((cd >> 16) & 0xff) - b_wrap[3 * k + 2] + wi2;
+                const double dx = b_pos[3 * k] - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
+                const double dy = b_pos[3 * k + 1] - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
+                const double dz = b_pos[3 * k + 2] - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
+                const double rr = sqrt(dx * dx + dy * dy + dz * dz);
+                hit = rr < rc && !(j == i && f0 == 0 && f1 == 0 && f2 == 0);
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int slot = base + __popcll(m & lt);
+                if (slot < maxnn) {
+                    nbr_j[(size_t)i * maxnn + slot] = j;
+                    nbr_shift[(size_t)i * maxnn + slot] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16);
                 }
             }
+            base += __popcll(m);
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0) {
         nn[i] = base < maxnn ? base : maxnn;
@@ -224,15 +288,28 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     }
 }
 
-void launch_neighbor_list(const NlParams &p, const double *pos, const double *cell, double rc, void *grid,
-                          int *bin_of, int *bin_start, int *bin_atoms, int *wrap, int *nn, int *nn_local,
-                          int *nbr_j, int *nbr_shift, int *stat, hipStream_t st)
+void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_in, double *pos, const double *cell,
+                          double rc, NlScratch s, int *nn, int *nn_local, int *nbr_j, int *nbr_shift,
+                          double *zero_a, int n_zero_a, double *zero_b, int n_zero_b, hipStream_t st)
 {
     if (p.N <= 0) return;
-    hipLaunchKernelGGL(nl_bin_kernel, dim3(1), dim3(1024), 0, st, p.N, pos, cell, p.pbc[0], p.pbc[1], p.pbc[2], rc,
-                       (NlGrid *)grid, bin_of, bin_start, bin_atoms, wrap, stat);
+    BinArgs a = {};
+    a.N = p.N; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
+    for (int k = 0; k < 3; k++) a.pbc[k] = p.pbc[k];
+    a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_start = s.bin_start; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
+    a.b_wrap = s.b_wrap; a.bin_of = s.bin_of; a.wrap = s.wrap; a.stat = s.stat;
+    a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
+    a.atoms_glob = s.atoms_glob;
+    const size_t dyn = p.N <= NL_LDS_ATOMS ? sizeof(int) * (size_t)p.N : 0;
+    static size_t attr = 0;
+    if (dyn > attr) {
+        (void)hipFuncSetAttribute((const void *)nl_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr = dyn;
+    }
+    hipLaunchKernelGGL(nl_bin_kernel, dim3(1), dim3(1024), dyn, st, a);
     if (p.count > 0)
-        hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first, p.stride > 0 ? p.stride : 1, p.count, pos,
-                           cell, rc, (const NlGrid *)grid, bin_of, bin_start, bin_atoms, wrap, p.maxnn, nn, nn_local,
-                           nbr_j, nbr_shift, stat);
+        hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first,
+                           p.stride > 0 ? p.stride : 1, p.count, pos, cell, rc, (const NlGrid *)s.grid, s.bin_of,
+                           s.bin_start, s.b_idx, s.b_pos, s.b_wrap, s.wrap, p.maxnn, nn, nn_local, nbr_j, nbr_shift,
+                           s.stat);
 }

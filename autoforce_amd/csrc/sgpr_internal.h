@@ -43,10 +43,24 @@ struct NlParams {
     int maxnn;        // capacity per atom
 };
 
-// scratch: grid (>= 128 B), bin_of[N], bin_start[8193], bin_atoms[N], wrap[N][3], stat[4]
-void launch_neighbor_list(const NlParams &p, const double *pos, const double *cell, double rc, void *grid,
-                          int *bin_of, int *bin_start, int *bin_atoms, int *wrap, int *nn /*[N] by sorted index*/,
-                          int *nn_local /*[count]*/, int *nbr_j, int *nbr_shift, int *stat, hipStream_t st);
+struct NlScratch {
+    void *grid;        // >= 128 B
+    int *bin_of;       // [N]
+    int *bin_start;    // [4097]
+    int *b_idx;        // [N]    binned copies (slot k of the bin-sorted order)
+    double *b_pos;     // [N][3]
+    int *b_wrap;       // [N][3]
+    int *wrap;         // [N][3]
+    int *stat;         // [4]
+    int *atoms_glob;   // [N]    only used when N exceeds the LDS-resident limit
+};
+
+// Bins ALL N atoms (also: gathers pos_in[perm] -> pos in species-sorted order and clears the
+// step's accumulators zero_a/zero_b), then builds the lists of this rank's atoms.
+void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_in, double *pos, const double *cell,
+                          double rc, NlScratch s, int *nn /*[N] by sorted index*/, int *nn_local /*[count]*/,
+                          int *nbr_j, int *nbr_shift, double *zero_a, int n_zero_a, double *zero_b, int n_zero_b,
+                          hipStream_t st);
 
 struct DescParams {
     int lmax, nmax, S;

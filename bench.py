@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py — MD-step throughput of the SGPR predict hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one frame: device neighbour list -> SeSoap descriptors
+-> K_nm -> energy, forces, virial -> covloss (calculator/active.py:425-502 of the reference),
+with positions already resident in HBM.  Workload at N=1: BASELINE configs[2] — 4096-atom
+"LiPS" (3 species), 512 inducing points, lmax=nmax=3, eta=4, rc=6 A, fp64.
+N > 1: atoms are dealt to ranks (per-species round robin, the reference's Distributer); every
+rank evaluates its share and ONE RCCL all-reduce of the packed [F | beta | E | virial] buffer
+combines them (the reference's four MPI all-reduces, calculator/active.py:562,601,602,777).
+The frame is the same for every N, so scaling is "strong".
+
+torch is used for device memory, streams and torch.distributed only; the numerics are
+libsgpr_hip.so (hand-written HIP) called through its C ABI.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6  # BASELINE.md §4 (MI355X FP64 matrix peak)
+
+
+def build_model(device, numbers, pos, cell, pbc, m, workload_seed=1):
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.workloads import inducing_from_frame, lips
+    species = sorted(set(int(z) for z in numbers))
+    mdl = SGPRModel(3, 3, 4, 6.0, species=species, device=device)
+    n2, p2, c2, b2 = lips(round(len(numbers) ** (1 / 3)), seed=workload_seed)
+    X = inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=workload_seed)
+    mdl.set_inducing(X)
+    # regression state: choli from the device solve on a small synthetic data block, mu ~ N(0,1)
+    rng = np.random.default_rng(2)
+    mdl.solve(rng.normal(size=(64, m)), rng.normal(size=64))
+    mu = rng.normal(size=m)
+    mdl.set_weights(mu, choli=mdl.choli, vscale=mdl.make_vscale())
+    return mdl
+
+
+def algorithmic_bytes(N, nn, D, m):
+    """Per-kernel algorithmic HBM bytes of one step (SURVEY.md §8d formula, split by kernel)."""
+    return {
+        "descriptor_fwd": N * nn * 44 + 8 * N * D,
+        "gemm_knm": 8 * N * D + 8 * m * D + 8 * N * m,
+        "gemm_w": 8 * N * m + 8 * m * D + 8 * N * D,
+        "descriptor_bwd": N * nn * 44 + N * nn * 24 + 8 * N * D + 24 * N,
+        "gemm_covloss": 8 * N * m + 8 * m * m,
+    }
+
+
+def cpu_baseline(numbers, pos, cell, pbc, mdl, mu, sample_atoms, min_seconds=12.0):
+    """Times the CPU oracle (C/OpenMP restatement of the reference path, pinned by the golden
+    vectors) on a bounded sample of the SAME frame: descriptors + K_nm + reverse pass + covloss for
+    `sample_atoms` atoms (forces scatter to all atoms), all host cores."""
+    from oracle import oracle as orc
+    species = np.array(mdl.species, np.int32)
+    X = mdl.X
+    ind_z = np.array([x.number for x in X], np.int32)
+    ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
+    Pm, nnm = orc.inducing_descriptors(3, 3, 6.0, species, ind_z, ind_ptr, np.concatenate([x._b for x in X]),
+                                       np.concatenate([x._r for x in X]))
+    ptr, j, off = mdl.neighbors(len(numbers))  # device neighbour list of the benchmark frame
+    # restrict to the first `sample_atoms` atoms' environments
+    ptr_s = ptr.copy()
+    ptr_s[sample_atoms + 1:] = ptr_s[sample_atoms]
+    reps, dt = 0, 0.0
+    t0 = time.perf_counter()
+    while dt < min_seconds:
+        orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, (ptr_s, j, off), ind_z, nnm, Pm, mu, choli=mdl.choli,
+                  want_p=False)
+        reps += 1
+        dt = time.perf_counter() - t0
+    return sample_atoms * reps / dt, dt, reps, orc.num_threads()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--atoms-side", type=int, default=16, help="simple-cubic sites per edge (16 -> 4096 atoms)")
+    ap.add_argument("--inducing", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from autoforce_amd import _lib
+    from autoforce_amd.workloads import lips
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libsgpr_hip has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    numbers, pos, cell, pbc = lips(args.atoms_side, seed=0)
+    N, m = len(numbers), args.inducing
+    mdl = build_model(local_rank, numbers, pos, cell, pbc, m)
+    lib = _lib.load()
+    h = mdl.handle
+    if args.no_graph:
+        _lib.check(lib.sgpr_set_option(h, b"graph", 0))
+
+    dev = torch.device("cuda", local_rank)
+    pos_d = torch.from_numpy(pos).to(dev)
+    cell_d = torch.from_numpy(cell).to(dev)
+    packed = torch.zeros(int(lib.sgpr_packed_len(N)), dtype=torch.float64, device=dev)
+    _lib.check(lib.sgpr_bind_system(h, N, _lib.ptr(_lib.i32(numbers)), _lib.ptr(_lib.i32(pbc.astype(np.int32))),
+                                    rank, world))
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def step():
+        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+        if world > 1:
+            dist.all_reduce(packed)
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    _lib.check(lib.sgpr_sync_check(h, sp))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    _lib.check(lib.sgpr_sync_check(h, sp))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = N * args.steps / dt
+
+    # ---- per-kernel durations: HIP events on the launch stream, same steps run eagerly
+    mdl.profile(True)
+    acc = {}
+    nprof = min(args.steps, 50)
+    for _ in range(nprof):
+        step()
+        torch.cuda.synchronize(dev)
+        for k, v in mdl.stage_times().items():
+            acc[k] = acc.get(k, 0.0) + v
+    mdl.profile(False)
+    stage_ms = {k: v / nprof for k, v in acc.items()}
+    dims = mdl.dims
+    out_host = packed.cpu().numpy()
+
+    result = None
+    if rank == 0:
+        cnt = (N - rank + world - 1) // world
+        ptr, _, _ = mdl.neighbors(N)
+        nn_mean = float(ptr[-1]) / max(cnt, 1)
+        Dc = dims["Dc"]
+        # algorithmic bytes of THIS formulation: packed rows (Dc) and only this rank's atoms
+        ab = algorithmic_bytes(cnt, nn_mean, Dc, m)
+        ab_survey = algorithmic_bytes(cnt, nn_mean, dims["D"] * dims["S"] ** 2, m)
+        dom = max((k for k in stage_ms if k in ab), key=lambda k: stage_ms[k])
+        dom_s = stage_ms[dom] * 1e-3
+        # dense flops actually required by the block-diagonal packed formulation
+        roof = {
+            "kernel": dom,
+            "bound": "hbm",
+            "achieved": ab[dom] / dom_s / 1e9,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": ab[dom] / dom_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes": ab[dom],
+            "avg_launch_us": stage_ms[dom] * 1e3,
+            "timing": f"hip events on the launch stream, {nprof} eager steps after the timed region",
+            "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
+            "step_bytes_packed_layout": sum(ab.values()),
+            "step_bytes_survey_formula": sum(ab_survey.values()),
+            "pass_GBs_packed": sum(ab.values()) / (sum(stage_ms[k] for k in ab if k in stage_ms) * 1e-3) / 1e9,
+        }
+        result = {
+            "metric": "MD-step atoms*steps/sec (SGPR predict: NL + descriptors + K_nm + E/F/stress + covloss)",
+            "value": value,
+            "unit": "atom*steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
+                "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
+                "packed_row": Dc, "graph": not args.no_graph,
+                "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step",
+            },
+            "roofline": roof,
+            "energy": float(out_host[4 * N]),
+            "max_force": float(np.abs(out_host[:3 * N]).max()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = args.cpu_sample or N
+            v, cdt, reps, cores = cpu_baseline(numbers, pos, cell, pbc, mdl, mdl.mu, sample)
+            result["cpu_baseline"] = {
+                "value": v, "unit": "atom*steps/s", "cores": cores, "kind": "port",
+                "sample": f"{reps} passes over {sample} of {N} atoms of the same frame (descriptors + K_nm + reverse "
+                          f"pass + covloss; neighbour list taken from the device), {cdt:.1f} s, "
+                          f"oracle/sgpr_oracle.c with OpenMP on {cores} threads",
+            }
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    mdl.close()
+
+
+if __name__ == "__main__":
+    main()
