@@ -89,12 +89,16 @@ struct sgpr_model {
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
     DevBuf<char> d_grid;
-    DevBuf<int> d_bin_of, d_bin_start, d_b_idx, d_b_wrap, d_atoms_glob, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    DevBuf<int> d_bin_of, d_bin_start, d_b_idx, d_b_wrap, d_rank_of, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
     DevBuf<double> d_b_pos;
+    DevBuf<int> d_nn_raw, d_hist, d_offs;
+    DevBuf<double> d_gpart;
     // per-step work arrays (local rows)
-    DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
+    DevBuf<double> d_Pn, d_norm, d_C, d_dC, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
+    DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
+    DevBuf<int4> t_knm, t_w, t_cov, t_kmm;  // working-tile tables of the four GEMMs
     // graph
     hipGraphExec_t gexec = nullptr;
     const void *g_pos = nullptr, *g_cell = nullptr, *g_out = nullptr;
@@ -123,39 +127,87 @@ __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, d
     }
 }
 
-// packed = [F(3N) | beta(N) | E | virial(9)] in CALLER atom order
-__global__ void finalize_kernel(int N, int cnt, int first, int stride, const int *perm, const int *slot,
-                                const double *Fnbr, const double *Fself, const double *csq, int has_beta,
-                                const double *vs_sqrt, const double *Epart, int nE, const double *virpart, int nV,
-                                double mean_energy, double *packed)
+// packed = [F(3N) | beta(N) | E | virial(9)] in CALLER atom order.
+// The scalar reductions (energy partials of the K_nm tiles, virial partials of the pair kernel,
+// largest neighbour count) are two-level: every workgroup reduces its slice, the last one to
+// arrive (agent-scope release / ticket / acquire, cdna_hip_programming.md Guideline 16) combines
+// the per-workgroup partials in a fixed order, so the sums are reproducible.
+__global__ __launch_bounds__(256) void finalize_kernel(int N, int cnt, int first, int stride, const int *perm,
+                                                       const int *slot, const double *Fnbr, const double *Fself,
+                                                       const double *csq, int has_beta, const double *vs_sqrt,
+                                                       const double *Epart, int nE, const double *virpart, int nV,
+                                                       double mean_energy, double *packed, const int *nn_raw,
+                                                       int *stat, double *gpart /*[grid][12]*/, unsigned *ticket)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int is_last;
+    const int tid = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
+    const int i = b * blockDim.x + tid;
     if (i < N) {
         const int c = perm[i];
 #pragma unroll
         for (int k = 0; k < 3; k++) packed[3 * c + k] = Fnbr[3 * i + k] + Fself[3 * i + k];
-        double b = 0.0;
+        double bt = 0.0;
         const int il = (i - first) / stride;
         if (has_beta && i >= first && (i - first) % stride == 0 && il < cnt) {
             const double v = 1.0 - csq[il];
-            b = sqrt(v > 0.0 ? v : 0.0) * vs_sqrt[slot[i]];
+            bt = sqrt(v > 0.0 ? v : 0.0) * vs_sqrt[slot[i]];
         }
-        packed[3 * N + c] = b;
+        packed[3 * N + c] = bt;
     }
-    if (blockIdx.x == 0) {
-        // energy + 9 virial components: one wave per component (fixed order: deterministic)
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-        for (int q = wave; q < 10; q += nw) {
+    // level 1: this workgroup's slice of each partial array, one wave per component
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int q = wave; q < 11; q += 4) {
+        if (q == 10) {
+            const int per = (cnt + nb - 1) / nb, lo = b * per, hi = min(cnt, lo + per);
+            int mx = 0;
+            for (int k = lo + lane; k < hi; k += 64) mx = max(mx, nn_raw[k]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            if (lane == 0) gpart[b * 12 + q] = (double)mx;
+        } else {
+            const double *src = q == 0 ? Epart : virpart + (size_t)(q - 1) * nV;
+            const int n = q == 0 ? nE : nV;
+            const int per = (n + nb - 1) / nb, lo = b * per, hi = min(n, lo + per);
             double s = 0.0;
-            if (q == 0)
-                for (int k = lane; k < nE; k += 64) s += Epart[k];
-            else
-                for (int k = lane; k < nV; k += 64) s += virpart[(size_t)k * 9 + (q - 1)];
+            for (int k = lo + lane; k < hi; k += 64) s += src[k];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) packed[4 * (size_t)N + q] = s + (q == 0 ? mean_energy : 0.0);
+            if (lane == 0) gpart[b * 12 + q] = s;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == (unsigned)nb - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // level 2: combine the per-workgroup partials in workgroup order
+    for (int q = wave; q < 11; q += 4) {
+        double s = 0.0, mx = 0.0;
+        for (int k = lane; k < nb; k += 64) {
+            const double v = __hip_atomic_load(&gpart[k * 12 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s += v;
+            mx = fmax(mx, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o, 64);
+            mx = fmax(mx, __shfl_xor(mx, o, 64));
+        }
+        if (lane == 0) {
+            if (q == 10) stat[0] = (int)mx;
+            else packed[4 * (size_t)N + q] = s + (q == 0 ? mean_energy : 0.0);
+        }
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------- host tables
@@ -184,7 +236,7 @@ static void build_pack(sgpr_model *h)
     const int N1 = h->nmax + 1, L1 = h->lmax + 1, U = h->S * N1;
     h->D = N1 * N1 * L1;
     h->Dc = U * (U + 1) / 2 * L1;
-    h->Dpad = rup(h->Dc, 16);
+    h->Dpad = rup(h->Dc, 32);
     h->CS = h->S * N1 * L1 * L1;
     h->h_pack.assign(h->Dc, PackEntry());
     for (int u = 0; u < U; u++)
@@ -254,6 +306,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_stat.alloc(4);
     h->d_bin_start.alloc(8200);
     h->d_cell_in.alloc(9);
+    if (getenv("SGPR_STAMPS")) h->d_stamps.alloc(4 * 4096);
     *out = h;
     return SGPR_OK;
 }
@@ -269,14 +322,27 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->d_stamps.p && h->t_knm.n) {
+        std::vector<long long> st(4 * h->t_knm.n);
+        (void)hipMemcpy(st.data(), h->d_stamps.p, sizeof(long long) * st.size(), hipMemcpyDeviceToHost);
+        double pro = 0, loop = 0, epi = 0; int n = 0; long long t0 = 1LL << 62, t1 = 0;
+        for (size_t b = 0; b < h->t_knm.n; b++) {
+            if (st[4 * b + 3] <= 0) continue;
+            loop += st[4 * b + 1] - st[4 * b]; epi += st[4 * b + 2] - st[4 * b + 1]; n++;
+            t0 = std::min(t0, st[4 * b]); t1 = std::max(t1, st[4 * b + 2]);
+        }
+        fprintf(stderr, "[sgpr stamps] K_nm gemm: %d tiles, start->loop end %.0f cyc, epilogue %.0f cyc, first start->last end %lld cyc\n",
+                n, loop / std::max(n, 1), epi / std::max(n, 1), t1 - t0);
+        (void)pro;
+    }
     drop_graph(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
-                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_b_idx, &h->d_b_wrap, &h->d_atoms_glob, &h->d_wrap, &h->d_nn,
+                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_b_idx, &h->d_b_wrap, &h->d_rank_of, &h->d_nn_raw, &h->d_hist, &h->d_offs, &h->d_wrap, &h->d_nn,
                          &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
-                            &h->d_vs_sqrt, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C,
+                            &h->d_vs_sqrt, &h->d_gpart, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_dC,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed};
     for (auto b : db) b->release();
     h->d_pack.release();
@@ -285,19 +351,75 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     delete h;
 }
 
+// Working-tile tables (64x64 tiles).  kind 0: K_nm (rows = this rank's atoms, cols = inducing, full
+// k); 1: W = Aw.Pm (cols = packed row, k = inducing range of the row tile's species); 2: covloss
+// (cols = inducing, k = inducing range, clipped at the column tile when choli is lower-triangular);
+// 3: K_mm.  Entries are dealt to list positions so that position % 8 == row tile % 8 (XCD affinity);
+// holes are padding entries with kend = 0.
+static int build_tiles(sgpr_model *h, int kind)
+{
+    const int KTc = 32;
+    const std::vector<int> &roff = kind == 3 ? h->qoff : h->aoff;
+    const int nrows = kind == 3 ? h->m : h->cnt;
+    const int ncols = kind == 1 ? h->Dpad : h->m;
+    const int nrt = (nrows + 63) / 64, nct = (ncols + 63) / 64;
+    std::vector<std::vector<int4>> bucket(8);
+    auto species_of = [&](const std::vector<int> &off, int idx) {
+        int s = 0;
+        while (s + 1 < h->S && off[s + 1] <= idx) s++;
+        return s;
+    };
+    for (int rt = 0; rt < nrt; rt++) {
+        const int r0 = rt * 64, r1 = std::min(nrows, r0 + 64) - 1;
+        const int sa = species_of(roff, r0), sb = species_of(roff, r1);
+        const int qlo = h->qoff[sa], qhi = h->qoff[sb + 1];  // inducing range of these species
+        for (int ct = 0; ct < nct; ct++) {
+            const int c0 = ct * 64, c1 = std::min(ncols, c0 + 64);
+            int kb = 0, ke = 0;
+            if (kind == 0 || kind == 3) {
+                if (c0 >= qhi || c1 <= qlo) continue;
+                kb = 0; ke = h->Dpad;
+            } else if (kind == 1) {
+                kb = qlo; ke = qhi;
+            } else {
+                if (c0 >= qhi || c1 <= qlo) continue;
+                kb = qlo; ke = h->choli_lower ? std::min(qhi, c1) : qhi;
+            }
+            kb = kb / KTc * KTc;
+            ke = (ke + KTc - 1) / KTc * KTc;
+            if (ke <= kb) continue;
+            bucket[rt % 8].push_back(make_int4(rt, ct, kb, ke));
+        }
+    }
+    size_t depth = 0;
+    for (auto &b : bucket) depth = std::max(depth, b.size());
+    std::vector<int4> list(depth * 8, make_int4(0, 0, 0, 0));
+    for (int x = 0; x < 8; x++)
+        for (size_t j = 0; j < bucket[x].size(); j++) list[j * 8 + x] = bucket[x][j];
+    DevBuf<int4> &dst = kind == 0 ? h->t_knm : kind == 1 ? h->t_w : kind == 2 ? h->t_cov : h->t_kmm;
+    dst.release();
+    if (list.empty()) return 0;
+    if (dst.alloc(list.size(), false)) return -1;
+    if (hipMemcpy(dst.p, list.data(), sizeof(int4) * list.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 0;
+}
+
 static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row_slot, const int *row_nn,
-                           const int *row_off, double *Kout, double *Aw, const double *mu, double *Epart,
+                           const DevBuf<int4> &tiles, double *Kout, double *Aw, const double *mu, double *Epart,
                            hipStream_t st)
 {
     GemmParams g = {};
     g.M = M; g.N = h->m; g.K = h->Dpad;
     g.lda = h->Dpad; g.ldb = h->Dpad; g.ldc = h->m_pad;
     g.A = A; g.B = h->d_Pm.p; g.C = Kout;
-    g.S = h->S; g.row_off = row_off; g.col_off = h->d_qoff.p; g.k_off = nullptr;
+    g.tiles = tiles.p; g.ntiles = (int)tiles.n;
     g.eta = h->eta; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
+    g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
     launch_gemm_nt(g, EPI_KERNEL, st);
 }
+
+static int alloc_work(sgpr_model *h);
 
 extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const int64_t *nbr_ptr,
                                  const int32_t *nbr_z, const double *nbr_r)
@@ -307,7 +429,7 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     drop_graph(h);
     h->has_mu = h->has_choli = false;
     h->m = m;
-    h->m_pad = rup(std::max(m, 1), 16);
+    h->m_pad = rup(std::max(m, 1), 32);
     h->m_rows = rup(std::max(m, 1), 64);
     std::vector<int> slot(m);
     for (int q = 0; q < m; q++) {
@@ -341,7 +463,7 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     for (int s = 0; s < h->S; s++) h->qoff[s + 1] += h->qoff[s];
     if (h->d_ind_slot.alloc(h->m_rows) || h->d_ind_nn.alloc(h->m_rows) || h->d_qoff.alloc(h->S + 1) ||
         h->d_Pm.alloc((size_t)h->m_rows * h->Dpad) || h->d_PmT.alloc((size_t)rup(h->Dpad, 64) * h->m_pad) ||
-        h->d_pm_norm.alloc(h->m_rows) || h->d_M.alloc((size_t)h->m_rows * h->m_pad) || h->d_mu.alloc(h->m_pad) ||
+        h->d_pm_norm.alloc(h->m_rows) || h->d_M.alloc((size_t)h->m_rows * h->m_pad) || h->d_mu.alloc(std::max(h->m_pad, h->m_rows)) ||
         h->d_choli.alloc((size_t)h->m_rows * h->m_pad))
         return fail(SGPR_E_NODEVICE, "hipMalloc failed (inducing set)");
     HIPCHK(hipMemcpy(h->d_ind_slot.p, dslot.data(), sizeof(int) * h->m_rows, hipMemcpyHostToDevice));
@@ -367,11 +489,13 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     hipLaunchKernelGGL(transpose_kernel, dim3((h->Dpad + 31) / 32, (m + 31) / 32), dim3(32, 8), 0, h->stream, m,
                        h->Dpad, h->d_Pm.p, h->Dpad, h->d_PmT.p, h->m_pad);
     // K_mm (regression/gppotential.py:506): same kernel epilogue, no weights
-    gemm_kernel_pm(h, h->d_Pm.p, m, h->d_ind_slot.p, h->d_ind_nn.p, h->d_qoff.p, h->d_M.p, nullptr, nullptr, nullptr,
+    build_tiles(h, 3);
+    gemm_kernel_pm(h, h->d_Pm.p, m, h->d_ind_slot.p, h->d_ind_nn.p, h->t_kmm, h->d_M.p, nullptr, nullptr, nullptr,
                    h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     d_ptr.release(); d_eslot.release(); d_er.release();
+    if (h->N > 0) return alloc_work(h);  // a system is bound: K/Aw buffers and tile tables follow m
     return SGPR_OK;
 }
 
@@ -440,7 +564,10 @@ extern "C" int sgpr_set_weights(sgpr_model *h, const double *mu, const double *m
             for (int b = a + 1; b < m; b++)
                 if (c[(size_t)a * h->m_pad + b] != 0.0) { lower = false; break; }
         h->has_choli = true;
-        h->choli_lower = lower;
+        if (h->choli_lower != lower) {
+            h->choli_lower = lower;
+            if (h->N > 0 && build_tiles(h, 2)) return fail(SGPR_E_NODEVICE, "hipMalloc failed (tile table)");
+        }
         HIPCHK(hipMemcpy(h->d_choli.p, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
     } else
         h->has_choli = false;
@@ -464,6 +591,7 @@ static int alloc_work(sgpr_model *h)
     bad |= h->d_Pn.alloc((size_t)cr * h->Dpad);
     bad |= h->d_norm.alloc(cr);
     bad |= h->d_C.alloc((size_t)std::max(h->cnt, 1) * h->CS);
+    bad |= h->d_dC.alloc((size_t)std::max(h->cnt, 1) * h->CS);
     bad |= h->d_shear.alloc(cr);
     bad |= h->d_W.alloc((size_t)cr * h->Dpad);
     bad |= h->d_csq.alloc(cr);
@@ -474,8 +602,9 @@ static int alloc_work(sgpr_model *h)
     if (h->m > 0) {
         bad |= h->d_K.alloc((size_t)cr * h->m_pad);   // zero-filled: off-species entries are never written
         bad |= h->d_Aw.alloc((size_t)cr * h->m_pad);
-        h->epart_len = ((h->m + 63) / 64) * ((std::max(h->cnt, 1) + 63) / 64);
-        bad |= h->d_Epart.alloc(h->epart_len);
+        if (build_tiles(h, 0) || build_tiles(h, 1) || build_tiles(h, 2)) bad = 1;
+        h->epart_len = (int)h->t_knm.n;
+        bad |= h->d_Epart.alloc(std::max(h->epart_len, 1));
     } else
         h->epart_len = 0;
     return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (work arrays)") : 0;
@@ -540,7 +669,11 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_b_idx.alloc(std::max(N, 1));
     bad |= h->d_b_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_b_pos.alloc((size_t)3 * std::max(N, 1));
-    bad |= h->d_atoms_glob.alloc(N > 16384 ? N : 1);
+    bad |= h->d_rank_of.alloc(std::max(N, 1));
+    bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
+    bad |= h->d_hist.alloc((size_t)4096 * ((std::max(N, 1) + 255) / 256));
+    bad |= h->d_offs.alloc((size_t)4096 * ((std::max(N, 1) + 255) / 256));
+    bad |= h->d_nn_raw.alloc(h->cnt_rows);
     bad |= h->d_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_nn.alloc(std::max(N, 1));
     if (bad) return fail(SGPR_E_NODEVICE, "hipMalloc failed (system arrays)");
@@ -595,9 +728,9 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
     NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_start.p, h->d_b_idx.p, h->d_b_pos.p, h->d_b_wrap.p,
-                    h->d_wrap.p, h->d_stat.p, h->d_atoms_glob.p};
+                    h->d_wrap.p, h->d_stat.p, h->d_rank_of.p, h->d_hist.p, h->d_offs.p, h->d_nn_raw.p};
     launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
-                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 6 * N, h->d_csq.p, cnt, st);
+                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, st);
     stamp(h, "neighbor_list", st);
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
@@ -609,7 +742,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     stamp(h, "descriptor_fwd", st);
     const bool predict = h->m > 0 && h->has_mu && cnt > 0;
     if (h->m > 0 && cnt > 0) {
-        gemm_kernel_pm(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->d_aoff.p, h->d_K.p, h->d_Aw.p,
+        gemm_kernel_pm(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->t_knm, h->d_K.p, h->d_Aw.p,
                        h->has_mu ? h->d_mu.p : nullptr, h->d_Epart.p, st);
         stamp(h, "gemm_knm", st);
     }
@@ -618,12 +751,12 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         g.M = cnt; g.N = h->Dpad; g.K = h->m_pad;
         g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = h->Dpad;
         g.A = h->d_Aw.p; g.B = h->d_PmT.p; g.C = h->d_W.p;
-        g.S = h->S; g.row_off = h->d_aoff.p; g.col_off = nullptr; g.k_off = h->d_qoff.p;
+        g.tiles = h->t_w.p; g.ntiles = (int)h->t_w.n;
         launch_gemm_nt(g, EPI_STORE, st);
         stamp(h, "gemm_w", st);
         rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
                                          h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
-                                         h->d_C.p, h->d_shear.p, h->d_W.p, h->d_F.p, h->d_virpart.p, st);
+                                         h->d_C.p, h->d_shear.p, h->d_W.p, h->d_dC.p, h->d_F.p, h->d_virpart.p, st);
         if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
         stamp(h, "descriptor_bwd", st);
     }
@@ -633,8 +766,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         g.M = cnt; g.N = h->m; g.K = h->m_pad;
         g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = 0;
         g.A = h->d_K.p; g.B = h->d_choli.p; g.C = nullptr;
-        g.S = h->S; g.row_off = h->d_aoff.p; g.col_off = nullptr; g.k_off = h->d_qoff.p;
-        g.tri = h->choli_lower ? 1 : 0;
+        g.tiles = h->t_cov.p; g.ntiles = (int)h->t_cov.n;
         g.rowsq = h->d_csq.p;
         launch_gemm_nt(g, EPI_ROWSQ, st);
         stamp(h, "gemm_covloss", st);
@@ -642,7 +774,8 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256), dim3(256), 0, st, N, cnt, h->rank,
                        h->world, h->d_perm.p, h->d_slot.p, h->d_F.p, h->d_F.p + 3 * (size_t)N, h->d_csq.p,
                        beta ? 1 : 0, h->d_vs_sqrt.p, h->d_Epart.p, predict ? h->epart_len : 0, h->d_virpart.p,
-                       predict ? h->virpart_len : 0, h->mean_energy, packed_dev);
+                       predict ? h->virpart_len : 0, h->mean_energy, packed_dev, h->d_nn_raw.p, h->d_stat.p,
+                       h->d_gpart.p, (unsigned *)(h->d_stat.p + 2));
     stamp(h, "finalize", st);
     return SGPR_OK;
 }

@@ -122,7 +122,7 @@ struct Harm {
 
 // ---------------------------------------------------------------- kernel arguments
 struct DescArgs {
-    int N, first, stride, maxnn, S, Dc, Dpad, CS;
+    int N, Nall, first, stride, maxnn, S, Dc, Dpad, CS;
     double rc;
     const double *pos;      // [Nall][3] (sorted order)
     const double *cell;     // [9]
@@ -138,6 +138,7 @@ struct DescArgs {
     double *Pn;             // [N][Dpad]
     double *norm;           // [N]
     double *C;              // [N][CS]
+    double *dC;             // [N][CS] dE/dc (reverse pass)
     int *shear;             // [N]
     const double *W;        // backward: [N][Dpad]
     double *Fnbr;           // backward: [Nall][3] (atomic)
@@ -329,10 +330,18 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
 }
 
 // =========================================================================== backward
-// Per atom: G~ = dE/dp^ (packed, from the W GEMM) -> dE/dp -> dE/dc -> per-neighbour dE/dr_j
-// -> forces (F_j -= dE/dr_j, F_i += sum_j dE/dr_j) and the virial sum_j r_j (x) dE/dr_j.
+// Reverse pass in two kernels.
+//  desc_dc_kernel    per atom: G~ = dE/dp^ (packed, from the W GEMM) -> dE/dp -> dE/dc, stored.
+//  desc_pair_kernel  per atom j (one wave), lane = neighbour t at r = x_i - x_j + off.cell:
+//      g_t  = dE_j/dr_jt            (own environment, dE/dc of j from LDS)
+//    MIRROR (single process): the same lane also evaluates the mirrored pair, i.e. atom j seen
+//      from i's environment at -r, with dE/dc of i gathered from global memory:
+//      g'_t = dE_i/dr_ij(-r)   ->   F_j = sum_t (g_t - g'_t)     no atomics, deterministic.
+//    !MIRROR (atoms sharded over ranks: dE/dc of remote atoms is not available): F_i -= g_t by
+//      fp64 atomics into the all-atom force buffer that the ranks then all-reduce.
+//    Virial: sum_t r (x) g_t from the own terms (each ordered pair once).
 template <int LMAX, int NMAX, int ST>
-__global__ __launch_bounds__(256) void desc_bwd_kernel(DescArgs a)
+__global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
 {
     using WL = WaveLds<LMAX, NMAX>;
     constexpr int N1 = WL::N1, LL = WL::LL, NSLOT = WL::NSLOT;
@@ -340,64 +349,126 @@ __global__ __launch_bounds__(256) void desc_bwd_kernel(DescArgs a)
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ia = blockIdx.x * 4 + wave;
+    if (ia >= a.N) return;
     const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
-    const int perwave = 2 * ST * NSLOT + a.Dpad;
+    const int perwave = ST * NSLOT + a.Dpad;
     double *cl = smem + (size_t)wave * perwave;  // [ST][NSLOT]  c
-    double *dcl = cl + ST * NSLOT;               // [ST][NSLOT]  dE/dc
-    double *gl = dcl + ST * NSLOT;               // [Dpad]       dE/dp~ * coef * (1 or 2)
+    double *gl = cl + ST * NSLOT;                // [Dpad]       dE/dp~ * coef * (1 or 2)
+    const int gi = a.first + ia * a.stride;
+    const int nn = a.nn[gi];
+    const double nrm = a.norm[ia];
+    double *dC = a.dC + (size_t)ia * a.CS;
+    if (!(nn > 0 && nrm > 0.0)) {
+        for (int k = lane; k < a.CS; k += 64) dC[k] = 0.0;
+        return;
+    }
+    const double sden = nrm + SGPR_EPS;
+    // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
+    const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
+    double pw = 0.0;
+    for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
+    pw = wave_sum(pw);
+    const double corr = pw * sden / nrm;
+    for (int e = lane; e < a.Dc; e += 64) {
+        const PackEntry pe = a.pack[e];
+        gl[e] = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+    }
+#pragma unroll
+    for (int s = 0; s < ST; s++)
+#pragma unroll
+        for (int k = 0; k < SPL; k++) {
+            const int slot = lane + 64 * k;
+            if (SPL * 64 == NSLOT || slot < NSLOT)
+                cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+        }
+    wave_sync();
+    // dE/dc[u][lm] = sum_v G[pair(u,v)][l] c[v][lm]
+#pragma unroll
+    for (int s = 0; s < ST; s++)
+#pragma unroll
+        for (int k = 0; k < SPL; k++) {
+            const int slot = lane + 64 * k;
+            if ((SPL * 64 == NSLOT || slot < NSLOT) && s < a.S) {
+                const int n = slot / LL, lm = slot % LL;
+                int l = 0;
+#pragma unroll
+                for (int q = 1; q <= LMAX; q++) l += (lm >= q * q) ? 1 : 0;
+                const int u = s * N1 + n;
+                double d = 0.0;
+                for (int v = 0; v < Ur; v++) {
+                    const int lo = min(u, v), hi = max(u, v);
+                    const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
+                    d += gl[pair * (LMAX + 1) + l] * cl[(v / N1) * NSLOT + (v % N1) * LL + lm];
+                }
+                dC[s * NSLOT + slot] = d;
+            }
+        }
+}
+
+// dE/dr of ONE pair term: neighbour at displacement r (unscaled), unit u, environment shear `ang`,
+// dc = dE/dc[species slot of that neighbour][n][lm] of the environment's centre.
+template <int LMAX, int NMAX>
+__device__ __forceinline__ void pair_grad(const double r[3], double u, double rc, double ang, const double *dc,
+                                          double gr[3])
+{
+    constexpr int N1 = NMAX + 1, LL = (LMAX + 1) * (LMAX + 1);
+    const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
+    const double d = sqrt(x * x + y * y + z * z);
+    double f[N1], g, dg;
+    radial<NMAX>(d, u, rc, f, g, dg);
+    double Y[LL], gY[LL];
+    Harm<LMAX> h;
+    h.eval(x, y - ang * z, ang * y + z, Y);
+    double dEdd = 0.0;
+#pragma unroll
+    for (int k = 0; k < LL; k++) gY[k] = 0.0;
+    const double rho = d * d;
+    double rpow = 1.0;  // rho^n
+#pragma unroll
+    for (int n = 0; n < N1; n++) {
+        double dEdf = 0.0;
+#pragma unroll
+        for (int k = 0; k < LL; k++) {
+            const double dck = dc[n * LL + k];
+            dEdf += dck * Y[k];
+            gY[k] += f[n] * dck;
+        }
+        // d f_n/dd = dg rho^n + g 2n d^(2n-1)
+        const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow / d : 0.0);
+        dEdd += dEdf * dfn;
+        rpow *= rho;
+    }
+    double gxs, gys, gzs;
+    h.backward(gY, gxs, gys, gzs);
+    // inverse shear (ylm.py:203-213) + radial part, then 1/u
+    gr[0] = (gxs + dEdd * x / d) / u;
+    gr[1] = (gys + ang * gzs + dEdd * y / d) / u;
+    gr[2] = (-ang * gys + gzs + dEdd * z / d) / u;
+}
+
+template <int LMAX, int NMAX, int ST, bool MIRROR>
+__global__ __launch_bounds__(256) void desc_pair_kernel(DescArgs a)
+{
+    using WL = WaveLds<LMAX, NMAX>;
+    constexpr int NSLOT = WL::NSLOT;
+    extern __shared__ double smem[];
+    __shared__ double vred[4][9];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ia = blockIdx.x * 4 + wave;
+    double *dcl = smem + (size_t)wave * ST * NSLOT;  // [S][NSLOT] dE/dc of this atom
     double vir[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) vir[k] = 0.0;
-    double fself[3] = {0, 0, 0};
+    double fsum[3] = {0, 0, 0};
     const bool active = ia < a.N;
     const int gi = a.first + (active ? ia : 0) * a.stride;
     const int nn = active ? a.nn[gi] : 0;
-    const double nrm = active ? a.norm[ia] : 0.0;
-    if (active && nn > 0 && nrm > 0.0) {
-        const double sden = nrm + SGPR_EPS;
-        // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
-        const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
-        double pw = 0.0;
-        for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
-        pw = wave_sum(pw);
-        const double corr = pw * sden / nrm;
-        for (int e = lane; e < a.Dc; e += 64) {
-            const PackEntry pe = a.pack[e];
-            gl[e] = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
-        }
-#pragma unroll
-        for (int s = 0; s < ST; s++)
-#pragma unroll
-            for (int k = 0; k < SPL; k++) {
-                const int slot = lane + 64 * k;
-                if (SPL * 64 == NSLOT || slot < NSLOT)
-                    cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
-            }
+    if (active && nn > 0) {
+        for (int k = lane; k < a.CS; k += 64) dcl[k] = a.dC[(size_t)ia * a.CS + k];
         wave_sync();
-        // dE/dc[u][lm] = sum_v G[pair(u,v)][l] c[v][lm]
-#pragma unroll
-        for (int s = 0; s < ST; s++)
-#pragma unroll
-            for (int k = 0; k < SPL; k++) {
-                const int slot = lane + 64 * k;
-                if (SPL * 64 == NSLOT || slot < NSLOT) {
-                    const int n = slot / LL, lm = slot % LL;
-                    int l = 0;
-#pragma unroll
-                    for (int q = 1; q <= LMAX; q++) l += (lm >= q * q) ? 1 : 0;
-                    const int u = s * N1 + n;
-                    double d = 0.0;
-                    for (int v = 0; v < Ur; v++) {
-                        const int lo = min(u, v), hi = max(u, v);
-                        const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
-                        d += gl[pair * (LMAX + 1) + l] * cl[(v / N1) * NSLOT + (v % N1) * LL + lm];
-                    }
-                    dcl[s * NSLOT + slot] = d;
-                }
-            }
-        wave_sync();
-        const bool shear = a.shear[ia] != 0;
-        const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
+        const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
+        const int sc = a.slot[gi];
+        const double uc = a.radii[sc];
         double pi[3], cell[9];
 #pragma unroll
         for (int k = 0; k < 3; k++) pi[k] = a.pos[3 * (size_t)gi + k];
@@ -406,71 +477,46 @@ __global__ __launch_bounds__(256) void desc_bwd_kernel(DescArgs a)
         for (int t0 = 0; t0 < nn; t0 += 64) {
             const int t = t0 + lane;
             if (t < nn) {
-                double r[3]; int s, j;
+                double r[3], gr[3];
+                int s, j;
                 load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
-                const double u = a.radii[s];
-                const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
-                const double d = sqrt(x * x + y * y + z * z);
-                double f[N1], g, dg;
-                radial<NMAX>(d, u, a.rc, f, g, dg);
-                double Y[LL], gY[LL];
-                Harm<LMAX> h;
-                h.eval(x, y - ang * z, ang * y + z, Y);
-                const double *dc = dcl + s * NSLOT;
-                double dEdd = 0.0;
-#pragma unroll
-                for (int k = 0; k < LL; k++) gY[k] = 0.0;
-                const double rho = d * d;
-                double rpow = 1.0;  // rho^n
-#pragma unroll
-                for (int n = 0; n < N1; n++) {
-                    double dEdf = 0.0;
-#pragma unroll
-                    for (int k = 0; k < LL; k++) {
-                        const double dck = dc[n * LL + k];
-                        dEdf += dck * Y[k];
-                        gY[k] += f[n] * dck;
-                    }
-                    // d f_n/dd = dg rho^n + g 2n d^(2n-1)
-                    const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow / d : 0.0);
-                    dEdd += dEdf * dfn;
-                    rpow *= rho;
-                }
-                double gxs, gys, gzs;
-                h.backward(gY, gxs, gys, gzs);
-                // inverse shear (ylm.py:203-213) + radial part, then 1/u
-                double gr[3];
-                gr[0] = (gxs + dEdd * x / d) / u;
-                gr[1] = (gys + ang * gzs + dEdd * y / d) / u;
-                gr[2] = (-ang * gys + gzs + dEdd * z / d) / u;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    fself[k] += gr[k];
-                    unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
-                }
+                pair_grad<LMAX, NMAX>(r, a.radii[s], a.rc, ang, dcl + s * NSLOT, gr);
 #pragma unroll
                 for (int p = 0; p < 3; p++)
 #pragma unroll
                     for (int q = 0; q < 3; q++) vir[3 * p + q] += r[p] * gr[q];
+                if constexpr (MIRROR) {
+                    // atom gi as a neighbour of j: displacement -r, our species, j's shear state
+                    double rm[3] = {-r[0], -r[1], -r[2]}, gm[3];
+                    const double angm = a.shear[j] ? SGPR_TINY_ANGLE : 0.0;
+                    pair_grad<LMAX, NMAX>(rm, uc, a.rc, angm, a.dC + (size_t)j * a.CS + sc * NSLOT, gm);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) fsum[k] += gr[k] - gm[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        fsum[k] += gr[k];
+                        unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
+                    }
+                }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) fself[k] = wave_sum(fself[k]);
+    for (int k = 0; k < 3; k++) fsum[k] = wave_sum(fsum[k]);
 #pragma unroll
     for (int k = 0; k < 9; k++) vir[k] = wave_sum(vir[k]);
     // one virial partial per workgroup: the 4 waves meet in LDS (all waves reach this point)
-    __shared__ double vred[4][9];
     if (lane == 0) {
         if (active)
 #pragma unroll
-            for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] = fself[k];
+            for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] = fsum[k];
 #pragma unroll
         for (int k = 0; k < 9; k++) vred[wave][k] = vir[k];
     }
     __syncthreads();
     if (threadIdx.x < 9)
-        a.vir_part[(size_t)blockIdx.x * 9 + threadIdx.x] =
+        a.vir_part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
             vred[0][threadIdx.x] + vred[1][threadIdx.x] + vred[2][threadIdx.x] + vred[3][threadIdx.x];
 }
 
@@ -526,14 +572,19 @@ static int run_bwd(const DescArgs &a, hipStream_t st)
 {
     if (a.N <= 0) return 0;
     using WL = WaveLds<LMAX, NMAX>;
-    const size_t lds = sizeof(double) * 4 * (size_t)(2 * ST * WL::NSLOT + a.Dpad);
+    const size_t lds1 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + a.Dpad);
     static size_t attr_set = 0;
-    if (attr_set < lds) {
-        (void)hipFuncSetAttribute((const void *)desc_bwd_kernel<LMAX, NMAX, ST>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = lds;
+    if (attr_set < lds1) {
+        (void)hipFuncSetAttribute((const void *)desc_dc_kernel<LMAX, NMAX, ST>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        attr_set = lds1;
     }
-    hipLaunchKernelGGL((desc_bwd_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
+    const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT);
+    if (a.stride == 1 && a.first == 0 && a.N == a.Nall)
+        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, true>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
+    else
+        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, false>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
     return 0;
 }
 
@@ -564,7 +615,7 @@ static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ?
 static DescArgs make_args(const DescParams &p)
 {
     DescArgs a = {};
-    a.N = p.N; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
+    a.N = p.N; a.Nall = p.Nall; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
     a.rc = p.rc;
     return a;
 }
@@ -597,12 +648,13 @@ int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, c
 int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell, const int *slot,
                                const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
-                               const int *shear, const double *W, double *F, double *virial, hipStream_t st)
+                               const int *shear, const double *W, double *dC, double *F, double *virial,
+                               hipStream_t st)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
     a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = (double *)Pn; a.norm = (double *)norm; a.C = (double *)C;
-    a.shear = (int *)shear; a.W = W;
+    a.shear = (int *)shear; a.W = W; a.dC = dC;
     // F points at [Fnbr | Fself], virial at the per-wave partial array (see api.hip)
     a.Fnbr = F;
     a.Fself = F + 3 * (size_t)p.Nall;

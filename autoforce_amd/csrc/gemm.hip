@@ -14,14 +14,17 @@
 // by the allocator (api.hip), so the main loop carries no bounds checks.
 //
 // Tile: 64x64 per 256-thread workgroup, 4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles;
-// K-step 16 through LDS (row stride 17 doubles: conflict-free ds_read_b64 fragment reads).
+// 32-deep K stages through double-buffered LDS, fetched two stages ahead (see the main loop).
+// Measured alternatives on the 4096 x 512 x 320 K_nm product: 16-deep stages fetched one ahead
+// 31 us; LDS-free fragment-shaped direct loads 35 us (TA-bound: each quad of lanes touches four
+// cache lines).
 #include "sgpr_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define BM 64
 #define BN 64
-#define KT 16
+#define KT 32
 #define LDS_LD 17
 
 struct GemmArgs {
@@ -29,6 +32,8 @@ struct GemmArgs {
     int ieta;        // integer exponent or -1
     const int *row_slot, *col_slot;
     double *Epart;
+    int row_tiles, rows_pad, col_tiles;
+    long long *stamps;  // diagnostic build only (SGPR_STAMPS=1): [block][4] s_memtime stamps
 };
 
 __device__ __forceinline__ double ipow_d(double x, int n)
@@ -42,43 +47,29 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 {
     const GemmParams &p = g.p;
-    __shared__ double As[2][BM * LDS_LD];
-    __shared__ double Bs[2][BN * LDS_LD];
+    __shared__ double As[2][BM * 34];
+    __shared__ double Bs[2][BN * 34];
     __shared__ double red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
-    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
-
-    // species range of this tile's rows / cols -> skip test and reduction range
-    int kbeg = 0, kend = p.K;
-    bool skip = false;
-    if (p.row_off) {
-        const int rlast = min(row0 + BM, p.M) - 1;
-        int sa = 0, sb = 0;
-        for (int s = 0; s < p.S; s++) {
-            if (p.row_off[s + 1] <= row0) sa = s + 1;
-            if (p.row_off[s + 1] <= rlast) sb = s + 1;
-        }
-        sa = min(sa, p.S - 1); sb = min(sb, p.S - 1);
-        if (p.col_off) {
-            const int clo = p.col_off[sa], chi = p.col_off[sb + 1];
-            if (col0 >= chi || col0 + BN <= clo) skip = true;
-        }
-        if (p.k_off) {
-            kbeg = p.k_off[sa];
-            kend = p.k_off[sb + 1];
-            if (EPI == EPI_ROWSQ && p.tri) kend = min(kend, col0 + BN);
-            if (EPI == EPI_ROWSQ && p.col_off == nullptr) {
-                // columns index the same (inducing) dimension as k
-                if (col0 >= p.k_off[sb + 1] || col0 + BN <= p.k_off[sa]) skip = true;
-            }
-        }
-        kbeg = (kbeg / KT) * KT;
-        kend = ((kend + KT - 1) / KT) * KT;
-        if (kend <= kbeg) skip = true;
+    // Tile selection.  With a host-built tile table (species-sorted operands: K_nm, K_mm, choli are
+    // block-diagonal) only the working tiles are launched, each with its trimmed reduction range;
+    // the table is ordered so that list position p sits on XCD p % 8 together with the other
+    // column tiles of the same row panel of A (one L2 fetches the panel once).  Without a table
+    // the grid is dense, row tile fastest (same XCD property).
+    const long long t_start = g.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    int rt, ct, kbeg = 0, kend = p.K;
+    if (p.tiles) {
+        const int4 t = p.tiles[blockIdx.x];
+        rt = t.x; ct = t.y; kbeg = t.z; kend = t.w;
+        if (kend <= kbeg) return;  // padding entry
+    } else {
+        rt = blockIdx.x % g.rows_pad;
+        ct = blockIdx.x / g.rows_pad;
+        if (rt >= g.row_tiles) return;
     }
-    if (row0 >= p.M) skip = true;
-    if (EPI == EPI_SUBLOWER && col0 > row0) skip = true;  // symmetric update: lower tiles only
+    const int row0 = rt * BM, col0 = ct * BN;
+    const bool skip = (EPI == EPI_SUBLOWER && col0 > row0);  // symmetric update: lower tiles only
 
     v4d acc[2][2];
 #pragma unroll
@@ -86,51 +77,100 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+    // EPI_KERNEL: species slot / neighbour count per row, slot / count / weight per column of this
+    // lane's 8 rows and 2 columns, requested now so the latency hides under the main loop
+    // (all arrays are padded to whole tiles by the allocator).
+    int e_rs[2][4], e_rn[2][4], e_cs[2], e_cn[2];
+    double e_mu[2];
+    if (EPI == EPI_KERNEL) {
+#pragma unroll
+        for (int tm = 0; tm < 2; tm++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = row0 + wr * 32 + tm * 16 + (lane >> 4) + 4 * r;
+                e_rs[tm][r] = g.row_slot[row];
+                e_rn[tm][r] = p.row_nn ? p.row_nn[row] : 1;
+            }
+#pragma unroll
+        for (int tn = 0; tn < 2; tn++) {
+            const int col = col0 + wc * 32 + tn * 16 + (lane & 15);
+            e_cs[tn] = g.col_slot[col];
+            e_cn[tn] = p.col_nn ? p.col_nn[col] : 1;
+            e_mu[tn] = p.mu ? p.mu[col] : 0.0;
+        }
+    }
+
     if (!skip) {
-        // global -> LDS staging: thread t moves 4 consecutive doubles of row t/4
-        const int lr = tid >> 2, lk = (tid & 3) * 4;
+        // LDS-staged main loop, KS = 32 deep stages, double-buffered in LDS and fetched TWO stages
+        // ahead through registers: every stage touches new cache lines (compulsory L2 misses,
+        // ~2000+ cycles under load) while its 32 MFMAs per wave issue in 2048 cycles.
+        // Global side: thread t moves 64 contiguous bytes of row t/4 (full-line coalescing: the
+        // four lanes of a quad cover two whole 128-B lines; fragment-shaped direct loads measured
+        // TA-bound at 4x the cycles).  LDS side: row stride 34 doubles -> conflict-free ds_read_b64
+        // fragment reads and 16-B aligned ds_write_b128 stores.
+        constexpr int KS = 32, LD = KS + 2;
+        const int lr = tid >> 2, lk = (tid & 3) * 8;
         const double *Ag = p.A + (size_t)(row0 + lr) * p.lda + lk;
         const double *Bg = p.B + (size_t)(col0 + lr) * p.ldb + lk;
-        double ra[4], rb[4];
-        auto gload = [&](int k0) {
-            const double2 a0 = *(const double2 *)(Ag + k0), a1 = *(const double2 *)(Ag + k0 + 2);
-            const double2 b0 = *(const double2 *)(Bg + k0), b1 = *(const double2 *)(Bg + k0 + 2);
-            ra[0] = a0.x; ra[1] = a0.y; ra[2] = a1.x; ra[3] = a1.y;
-            rb[0] = b0.x; rb[1] = b0.y; rb[2] = b1.x; rb[3] = b1.y;
-        };
-        auto lstore = [&](int buf) {
+        // register stages as plain named values (a struct taken by reference in a lambda ended up
+        // in scratch: 272 B/lane of spills and a 45 us kernel)
+        double2 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;  // stage "p"
+        double2 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;  // stage "q"
+#define GLOAD(S, K0)                                                                             \
+    if ((K0) < kend) {                                                                           \
+        S##a0 = *(const double2 *)(Ag + (K0)); S##a1 = *(const double2 *)(Ag + (K0) + 2);        \
+        S##a2 = *(const double2 *)(Ag + (K0) + 4); S##a3 = *(const double2 *)(Ag + (K0) + 6);    \
+        S##b0 = *(const double2 *)(Bg + (K0)); S##b1 = *(const double2 *)(Bg + (K0) + 2);        \
+        S##b2 = *(const double2 *)(Bg + (K0) + 4); S##b3 = *(const double2 *)(Bg + (K0) + 6);    \
+    }
+#define LSTORE(S, BUF)                                                                           \
+    {                                                                                            \
+        double *da = &As[BUF][lr * LD + lk], *db = &Bs[BUF][lr * LD + lk];                       \
+        *(double2 *)(da) = S##a0; *(double2 *)(da + 2) = S##a1;                                  \
+        *(double2 *)(da + 4) = S##a2; *(double2 *)(da + 6) = S##a3;                              \
+        *(double2 *)(db) = S##b0; *(double2 *)(db + 2) = S##b1;                                  \
+        *(double2 *)(db + 4) = S##b2; *(double2 *)(db + 6) = S##b3;                              \
+    }
+        const int fa = (wr * 32 + (lane & 15)) * LD + (lane >> 4);
+        const int fb = (wc * 32 + (lane & 15)) * LD + (lane >> 4);
+        auto compute = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                As[buf][lr * LDS_LD + lk + q] = ra[q];
-                Bs[buf][lr * LDS_LD + lk + q] = rb[q];
-            }
-        };
-        gload(kbeg);
-        lstore(0);
-        __syncthreads();
-        int buf = 0;
-        const int fa = (wr * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
-        const int fb = (wc * 32 + (lane & 15)) * LDS_LD + (lane >> 4);
-        for (int k0 = kbeg; k0 < kend; k0 += KT) {
-            const bool more = k0 + KT < kend;
-            if (more) gload(k0 + KT);
-#pragma unroll
-            for (int kk = 0; kk < KT; kk += 4) {
-                const double a0 = As[buf][fa + kk], a1 = As[buf][fa + 16 * LDS_LD + kk];
-                const double b0 = Bs[buf][fb + kk], b1 = Bs[buf][fb + 16 * LDS_LD + kk];
+            for (int kk = 0; kk < KS; kk += 4) {
+                const double a0 = As[buf][fa + kk], a1 = As[buf][fa + 16 * LD + kk];
+                const double b0 = Bs[buf][fb + kk], b1 = Bs[buf][fb + 16 * LD + kk];
                 acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
             }
-            if (more) {
-                lstore(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            }
+        };
+        // prologue: stage 0 -> LDS buffer 0, stage 1 and 2 in flight in registers
+        pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = make_double2(0.0, 0.0);
+        qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = make_double2(0.0, 0.0);
+        GLOAD(p, kbeg);
+        GLOAD(q, kbeg + KS);
+        LSTORE(p, 0);
+        GLOAD(p, kbeg + 2 * KS);
+        __syncthreads();
+        // steady state, unrolled by two so the register stages keep static names
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * KS) {
+            // buffer 0 holds stage k0; s1 = stage k0+KS; s0 = stage k0+2KS
+            if (k0 + KS < kend) LSTORE(q, 1);
+            GLOAD(q, k0 + 3 * KS);
+            compute(0);
+            __syncthreads();
+            if (k0 + KS >= kend) break;
+            // buffer 1 holds stage k0+KS; s0 = stage k0+2KS; s1 = stage k0+3KS
+            if (k0 + 2 * KS < kend) LSTORE(p, 0);
+            GLOAD(p, k0 + 4 * KS);
+            compute(1);
+            __syncthreads();
         }
     }
 
+#undef GLOAD
+#undef LSTORE
+    const long long t_loop = g.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
     // ------------------------------------------------------------------ epilogues
     // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
     double esum = 0.0;
@@ -150,25 +190,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                     } else if (EPI == EPI_SUBLOWER) {
                         if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] -= v;
                     } else if (EPI == EPI_KERNEL) {
-                        if (row < p.M && col < p.N && g.row_slot[row] == g.col_slot[col]) {
-                            const bool rl = p.row_nn ? p.row_nn[row] == 0 : false;
-                            const bool cl = p.col_nn ? p.col_nn[col] == 0 : false;
-                            double k = 0.0, kp = 0.0;
-                            if (!rl && !cl) {
-                                if (g.ieta >= 1) {
-                                    const double pm1 = ipow_d(v, g.ieta - 1);
-                                    k = pm1 * v;
-                                    kp = g.ieta * pm1;
-                                } else {
-                                    k = pow(v, p.eta);
-                                    kp = p.eta * pow(v, p.eta - 1.0);
-                                }
-                            } else if (rl && cl)
-                                k = 1.0;  // similarity/similarity.py:94-103
-                            const double mu = p.mu ? p.mu[col] : 0.0;
+                        // branch-free: per-row / per-column metadata was fetched before the main
+                        // loop (a load inside a data-dependent branch cost one L2 round trip per
+                        // element: 24.7k cycles of epilogue, measured with s_memtime stamps)
+                        const bool same = e_rs[tm][r] == e_cs[tn];
+                        const bool rl = e_rn[tm][r] == 0, cl = e_cn[tn] == 0;
+                        double pm1;
+                        if (g.ieta >= 1) {
+                            pm1 = 1.0;
+                            for (int q = 1; q < g.ieta; q++) pm1 *= v;
+                        } else
+                            pm1 = pow(v, p.eta - 1.0);
+                        const double eta_d = g.ieta >= 1 ? (double)g.ieta : p.eta;
+                        double k = (!rl && !cl) ? pm1 * v : ((rl && cl) ? 1.0 : 0.0);  // similarity.py:94-103
+                        const double kp = (!rl && !cl) ? eta_d * pm1 : 0.0;
+                        if (same && row < p.M && col < p.N) {
                             p.C[(size_t)row * p.ldc + col] = k;
-                            if (p.Aw) p.Aw[(size_t)row * p.ldc + col] = mu * kp;
-                            esum += k * mu;
+                            if (p.Aw) p.Aw[(size_t)row * p.ldc + col] = e_mu[tn] * kp;
+                            esum += k * e_mu[tn];
                         }
                     } else {  // EPI_ROWSQ
                         if (col < p.N) rsq[r] += v * v;
@@ -194,7 +233,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
         if (lane == 0) red[wave] = esum;
         __syncthreads();
-        if (tid == 0) g.Epart[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (tid == 0) g.Epart[p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct] = red[0] + red[1] + red[2] + red[3];
+    }
+    if (g.stamps && threadIdx.x == 0) {
+        long long *o = g.stamps + (size_t)blockIdx.x * 4;
+        o[0] = t_start; o[1] = t_loop; o[2] = (long long)__builtin_amdgcn_s_memtime(); o[3] = kend - kbeg;
     }
 }
 
@@ -207,7 +250,12 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
     g.row_slot = p.row_slot;
     g.col_slot = p.col_slot;
     g.Epart = p.Esum;
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM), block(256);
+    g.stamps = p.stamps;
+    g.row_tiles = (p.M + BM - 1) / BM;
+    g.col_tiles = (p.N + BN - 1) / BN;
+    g.rows_pad = (g.row_tiles + 7) / 8 * 8;
+    dim3 grid(p.tiles ? p.ntiles : g.rows_pad * g.col_tiles), block(256);
+    if (p.tiles && p.ntiles <= 0) return;
     if (epi == EPI_STORE) hipLaunchKernelGGL(gemm_nt_kernel<EPI_STORE>, grid, block, 0, st, g);
     else if (epi == EPI_KERNEL) hipLaunchKernelGGL(gemm_nt_kernel<EPI_KERNEL>, grid, block, 0, st, g);
     else if (epi == EPI_SUBLOWER) hipLaunchKernelGGL(gemm_nt_kernel<EPI_SUBLOWER>, grid, block, 0, st, g);

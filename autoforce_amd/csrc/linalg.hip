@@ -107,7 +107,7 @@ int launch_cholesky_lower(int m, double *A, int ld, int *info, hipStream_t st)
         if (below > 0) {
             // A22 -= L21 L21^T on the MFMA GEMM (lower tiles only)
             GemmParams g = {};
-            g.M = below; g.N = below; g.K = (nb + 15) / 16 * 16;
+            g.M = below; g.N = below; g.K = (nb + 31) / 32 * 32;
             g.lda = ld; g.ldb = ld; g.ldc = ld;
             g.A = A + (size_t)(k0 + nb) * ld + k0;
             g.B = g.A;

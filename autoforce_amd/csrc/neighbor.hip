@@ -5,12 +5,15 @@
 // |x_j - x_i + off.cell| < rc and (j,off) != (i,0); periodic self-images are kept.
 // General triclinic cells, any pbc combination, atoms may sit outside the cell.
 //
-// Two launches:
-//   nl_bin_kernel   ONE workgroup (1024 threads), everything in LDS: species-sort gather of the
-//                   caller's positions, bin grid derived from the (device-resident) cell, LDS
-//                   counters + scan + fill + per-bin index sort (deterministic order), then a
-//                   coalesced write of the binned copies (index, position, wrap) and the zeroing
-//                   of the step's accumulators.
+// Four launches (a one-workgroup version of the binning measured 37 us at 4096 atoms: a single
+// CU moves ~10 B/clk, so the binning is spread over N/256 workgroups instead):
+//   nl_bin1_kernel    species-sort gather of the caller's positions, bin grid from the
+//                     (device-resident) cell, bin/wrap per atom, deterministic in-workgroup rank
+//                     of each atom among its bin-mates, per-(bin, workgroup) counts; also clears
+//                     the step's accumulators.
+//   nl_scan_kernel    one workgroup: exclusive scan of the counts in (bin, workgroup) order.
+//   nl_scatter_kernel binned copies (index, position, wrap): index-sorted inside every bin, no
+//                     sort pass, no atomics -> neighbour order is reproducible run to run.
 //   nl_build_kernel one wave64 per atom: the (2R+1)^3 neighbouring bins are flattened into one
 //                   candidate range (lane-parallel prefix over bins), swept 64 candidates at a
 //                   time from the binned copies (one coalesced load level), and the hits are
@@ -18,7 +21,6 @@
 #include "sgpr_internal.h"
 
 #define NL_MAX_BINS 4096
-#define NL_LDS_ATOMS 16384
 
 struct NlGrid {
     double inv[9];   // inverse cell (columns = reciprocal vectors): frac = pos . inv
@@ -34,7 +36,7 @@ __device__ __forceinline__ double det3d(const double *h)
 }
 
 struct BinArgs {
-    int N;
+    int N, nwg;
     const int *perm;        // sorted -> caller (may be null: identity)
     const double *pos_in;   // caller order
     const double *cell;
@@ -47,68 +49,71 @@ struct BinArgs {
     double *b_pos;          // [N][3] its position
     int *b_wrap;            // [N][3] its wrap (floor of the fractional coordinate)
     int *bin_of;            // [N]
+    int *rank_of;           // [N] rank of the atom among the same-bin atoms of its workgroup
     int *wrap;              // [N][3]
-    int *stat;              // [4]
+    int *hist;              // [nbins][nwg] same-bin counts per workgroup (zero between steps)
+    int *offs;              // [nbins][nwg] exclusive prefix of hist in (bin, workgroup) order
     double *zero_a; int n_zero_a;   // accumulators to clear for this step
     double *zero_b; int n_zero_b;
-    int *atoms_glob;        // fallback storage when N > NL_LDS_ATOMS
 };
 
-__global__ __launch_bounds__(1024) void nl_bin_kernel(BinArgs a)
+__device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGrid &g)
 {
-    __shared__ int cnt[NL_MAX_BINS];
-    __shared__ int start[NL_MAX_BINS + 1];
-    __shared__ int part[1024];
-    __shared__ NlGrid g;
-    extern __shared__ int atoms_lds[];
-    const int tid = threadIdx.x;
-    const int N = a.N;
-    int *atoms = N <= NL_LDS_ATOMS ? atoms_lds : a.atoms_glob;
-    if (tid == 0) {
-        double h[9];
-        for (int k = 0; k < 9; k++) h[k] = a.cell[k];
-        const double dt = det3d(h);
-        if (fabs(dt) > 1e-12) {
-            const double *p = h, *q = h + 3, *r = h + 6;
-            const double bc[3] = {q[1] * r[2] - q[2] * r[1], q[2] * r[0] - q[0] * r[2], q[0] * r[1] - q[1] * r[0]};
-            const double ca[3] = {r[1] * p[2] - r[2] * p[1], r[2] * p[0] - r[0] * p[2], r[0] * p[1] - r[1] * p[0]};
-            const double ab[3] = {p[1] * q[2] - p[2] * q[1], p[2] * q[0] - p[0] * q[2], p[0] * q[1] - p[1] * q[0]};
-            for (int k = 0; k < 3; k++) {
-                g.inv[3 * k + 0] = bc[k] / dt;
-                g.inv[3 * k + 1] = ca[k] / dt;
-                g.inv[3 * k + 2] = ab[k] / dt;
-            }
-            const double V = fabs(dt);
-            const double hgt[3] = {V / sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
-                                   V / sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
-                                   V / sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
-            for (int k = 0; k < 3; k++) {
-                if (a.pbc[k]) {
-                    int nb = (int)floor(hgt[k] / a.rc);
-                    nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
-                    g.nb[k] = nb;
-                    g.rng[k] = (int)ceil(a.rc * nb / hgt[k]);
-                } else {
-                    g.nb[k] = 1;  // open direction: one slab, no images
-                    g.rng[k] = 0;
-                }
-            }
-        } else {
-            // no usable cell (cluster): everything in one bin, no images
-            for (int k = 0; k < 9; k++) g.inv[k] = 0.0;
-            for (int k = 0; k < 3; k++) { g.nb[k] = 1; g.rng[k] = 0; }
+    double h[9];
+    for (int k = 0; k < 9; k++) h[k] = cell[k];
+    const double dt = det3d(h);
+    if (fabs(dt) > 1e-12) {
+        const double *p = h, *q = h + 3, *r = h + 6;
+        const double bc[3] = {q[1] * r[2] - q[2] * r[1], q[2] * r[0] - q[0] * r[2], q[0] * r[1] - q[1] * r[0]};
+        const double ca[3] = {r[1] * p[2] - r[2] * p[1], r[2] * p[0] - r[0] * p[2], r[0] * p[1] - r[1] * p[0]};
+        const double ab[3] = {p[1] * q[2] - p[2] * q[1], p[2] * q[0] - p[0] * q[2], p[0] * q[1] - p[1] * q[0]};
+        for (int k = 0; k < 3; k++) {
+            g.inv[3 * k + 0] = bc[k] / dt;
+            g.inv[3 * k + 1] = ca[k] / dt;
+            g.inv[3 * k + 2] = ab[k] / dt;
         }
-        g.nbins = g.nb[0] * g.nb[1] * g.nb[2];
-        *a.grid = g;
-        a.stat[0] = 0;  // max neighbour count seen by the build kernel
+        const double V = fabs(dt);
+        const double hgt[3] = {V / sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]),
+                               V / sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]),
+                               V / sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2])};
+        for (int k = 0; k < 3; k++) {
+            if (pbc[k]) {
+                int nb = (int)floor(hgt[k] / rc);
+                nb = nb < 1 ? 1 : (nb > 16 ? 16 : nb);
+                g.nb[k] = nb;
+                g.rng[k] = (int)ceil(rc * nb / hgt[k]);
+            } else {
+                g.nb[k] = 1;  // open direction: one slab, no images
+                g.rng[k] = 0;
+            }
+        }
+    } else {
+        // no usable cell (cluster): everything in one bin, no images
+        for (int k = 0; k < 9; k++) g.inv[k] = 0.0;
+        for (int k = 0; k < 3; k++) { g.nb[k] = 1; g.rng[k] = 0; }
     }
-    for (int k = tid; k < a.n_zero_a; k += 1024) a.zero_a[k] = 0.0;
-    for (int k = tid; k < a.n_zero_b; k += 1024) a.zero_b[k] = 0.0;
+    g.nbins = g.nb[0] * g.nb[1] * g.nb[2];
+}
+
+// K1: 256 atoms per workgroup.  Species-sort gather, bin + wrap, and a DETERMINISTIC rank of every
+// atom among the same-bin atoms of its workgroup (counting lower lanes; index order is kept, so
+// the binned lists come out index-sorted with no sort pass and no atomics).
+__global__ __launch_bounds__(256) void nl_bin1_kernel(BinArgs a)
+{
+    __shared__ NlGrid g;
+    __shared__ int sbin[256];
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    if (tid == 0) {
+        nl_make_grid(a.cell, a.pbc, a.rc, g);
+        if (wg == 0) *a.grid = g;
+    }
+    const int gsz = gridDim.x * 256, gid = wg * 256 + tid;
+    for (int k = gid; k < a.n_zero_a; k += gsz) a.zero_a[k] = 0.0;
+    for (int k = gid; k < a.n_zero_b; k += gsz) a.zero_b[k] = 0.0;
     __syncthreads();
-    const int nbins = g.nbins;
-    for (int b = tid; b < nbins; b += 1024) cnt[b] = 0;
-    __syncthreads();
-    for (int i = tid; i < N; i += 1024) {
+    const int i = gid;
+    int bin = -1;
+    if (i < a.N) {
         const int c = a.perm ? a.perm[i] : i;
         const double x = a.pos_in[3 * c], y = a.pos_in[3 * c + 1], z = a.pos_in[3 * c + 2];
         a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
@@ -127,70 +132,80 @@ __global__ __launch_bounds__(1024) void nl_bin_kernel(BinArgs a)
             }
             a.wrap[3 * i + k] = w;
         }
-        const int bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
+        bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
         a.bin_of[i] = bin;
-        atomicAdd(&cnt[bin], 1);
     }
+    sbin[tid] = bin;
     __syncthreads();
-    // exclusive scan of cnt[0..nbins) -> start
-    const int per = (nbins + 1023) / 1024;
-    int loc = 0;
-    for (int k = 0; k < per; k++) {
-        const int b = tid * per + k;
-        if (b < nbins) loc += cnt[b];
-    }
-    part[tid] = loc;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = part[tid] - loc;
-    for (int k = 0; k < per; k++) {
-        const int b = tid * per + k;
-        if (b < nbins) {
-            start[b] = run;
-            run += cnt[b];
+    if (i < a.N) {
+        int below = 0, total = 0;
+        for (int t = 0; t < 256; t++) {
+            const int same = sbin[t] == bin;
+            total += same;
+            below += same & (t < tid);
         }
+        a.rank_of[i] = below;
+        if (below == 0) a.hist[bin * a.nwg + wg] = total;
     }
-    if (tid == 0) start[nbins] = N;
+}
+
+// K2: one workgroup scans hist in (bin, workgroup) order, emits offs and bin_start, and clears
+// hist for the next step.
+__global__ __launch_bounds__(1024) void nl_scan_kernel(BinArgs a)
+{
+    __shared__ int part[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const NlGrid g = *a.grid;
+    const int n = g.nbins * a.nwg;
+    if (tid == 0) carry = 0;
     __syncthreads();
-    for (int b = tid; b <= nbins; b += 1024) a.bin_start[b] = start[b];
-    for (int b = tid; b < nbins; b += 1024) cnt[b] = 0;
-    __syncthreads();
-    for (int i = tid; i < N; i += 1024) {
-        const int bin = a.bin_of[i];  // written by this same thread above
-        const int k = atomicAdd(&cnt[bin], 1);
-        atoms[start[bin] + k] = i;
-    }
-    __threadfence_block();
-    __syncthreads();
-    // index-sort each bin (insertion sort; bins hold ~rc^3 * density atoms): deterministic lists
-    for (int b = tid; b < nbins; b += 1024) {
-        const int s = start[b], e = start[b + 1];
-        for (int p = s + 1; p < e; p++) {
-            const int v = atoms[p];
-            int q = p - 1;
-            while (q >= s && atoms[q] > v) {
-                atoms[q + 1] = atoms[q];
-                q--;
-            }
-            atoms[q + 1] = v;
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int k = tid; k < N; k += 1024) {
-        const int i = atoms[k];
-        const int c = a.perm ? a.perm[i] : i;
-        a.b_idx[k] = i;
+    for (int base = 0; base < n; base += 4096) {
+        int v[4], loc = 0;
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            a.b_pos[3 * k + q] = a.pos_in[3 * c + q];
-            a.b_wrap[3 * k + q] = a.wrap[3 * i + q];  // ordered by the fence + barrier above
+        for (int k = 0; k < 4; k++) {
+            const int e = base + tid * 4 + k;
+            v[k] = e < n ? a.hist[e] : 0;
+            loc += v[k];
         }
+        int incl = loc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) part[wv] = incl;
+        __syncthreads();
+        int run = carry + incl - loc;
+        for (int w = 0; w < wv; w++) run += part[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = base + tid * 4 + k;
+            if (e < n) {
+                a.offs[e] = run;
+                a.hist[e] = 0;
+                if (e % a.nwg == 0) a.bin_start[e / a.nwg] = run;
+                run += v[k];
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) a.bin_start[g.nbins] = a.N;
+}
+
+// K3: scatter into the binned copies (index, position, wrap).
+__global__ __launch_bounds__(256) void nl_scatter_kernel(BinArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.N) return;
+    const int k = a.offs[a.bin_of[i] * a.nwg + blockIdx.x] + a.rank_of[i];
+    a.b_idx[k] = i;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        a.b_pos[3 * k + q] = a.pos[3 * i + q];
+        a.b_wrap[3 * k + q] = a.wrap[3 * i + q];
     }
 }
 
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
                                                        const int *bin_of, const int *bin_start, const int *b_idx,
                                                        const double *b_pos, const int *b_wrap, const int *wrap,
                                                        int maxnn, int *nn, int *nn_local, int *nbr_j,
-                                                       int *nbr_shift, int *stat)
+                                                       int *nbr_shift, int *nn_raw)
 {
     __shared__ int s_start[4][64], s_pref[4][65], s_code[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     if (lane == 0) {
         nn[i] = base < maxnn ? base : maxnn;
         nn_local[il] = base < maxnn ? base : maxnn;
-        atomicMax(&stat[0], base);
+        nn_raw[il] = base;  // unclamped: finalize reduces the max for the overflow check
     }
 }
 
@@ -294,22 +309,17 @@ void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_
 {
     if (p.N <= 0) return;
     BinArgs a = {};
-    a.N = p.N; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
+    a.N = p.N; a.nwg = (p.N + 255) / 256; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
     for (int k = 0; k < 3; k++) a.pbc[k] = p.pbc[k];
     a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_start = s.bin_start; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
-    a.b_wrap = s.b_wrap; a.bin_of = s.bin_of; a.wrap = s.wrap; a.stat = s.stat;
+    a.b_wrap = s.b_wrap; a.bin_of = s.bin_of; a.rank_of = s.rank_of; a.wrap = s.wrap; a.hist = s.hist; a.offs = s.offs;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
-    a.atoms_glob = s.atoms_glob;
-    const size_t dyn = p.N <= NL_LDS_ATOMS ? sizeof(int) * (size_t)p.N : 0;
-    static size_t attr = 0;
-    if (dyn > attr) {
-        (void)hipFuncSetAttribute((const void *)nl_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        attr = dyn;
-    }
-    hipLaunchKernelGGL(nl_bin_kernel, dim3(1), dim3(1024), dyn, st, a);
+    hipLaunchKernelGGL(nl_bin1_kernel, dim3(a.nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(nl_scatter_kernel, dim3(a.nwg), dim3(256), 0, st, a);
     if (p.count > 0)
         hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first,
                            p.stride > 0 ? p.stride : 1, p.count, pos, cell, rc, (const NlGrid *)s.grid, s.bin_of,
                            s.bin_start, s.b_idx, s.b_pos, s.b_wrap, s.wrap, p.maxnn, nn, nn_local, nbr_j, nbr_shift,
-                           s.stat);
+                           s.nn_raw);
 }

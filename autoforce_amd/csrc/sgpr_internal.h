@@ -52,7 +52,9 @@ struct NlScratch {
     int *b_wrap;       // [N][3]
     int *wrap;         // [N][3]
     int *stat;         // [4]
-    int *atoms_glob;   // [N]    only used when N exceeds the LDS-resident limit
+    int *rank_of;      // [N]
+    int *hist, *offs;  // [4096 * ceil(N/256)] each; hist must be zero on entry (the scan re-zeroes it)
+    int *nn_raw;       // [count] unclamped neighbour counts (overflow check)
 };
 
 // Bins ALL N atoms (also: gathers pos_in[perm] -> pos in species-sorted order and clears the
@@ -88,8 +90,9 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const int *slot, const double *radii, const int *nn, const int *nbr_j,
                                const int *nbr_shift, const PackEntry *pack, const double *Pn,
                                const double *norm, const double *C, const int *shear,
-                               const double *W /*[N][Dpad] dE/dp-hat*/, double *F /*[Nall][3]*/,
-                               double *virial /*[9]*/, hipStream_t st);
+                               const double *W /*[N][Dpad] dE/dp-hat*/, double *dC /*[N][CS] scratch*/,
+                               double *F /*[2][Nall][3]: atomic part | own part*/,
+                               double *virial /*[9][workgroups]*/, hipStream_t st);
 
 // Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
 void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,
@@ -103,13 +106,11 @@ struct GemmParams {
     int lda, ldb, ldc;
     const double *A, *B;
     double *C;
-    // species structure (sorted operands): row r of A belongs to species block
-    // rowblk(r); tiles outside the allowed ranges are skipped / their K loop trimmed.
-    int S;
-    const int *row_off;   // [S+1] offsets of species blocks along M  (device)
-    const int *col_off;   // [S+1] offsets of species blocks along N  (device), may be null
-    const int *k_off;     // [S+1] offsets of species blocks along K  (device), may be null
-    int tri;              // EPI_ROWSQ: B is lower-triangular (k <= col)
+    // species structure (sorted operands): optional host-built list of working tiles
+    // {row tile, col tile, kbeg, kend} (kend <= kbeg marks a padding entry); null = dense.
+    const int4 *tiles;
+    int ntiles;
+    int tri;              // unused by the kernel (the tile table carries the trimmed k range)
     // EPI_KERNEL extras
     double eta;
     const double *mu;     // [N]
@@ -121,6 +122,7 @@ struct GemmParams {
     const int *col_slot;  // [N] species slot per column
     // EPI_ROWSQ extras
     double *rowsq;        // [M] accumulators (atomicAdd)
+    long long *stamps;    // diagnostic only
 };
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st);
 
