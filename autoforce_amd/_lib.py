@@ -52,6 +52,27 @@ SIGNATURES = {
 }
 
 
+def _preload_host_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+    /opt/rocm's); whichever is mapped first serves both.  If the system runtime wins, a later
+    `import torch` finds no GPU ("No HIP GPUs are available").  Hosts that use torch for device
+    memory / torch.distributed next to this library therefore get torch's runtime mapped first —
+    located via importlib, WITHOUT importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load the shared library (no GPU needed to load; needed for every compute call)."""
     global _lib
@@ -61,6 +82,7 @@ def load():
                 f"{LIB_PATH} is missing: build it with autoforce_amd/csrc/build.sh "
                 "(or __graft_entry__.build()).  There is no CPU fallback."
             )
+        _preload_host_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -1,0 +1,155 @@
+"""GPU tests of the calculator surface, the device-resident step (HIP graph replay), model IO and
+the full-size BASELINE workload (4096 atoms / 512 inducing) against the oracle and through
+size-independent properties."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load
+
+pytestmark = pytest.mark.gpu
+
+
+def model_from_fixture(g):
+    from autoforce_amd import Local, SGPRModel
+    mdl = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=g["species"].tolist())
+    ptr = g["ind_ptr"]
+    mdl.set_inducing([Local(int(z), g["ind_nbr_z"][ptr[q]:ptr[q + 1]], g["ind_nbr_r"][ptr[q]:ptr[q + 1]])
+                      for q, z in enumerate(g["ind_z"])])
+    vs = dict(zip(g["vscale_z"].tolist(), g["vscale"].tolist()))
+    mdl.set_weights(g["mu"], vscale=vs, choli=g["choli"])
+    return mdl
+
+
+def test_calculator_on_hip(tmp_path):
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    g = load("g5_mixed64")
+    calc = ActiveCalculator(covariance=model_from_fixture(g), logfile=str(tmp_path / "active.log"))
+    atoms = Atoms(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    atoms.calc = calc
+    assert abs(atoms.get_potential_energy() - float(g["energy"])) < 1e-10
+    assert np.abs(atoms.get_forces() - g["forces"]).max() <= 1e-9 * np.abs(g["forces"]).max()
+    assert np.abs(atoms.get_stress() - g["stress"]).max() <= 1e-9 * np.abs(g["stress"]).max()
+    ok = np.isfinite(g["covloss"])
+    np.testing.assert_allclose(calc.get_covloss()[ok], g["covloss"][ok], rtol=0, atol=1e-6)
+    assert calc.step == 1 and calc.size == (0, 24)
+
+
+def test_model_io_roundtrip(tmp_path):
+    from autoforce_amd.modelio import load_model, save_model
+    g = load("g5_tric24")
+    mdl = model_from_fixture(g)
+    ref = mdl.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    path = str(tmp_path / "model.npz")
+    save_model(path, mdl)
+    mdl.close()
+    m2 = load_model(path)
+    out = m2.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    for k in ("energy", "forces", "stress", "beta"):
+        np.testing.assert_array_equal(np.asarray(out[k]), np.asarray(ref[k]))
+    m2.close()
+
+
+def test_device_step_matches_host_step_and_replays():
+    """sgpr_step_dev (device pointers, HIP-graph replay) gives bit-identical packed results to
+    sgpr_compute, also after the atoms moved (same graph, new positions in the same buffer)."""
+    import torch
+    from autoforce_amd import _lib
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    lib = _lib.load()
+    N = len(g["numbers"])
+    dev = torch.device("cuda", 0)
+    pos = torch.from_numpy(g["positions"].copy()).to(dev)
+    cell = torch.from_numpy(g["cell"].copy()).to(dev)
+    packed = torch.zeros(int(lib.sgpr_packed_len(N)), dtype=torch.float64, device=dev)
+    _lib.check(lib.sgpr_bind_system(mdl.handle, N, _lib.ptr(_lib.i32(g["numbers"])),
+                                    _lib.ptr(_lib.i32(g["pbc"].astype(np.int32))), 0, 1))
+    sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rng = np.random.default_rng(0)
+    for it in range(4):  # 1st eager+checked, 2nd captures, 3rd/4th replay
+        if it >= 2:
+            pos += torch.from_numpy(0.02 * rng.normal(size=(N, 3))).to(dev)
+        _lib.check(lib.sgpr_step_dev(mdl.handle, pos.data_ptr(), cell.data_ptr(), packed.data_ptr(), sp))
+        _lib.check(lib.sgpr_sync_check(mdl.handle, sp))
+        got = packed.cpu().numpy().copy()
+        ref = mdl.predict(g["numbers"], pos.cpu().numpy(), g["cell"], g["pbc"])
+        # predict() re-binds nothing (same system) but leaves the graph valid
+        np.testing.assert_array_equal(got[:3 * N].reshape(N, 3), ref["forces"])
+        np.testing.assert_array_equal(got[3 * N:4 * N], ref["beta"])
+        assert got[4 * N] == ref["energy"]
+        s = np.zeros(6)
+        lib.sgpr_stress_from_virial(_lib.ptr(got[4 * N + 1:4 * N + 10].copy()), _lib.ptr(g["cell"].copy()), _lib.ptr(s))
+        np.testing.assert_array_equal(s, ref["stress"])
+    mdl.close()
+
+
+def _lips_model(n_side, m, seed=1):
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.workloads import inducing_from_frame, lips
+    numbers, pos, cell, pbc = lips(n_side, seed=0)
+    mdl = SGPRModel(3, 3, 4, 6.0, species=[3, 15, 16])
+    n2, p2, c2, b2 = lips(n_side, seed=seed)
+    mdl.set_inducing(inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=seed))
+    rng = np.random.default_rng(2)
+    mdl.solve(rng.normal(size=(64, m)), rng.normal(size=64))
+    mu = rng.normal(size=m)
+    mdl.set_weights(mu, choli=mdl.choli, vscale=mdl.make_vscale())
+    return mdl, numbers, pos, cell, pbc
+
+
+def test_full_size_lips4096_against_oracle():
+    """BASELINE configs[2] sizes: 4096 atoms, 3 species, 512 inducing.  north_star tolerance:
+    forces within 1e-6 relative of the CPU path; held to 1e-8 here."""
+    from oracle import oracle as orc
+    mdl, numbers, pos, cell, pbc = _lips_model(16, 512)
+    out = mdl.predict(numbers, pos, cell, pbc, cov=True)
+    X = mdl.X
+    species = np.array(mdl.species, np.int32)
+    ind_z = np.array([x.number for x in X], np.int32)
+    ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
+    Pm, nnm = orc.inducing_descriptors(3, 3, 6.0, species, ind_z, ind_ptr, np.concatenate([x._b for x in X]),
+                                       np.concatenate([x._r for x in X]))
+    M = orc.kernel_matrix(ind_z, nnm, Pm, ind_z, nnm, Pm, 4.0)
+    np.testing.assert_allclose(mdl.M, M, rtol=1e-10, atol=1e-13)
+    nl = orc.neighbors(pos, cell, pbc, 6.0) if False else mdl.neighbors(len(numbers))  # O(N^2 images) on CPU is slow
+    ref = orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mdl.mu, choli=mdl.choli)
+    np.testing.assert_allclose(out["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
+    assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
+    assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
+    assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
+    vs = np.sqrt([mdl._vscale[int(z)] for z in numbers])
+    np.testing.assert_allclose(out["beta"], ref["beta"] * vs, rtol=0, atol=2e-6 * vs.max())
+    mdl.close()
+
+
+def test_full_size_properties():
+    """Size-independent properties at 4096 atoms: Newton's third law, translation invariance,
+    invariance under a permutation of the caller's atom order, virial = -sum r_i (x) F_i for a
+    non-periodic copy (no image terms), and neighbour-list symmetry."""
+    mdl, numbers, pos, cell, pbc = _lips_model(16, 512)
+    N = len(numbers)
+    a = mdl.predict(numbers, pos, cell, pbc)
+    fmax = np.abs(a["forces"]).max()
+    assert np.abs(a["forces"].sum(0)).max() <= 1e-9 * fmax
+    ptr, j, off = mdl.neighbors(N)
+    i = np.repeat(np.arange(N), np.diff(ptr))
+    fwd = set(zip(i.tolist(), j.tolist(), map(tuple, off.tolist())))
+    assert all((jj, ii, (-o[0], -o[1], -o[2])) in fwd for ii, jj, o in list(fwd)[:20000])
+    b = mdl.predict(numbers, pos + np.array([1.234, -5.1, 77.7]), cell, pbc)  # atoms far outside the cell
+    assert abs(b["energy"] - a["energy"]) <= 1e-9 * abs(a["energy"])
+    assert np.abs(b["forces"] - a["forces"]).max() <= 1e-8 * fmax
+    perm = np.random.default_rng(3).permutation(N)
+    c = mdl.predict(numbers[perm], pos[perm], cell, pbc)
+    assert abs(c["energy"] - a["energy"]) <= 1e-10 * abs(a["energy"])
+    assert np.abs(c["forces"] - a["forces"][perm]).max() <= 1e-9 * fmax
+    np.testing.assert_allclose(c["beta"], a["beta"][perm], rtol=0, atol=1e-7)
+    # open boundaries: stress * V == -sum_i r_i (x) F_i exactly (calculator/active.py:604-610 with dcell = 0)
+    d = mdl.predict(numbers[:512], pos[:512], cell, [False] * 3)
+    vir = -(pos[:512][:, :, None] * d["forces"][:, None, :]).sum(0)
+    want = vir.flat[[0, 4, 8, 5, 2, 1]] / abs(np.linalg.det(cell))
+    assert np.abs(d["stress"] - want).max() <= 1e-8 * np.abs(want).max()
+    mdl.close()
