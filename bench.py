@@ -173,6 +173,17 @@ def main():
     stage_ms = {k: v / nprof for k, v in acc.items()}
     dims = mdl.dims
     out_host = packed.cpu().numpy()
+    # PCIe-inclusive rate of the host-array entry point (never `value`): numpy in, numpy out
+    host_rate = None
+    if world == 1:
+        mdl.predict(numbers, pos, cell, pbc, beta=True)
+        th = time.perf_counter()
+        nh = 20
+        for _ in range(nh):
+            mdl.predict(numbers, pos, cell, pbc, beta=True)
+        host_rate = N * nh / (time.perf_counter() - th)
+        _lib.check(lib.sgpr_bind_system(h, N, _lib.ptr(_lib.i32(numbers)), _lib.ptr(_lib.i32(pbc.astype(np.int32))),
+                                        rank, world))
 
     result = None
     if rank == 0:
@@ -219,6 +230,7 @@ def main():
                 "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
                 "packed_row": Dc, "graph": not args.no_graph,
+                "host_array_path_atom_steps_per_s": host_rate,
                 "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step",
             },
             "roofline": roof,
