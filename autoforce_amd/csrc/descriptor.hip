@@ -30,6 +30,14 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// wave-uniform value into SGPRs (keeps cell / centre position out of the VGPR budget)
+__device__ __forceinline__ double uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -192,7 +200,7 @@ template <int LMAX, int NMAX>
 struct WaveLds {
     static constexpr int L1 = LMAX + 1, N1 = NMAX + 1, LL = L1 * L1, LLP = LL + 1, NSLOT = N1 * LL;
     // doubles per wave for the neighbour tile
-    static constexpr int TILE_D = 64 * 3 + 64 * N1 + 64 * LLP;
+    static constexpr int TILE_D = 64 * N1 + 64 * LLP;
 };
 
 // =========================================================================== forward
@@ -208,8 +216,7 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
     if (ia >= a.N) return;
     const int gi = a.first + ia * a.stride;
     const int perwave = WL::TILE_D + ST * NSLOT + 64 / 2;  // + 64 ints
-    double *xs = smem + (size_t)wave * perwave;  // [64][3]
-    double *fl = xs + 64 * 3;                    // [64][N1]
+    double *fl = smem + (size_t)wave * perwave;  // [64][N1]
     double *Yl = fl + 64 * N1;                   // [64][LLP]
     double *cl = Yl + 64 * LLP;                  // [ST][NSLOT]
     int *sl = (int *)(cl + ST * NSLOT);          // [64]
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         }
         wave_sync();
         // lane = output slot (n,lm): c[s][slot] += f[t][n] * Y[t][lm]
+#pragma unroll 4
         for (int tt = 0; tt < cnt; tt++) {
             const int s = __builtin_amdgcn_readfirstlane(sl[tt]);
 #pragma unroll
@@ -407,8 +415,8 @@ __global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
 
 // dE/dr of ONE pair term: neighbour at displacement r (unscaled), unit u, environment shear `ang`,
 // dc = dE/dc[species slot of that neighbour][n][lm] of the environment's centre.
-template <int LMAX, int NMAX>
-__device__ __forceinline__ void pair_grad(const double r[3], double u, double rc, double ang, const double *dc,
+template <int LMAX, int NMAX, typename Fetch>
+__device__ __forceinline__ void pair_grad(const double r[3], double u, double rc, double ang, Fetch fetch,
                                           double gr[3])
 {
     constexpr int N1 = NMAX + 1, LL = (LMAX + 1) * (LMAX + 1);
@@ -424,14 +432,18 @@ __device__ __forceinline__ void pair_grad(const double r[3], double u, double rc
     for (int k = 0; k < LL; k++) gY[k] = 0.0;
     const double rho = d * d;
     double rpow = 1.0;  // rho^n
-#pragma unroll
+    // rolled over the radial channels on purpose: fully unrolled, the scheduler hoisted all 64
+    // coefficient loads and the kernel needed > 256 VGPRs (1 wave per SIMD)
+#pragma unroll 1
     for (int n = 0; n < N1; n++) {
+        const double *dcn = fetch(n);  // channel n of dE/dc (LDS)
+        const double fn = g * rpow;    // f_n = g d^(2n)
         double dEdf = 0.0;
 #pragma unroll
         for (int k = 0; k < LL; k++) {
-            const double dck = dc[n * LL + k];
+            const double dck = dcn[k];
             dEdf += dck * Y[k];
-            gY[k] += f[n] * dck;
+            gY[k] += fn * dck;
         }
         // d f_n/dd = dg rho^n + g 2n d^(2n-1)
         const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow / d : 0.0);
@@ -447,18 +459,22 @@ __device__ __forceinline__ void pair_grad(const double r[3], double u, double rc
 }
 
 template <int LMAX, int NMAX, int ST, bool MIRROR>
-__global__ __launch_bounds__(256) void desc_pair_kernel(DescArgs a)
+__global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
 {
     using WL = WaveLds<LMAX, NMAX>;
-    constexpr int NSLOT = WL::NSLOT;
+    constexpr int NSLOT = WL::NSLOT, LL = WL::LL;
+    constexpr int SP = LL + 2;                // staged row stride (doubles): 16-B aligned, conflict-free
+    constexpr int G = (LL % 2 == 0) ? 2 : 1;  // doubles per load granule
+    constexpr int GR = LL / G;                // granules per row
     extern __shared__ double smem[];
     __shared__ double vred[4][9];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ia = blockIdx.x * 4 + wave;
-    double *dcl = smem + (size_t)wave * ST * NSLOT;  // [S][NSLOT] dE/dc of this atom
-    double vir[9];
+    double *dcl = smem + (size_t)wave * (ST * NSLOT + 64 * SP + 9 * 64);  // [S][NSLOT] dE/dc of this atom
+    double *stage = dcl + ST * NSLOT;                            // [64][SP] one channel of 64 mirrored rows
+    double *lv = stage + 64 * SP;                                // [9][64] per-lane virial accumulators
 #pragma unroll
-    for (int k = 0; k < 9; k++) vir[k] = 0.0;
+    for (int k = 0; k < 9; k++) lv[k * 64 + lane] = 0.0;
     double fsum[3] = {0, 0, 0};
     const bool active = ia < a.N;
     const int gi = a.first + (active ? ia : 0) * a.stride;
@@ -471,41 +487,75 @@ __global__ __launch_bounds__(256) void desc_pair_kernel(DescArgs a)
         const double uc = a.radii[sc];
         double pi[3], cell[9];
 #pragma unroll
-        for (int k = 0; k < 3; k++) pi[k] = a.pos[3 * (size_t)gi + k];
+        for (int k = 0; k < 3; k++) pi[k] = uniform(a.pos[3 * (size_t)gi + k]);
 #pragma unroll
-        for (int k = 0; k < 9; k++) cell[k] = a.cell[k];
+        for (int k = 0; k < 9; k++) cell[k] = uniform(a.cell[k]);
+        // pass 1: own terms g_t = dE_j/dr_jt (dE/dc of this atom from LDS)
         for (int t0 = 0; t0 < nn; t0 += 64) {
             const int t = t0 + lane;
             if (t < nn) {
                 double r[3], gr[3];
                 int s, j;
                 load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
-                pair_grad<LMAX, NMAX>(r, a.radii[s], a.rc, ang, dcl + s * NSLOT, gr);
+                pair_grad<LMAX, NMAX>(r, a.radii[s], a.rc, ang,
+                                      [&](int n) { return (const double *)(dcl + s * NSLOT + n * LL); }, gr);
 #pragma unroll
                 for (int p = 0; p < 3; p++)
 #pragma unroll
-                    for (int q = 0; q < 3; q++) vir[3 * p + q] += r[p] * gr[q];
-                if constexpr (MIRROR) {
-                    // atom gi as a neighbour of j: displacement -r, our species, j's shear state
-                    double rm[3] = {-r[0], -r[1], -r[2]}, gm[3];
-                    const double angm = a.shear[j] ? SGPR_TINY_ANGLE : 0.0;
-                    pair_grad<LMAX, NMAX>(rm, uc, a.rc, angm, a.dC + (size_t)j * a.CS + sc * NSLOT, gm);
+                    for (int q = 0; q < 3; q++) lv[(3 * p + q) * 64 + lane] += r[p] * gr[q];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) fsum[k] += gr[k] - gm[k];
-                } else {
+                for (int k = 0; k < 3; k++) fsum[k] += gr[k];
+                if constexpr (!MIRROR) {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        fsum[k] += gr[k];
-                        unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
+                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
+                }
+            }
+        }
+        if constexpr (MIRROR) {
+            // pass 2: mirrored terms g'_t = dE_i/dr_ij(-r): this atom as a neighbour of i, our
+            // species slot, i's shear state.  The 64 rows dC[i][our slot][n][:] are fetched
+            // cooperatively, one radial channel at a time, GR lanes per row (whole cache lines per
+            // quad of lanes), and handed to their lanes through LDS: a per-lane 512-B gather costs
+            // 4x the TA cycles.
+            for (int t0 = 0; t0 < nn; t0 += 64) {
+                const int t = t0 + lane;
+                const bool on = t < nn;
+                double r[3] = {-1.0, 0.0, 0.0}, gm[3];
+                int s = sc, j = gi;
+                if (on) {
+                    load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
+                    r[0] = -r[0]; r[1] = -r[1]; r[2] = -r[2];
+                }
+                const double angm = a.shear[j] ? SGPR_TINY_ANGLE : 0.0;
+                auto fetch_mirror = [&](int n) {
+                    wave_sync();
+#pragma unroll
+                    for (int q = 0; q < GR; q++) {
+                        const int idx = q * 64 + lane;
+                        const int row = idx / GR, gc = idx % GR;
+                        const int jr = __shfl(j, row, 64);
+                        const double *src = a.dC + (size_t)jr * a.CS + sc * NSLOT + n * LL + gc * G;
+                        if constexpr (G == 2)
+                            *(double2 *)(stage + row * SP + gc * 2) = *(const double2 *)src;
+                        else
+                            stage[row * SP + gc] = *src;
                     }
+                    wave_sync();
+                    return (const double *)(stage + lane * SP);
+                };
+                pair_grad<LMAX, NMAX>(r, uc, a.rc, angm, fetch_mirror, gm);
+                if (on) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) fsum[k] -= gm[k];
                 }
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) fsum[k] = wave_sum(fsum[k]);
+    double vir[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) vir[k] = wave_sum(vir[k]);
+    for (int k = 0; k < 9; k++) vir[k] = wave_sum(lv[k * 64 + lane]);
     // one virial partial per workgroup: the 4 waves meet in LDS (all waves reach this point)
     if (lane == 0) {
         if (active)
@@ -580,7 +630,7 @@ static int run_bwd(const DescArgs &a, hipStream_t st)
         attr_set = lds1;
     }
     hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
-    const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT);
+    const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + 64 * (WL::LL + 2) + 9 * 64);
     if (a.stride == 1 && a.first == 0 && a.N == a.Nall)
         hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, true>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
     else

@@ -182,8 +182,6 @@ def main():
         for _ in range(nh):
             mdl.predict(numbers, pos, cell, pbc, beta=True)
         host_rate = N * nh / (time.perf_counter() - th)
-        _lib.check(lib.sgpr_bind_system(h, N, _lib.ptr(_lib.i32(numbers)), _lib.ptr(_lib.i32(pbc.astype(np.int32))),
-                                        rank, world))
 
     result = None
     if rank == 0:
