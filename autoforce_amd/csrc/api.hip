@@ -62,7 +62,8 @@ struct sgpr_model {
     double eta, rc;
     std::vector<int> species;
     std::vector<double> radii;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // packed layout
     int D, Dc, Dpad, CS;
     std::vector<PackEntry> h_pack;
@@ -103,7 +104,9 @@ struct sgpr_model {
     hipGraphExec_t gexec = nullptr;
     const void *g_pos = nullptr, *g_cell = nullptr, *g_out = nullptr;
     hipStream_t g_stream = nullptr;
-    bool use_graph = true;
+    bool use_graph = false;  // eager launches pipeline fine while a step is >100 us of kernels; graph replay
+                             // measured 8 us/step slower (177 vs 169 us) — opt in with sgpr_set_option("graph",1)
+    bool use_fork = false;   // measured neutral (169.0 vs 167.6 us): kept as an option only
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev;
@@ -291,6 +294,9 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->mean_w.assign(S, 0.0);
     h->vscale.assign(S, 1.0);
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return fail(SGPR_E_NODEVICE, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) h->side = nullptr;
+    (void)hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     build_pack(h);
     h->d_pack.alloc(h->Dc, false);
     (void)hipMemcpy(h->d_pack.p, h->h_pack.data(), sizeof(PackEntry) * h->Dc, hipMemcpyHostToDevice);
@@ -348,6 +354,9 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     h->d_pack.release();
     h->d_grid.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
 }
 
@@ -741,10 +750,31 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
     stamp(h, "descriptor_fwd", st);
     const bool predict = h->m > 0 && h->has_mu && cnt > 0;
+    const bool beta = h->m > 0 && h->has_choli && cnt > 0;
     if (h->m > 0 && cnt > 0) {
         gemm_kernel_pm(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->t_knm, h->d_K.p, h->d_Aw.p,
                        h->has_mu ? h->d_mu.p : nullptr, h->d_Epart.p, st);
         stamp(h, "gemm_knm", st);
+    }
+    // The covloss product needs only K_nm; the reverse pass needs only Aw.  Each of these kernels
+    // leaves CUs idle (a few hundred tiles, one wave per SIMD), so the covloss GEMM is forked onto a
+    // side stream and runs beside W -> dE/dc -> pair forces (a parallel branch of the captured
+    // graph); finalize joins both.  Profiling mode keeps everything on one stream (stage times).
+    const bool fork = beta && predict && !h->profile && h->side != nullptr && h->use_fork;
+    auto covloss = [&](hipStream_t s2) {
+        GemmParams g = {};
+        g.M = cnt; g.N = h->m; g.K = h->m_pad;
+        g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = 0;
+        g.A = h->d_K.p; g.B = h->d_choli.p; g.C = nullptr;
+        g.tiles = h->t_cov.p; g.ntiles = (int)h->t_cov.n;
+        g.rowsq = h->d_csq.p;
+        launch_gemm_nt(g, EPI_ROWSQ, s2);
+    };
+    if (fork) {
+        (void)hipEventRecord(h->ev_fork, st);
+        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        covloss(h->side);
+        (void)hipEventRecord(h->ev_join, h->side);
     }
     if (predict) {
         GemmParams g = {};
@@ -760,15 +790,10 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
         stamp(h, "descriptor_bwd", st);
     }
-    const bool beta = h->m > 0 && h->has_choli && cnt > 0;
-    if (beta) {
-        GemmParams g = {};
-        g.M = cnt; g.N = h->m; g.K = h->m_pad;
-        g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = 0;
-        g.A = h->d_K.p; g.B = h->d_choli.p; g.C = nullptr;
-        g.tiles = h->t_cov.p; g.ntiles = (int)h->t_cov.n;
-        g.rowsq = h->d_csq.p;
-        launch_gemm_nt(g, EPI_ROWSQ, st);
+    if (fork)
+        (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    else if (beta) {
+        covloss(st);
         stamp(h, "gemm_covloss", st);
     }
     hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256), dim3(256), 0, st, N, cnt, h->rank,
@@ -916,6 +941,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
 {
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
+    if (!strcmp(name, "fork")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     return fail(SGPR_E_INVALID, "sgpr_set_option: unknown option %s", name);
 }
 

@@ -91,7 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--atoms-side", type=int, default=16, help="simple-cubic sites per edge (16 -> 4096 atoms)")
     ap.add_argument("--inducing", type=int, default=512)
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--no-fork", action="store_true", help="keep the covloss GEMM on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -119,8 +120,9 @@ def main():
     mdl = build_model(local_rank, numbers, pos, cell, pbc, m)
     lib = _lib.load()
     h = mdl.handle
-    if args.no_graph:
-        _lib.check(lib.sgpr_set_option(h, b"graph", 0))
+    _lib.check(lib.sgpr_set_option(h, b"graph", 1 if args.graph else 0))
+    if args.no_fork:
+        _lib.check(lib.sgpr_set_option(h, b"fork", 0))
 
     dev = torch.device("cuda", local_rank)
     pos_d = torch.from_numpy(pos).to(dev)
@@ -227,7 +229,7 @@ def main():
             "config": {
                 "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
-                "packed_row": Dc, "graph": not args.no_graph,
+                "packed_row": Dc, "graph": bool(args.graph),
                 "host_array_path_atom_steps_per_s": host_rate,
                 "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step",
             },

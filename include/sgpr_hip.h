@@ -138,7 +138,7 @@ int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *pos
  *   packed[4N+1..+9)   virial sum_pairs r (x) dE/dr (partial), row-major 3x3
  * i.e. exactly what one all-reduce(SUM) over ranks must combine (the reference's four
  * collectives calculator/active.py:562,601,602,777 fused into one buffer).
- * `stream` is a hipStream_t passed as void*.  The step is captured into a HIP graph on first
+ * `stream` is a hipStream_t passed as void*.  With option "graph" the step is captured into a HIP graph on first
  * use and replayed afterwards.
  */
 int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, const int32_t *pbc, int rank,
@@ -150,7 +150,9 @@ int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell
  * check overflowed the neighbour-list capacity.  Returns SGPR_E_OVERFLOW if one did (those
  * steps' results are invalid; capacity has been grown, the next step re-sizes eagerly). */
 int sgpr_sync_check(sgpr_model *h, void *stream);
-/* Options: "graph" = 0/1 (replay sgpr_step_dev from a captured HIP graph; default 1). */
+/* Options: "graph" = 0/1 (replay sgpr_step_dev from a captured HIP graph; default 0: eager launches
+ * pipeline well while a step is >100 us of kernels and measured faster than replay);
+ * "fork" = 0/1 (covloss GEMM on a side stream beside the reverse pass; default 0). */
 int sgpr_set_option(sgpr_model *h, const char *name, int value);
 /* stress[6] (Voigt, eV/A^3) from a (summed) packed buffer on the host:
  * calculator/active.py:604-610, volume = |det cell| or -2 for a rank-deficient cell. */
