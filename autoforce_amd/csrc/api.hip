@@ -92,7 +92,7 @@ struct sgpr_model {
     DevBuf<char> d_grid;
     DevBuf<int> d_bin_of, d_bin_start, d_b_idx, d_b_wrap, d_rank_of, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
     DevBuf<double> d_b_pos;
-    DevBuf<int> d_nn_raw, d_hist, d_offs;
+    DevBuf<int> d_nn_raw, d_hist, d_offs, d_b_slot;
     DevBuf<double> d_gpart;
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_dC, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
@@ -344,7 +344,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     drop_graph(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
-                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_b_idx, &h->d_b_wrap, &h->d_rank_of, &h->d_nn_raw, &h->d_hist, &h->d_offs, &h->d_wrap, &h->d_nn,
+                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_b_idx, &h->d_b_wrap, &h->d_rank_of, &h->d_b_slot, &h->d_nn_raw, &h->d_hist, &h->d_offs, &h->d_wrap, &h->d_nn,
                          &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
@@ -492,6 +492,7 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = m; dp.Nall = m; dp.first = 0; dp.stride = 1;
     dp.maxnn = 0; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
+    for (int k = 0; k < SGPR_MAX_S; k++) dp.radii_v[k] = k < h->S ? h->radii[k] : 1.0;
     const int rcd = launch_descriptor_forward_env(dp, d_ptr.p, d_eslot.p, d_er.p, h->d_radii.p, h->d_pack.p,
                                                   h->d_Pm.p, h->d_pm_norm.p, h->stream);
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel for (lmax,nmax,S)=(%d,%d,%d) not compiled in", h->lmax, h->nmax, h->S);
@@ -612,7 +613,7 @@ static int alloc_work(sgpr_model *h)
         bad |= h->d_K.alloc((size_t)cr * h->m_pad);   // zero-filled: off-species entries are never written
         bad |= h->d_Aw.alloc((size_t)cr * h->m_pad);
         if (build_tiles(h, 0) || build_tiles(h, 1) || build_tiles(h, 2)) bad = 1;
-        h->epart_len = (int)h->t_knm.n;
+        h->epart_len = 4 * (int)h->t_knm.n;  // one partial per wave of every K_nm tile
         bad |= h->d_Epart.alloc(std::max(h->epart_len, 1));
     } else
         h->epart_len = 0;
@@ -679,6 +680,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_b_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_b_pos.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_rank_of.alloc(std::max(N, 1));
+    bad |= h->d_b_slot.alloc(std::max(N, 1));
     bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
     bad |= h->d_hist.alloc((size_t)4096 * ((std::max(N, 1) + 255) / 256));
     bad |= h->d_offs.alloc((size_t)4096 * ((std::max(N, 1) + 255) / 256));
@@ -737,13 +739,14 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
     NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_start.p, h->d_b_idx.p, h->d_b_pos.p, h->d_b_wrap.p,
-                    h->d_wrap.p, h->d_stat.p, h->d_rank_of.p, h->d_hist.p, h->d_offs.p, h->d_nn_raw.p};
+                    h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_rank_of.p, h->d_hist.p, h->d_offs.p, h->d_nn_raw.p};
     launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
                          h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, st);
     stamp(h, "neighbor_list", st);
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
     dp.stride = h->world; dp.maxnn = h->maxnn; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
+    for (int k = 0; k < SGPR_MAX_S; k++) dp.radii_v[k] = k < h->S ? h->radii[k] : 1.0;
     int rcd = launch_descriptor_forward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
                                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
                                         h->d_C.p, h->d_shear.p, st);

@@ -135,7 +135,8 @@ struct DescArgs {
     const double *pos;      // [Nall][3] (sorted order)
     const double *cell;     // [9]
     const int *slot;        // [Nall]
-    const double *radii;    // [S]
+    const double *radii;    // [S] (device; ENV path)
+    double radii_v[SGPR_MAX_S];  // the same by value: unit lookup is a select chain, no load
     const int *nn;          // [Nall]
     const int *nbr_j;       // [Nall][maxnn]
     const int *nbr_shift;   // [Nall][maxnn]
@@ -153,6 +154,16 @@ struct DescArgs {
     double *Fself;          // backward: [Nall][3] (plain store, one writer)
     double *vir_part;       // backward: [gridDim][4 waves][9]
 };
+
+// length unit of species slot s (wave-divergent s): select chain over the by-value table
+template <int ST>
+__device__ __forceinline__ double unit_of(const DescArgs &a, int s)
+{
+    double u = a.radii_v[0];
+#pragma unroll
+    for (int q = 1; q < ST; q++) u = (s == q) ? a.radii_v[q] : u;
+    return u;
+}
 
 // neighbour t of atom (global sorted index gi / local index ia): displacement, species slot
 template <bool ENV>
@@ -174,7 +185,7 @@ __device__ __forceinline__ void load_neighbor(const DescArgs &a, int gi, int ia,
 #pragma unroll
         for (int k = 0; k < 3; k++)
             r[k] = a.pos[3 * (size_t)j + k] - pi[k] + (s0 * cell[k] + s1 * cell[3 + k] + s2 * cell[6 + k]);
-        s = a.slot[j];
+        s = (code >> 24) & 0xff;  // species slot of the neighbour (packed by nl_build)
     }
 }
 
@@ -233,20 +244,24 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         for (int k = 0; k < 9; k++) cell[k] = a.cell[k];
     }
 
-    // pass 0: does any neighbour sit inside the z cone? (ylm.py:10-23; whole environment shears)
-    bool near = false;
-    for (int t0 = 0; t0 < nn; t0 += 64) {
-        const int t = t0 + lane;
-        if (t < nn) {
-            double r[3]; int s, j;
-            load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
-            const double u = a.radii[s];
-            const double tol = SGPR_TINY_ANGLE * fabs(r[2] / u);
-            near |= (fabs(r[0] / u) < tol) && (fabs(r[1] / u) < tol);
+    // Does any neighbour sit inside the z cone? (ylm.py:10-23: then the whole environment shears.)
+    // Environments that fit one 64-neighbour tile decide it inside the main pass; larger ones
+    // need a pass of their own first.
+    bool shear = false;
+    if (nn > 64) {
+        bool near = false;
+        for (int t0 = 0; t0 < nn; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < nn) {
+                double r[3]; int s, j;
+                load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
+                const double u = unit_of<ST>(a, s);
+                const double tol = SGPR_TINY_ANGLE * fabs(r[2] / u);
+                near |= (fabs(r[0] / u) < tol) && (fabs(r[1] / u) < tol);
+            }
         }
+        shear = __any(near);
     }
-    const bool shear = __any(near);
-    const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
 
     double acc[ST][SPL];
 #pragma unroll
@@ -258,11 +273,17 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         const int t = t0 + lane;
         const int cnt = min(64, nn - t0);
         wave_sync();
+        double r[3] = {1.0, 0.0, 0.0};
+        int s = 0, j = 0;
+        if (t < nn) load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
+        const double u = unit_of<ST>(a, s);
+        const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
+        if (nn <= 64) {
+            const double tol = SGPR_TINY_ANGLE * fabs(z);
+            shear = __any(t < nn && fabs(x) < tol && fabs(y) < tol);
+        }
+        const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
         if (t < nn) {
-            double r[3]; int s, j;
-            load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
-            const double u = a.radii[s];
-            const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
             const double d = sqrt(x * x + y * y + z * z);
             double f[N1], g, dg;
             radial<NMAX>(d, u, a.rc, f, g, dg);
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
         wave_sync();
         const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
         const int sc = a.slot[gi];
-        const double uc = a.radii[sc];
+        const double uc = unit_of<ST>(a, sc);
         double pi[3], cell[9];
 #pragma unroll
         for (int k = 0; k < 3; k++) pi[k] = uniform(a.pos[3 * (size_t)gi + k]);
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
                 double r[3], gr[3];
                 int s, j;
                 load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
-                pair_grad<LMAX, NMAX>(r, a.radii[s], a.rc, ang,
+                pair_grad<LMAX, NMAX>(r, unit_of<ST>(a, s), a.rc, ang,
                                       [&](int n) { return (const double *)(dcl + s * NSLOT + n * LL); }, gr);
 #pragma unroll
                 for (int p = 0; p < 3; p++)
@@ -667,6 +688,7 @@ static DescArgs make_args(const DescParams &p)
     DescArgs a = {};
     a.N = p.N; a.Nall = p.Nall; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
     a.rc = p.rc;
+    for (int k = 0; k < SGPR_MAX_S; k++) a.radii_v[k] = p.radii_v[k];
     return a;
 }
 

@@ -49,7 +49,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     const GemmParams &p = g.p;
     __shared__ double As[2][BM * 34];
     __shared__ double Bs[2][BN * 34];
-    __shared__ double red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
     // Tile selection.  With a host-built tile table (species-sorted operands: K_nm, K_mm, choli are
@@ -229,11 +228,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         }
     }
     if (EPI == EPI_KERNEL && g.Epart) {
+        // one energy partial per WAVE (no workgroup barrier: the waves retire independently)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-        if (lane == 0) red[wave] = esum;
-        __syncthreads();
-        if (tid == 0) g.Epart[p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct] = red[0] + red[1] + red[2] + red[3];
+        if (lane == 0) g.Epart[(size_t)(p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct) * 4 + wave] = esum;
     }
     if (g.stamps && threadIdx.x == 0) {
         long long *o = g.stamps + (size_t)blockIdx.x * 4;

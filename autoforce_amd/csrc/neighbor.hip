@@ -48,6 +48,8 @@ struct BinArgs {
     int *b_idx;             // [N] atom (sorted index) at binned slot k
     double *b_pos;          // [N][3] its position
     int *b_wrap;            // [N][3] its wrap (floor of the fractional coordinate)
+    int *b_slot;            // [N] its species slot
+    const int *slot;        // [N] species slot by sorted index
     int *bin_of;            // [N]
     int *rank_of;           // [N] rank of the atom among the same-bin atoms of its workgroup
     int *wrap;              // [N][3]
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void nl_scatter_kernel(BinArgs a)
     if (i >= a.N) return;
     const int k = a.offs[a.bin_of[i] * a.nwg + blockIdx.x] + a.rank_of[i];
     a.b_idx[k] = i;
+    a.b_slot[k] = a.slot[i];
 #pragma unroll
     for (int q = 0; q < 3; q++) {
         a.b_pos[3 * k + q] = a.pos[3 * i + q];
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(256) void nl_scatter_kernel(BinArgs a)
 __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int stride, int count, const double *pos,
                                                        const double *cell, double rc, const NlGrid *grid,
                                                        const int *bin_of, const int *bin_start, const int *b_idx,
-                                                       const double *b_pos, const int *b_wrap, const int *wrap,
+                                                       const double *b_pos, const int *b_wrap, const int *b_slot,
+                                                       const int *wrap,
                                                        int maxnn, int *nn, int *nn_local, int *nbr_j,
                                                        int *nbr_shift, int *nn_raw)
 {
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
         for (int c0 = 0; c0 < total; c0 += 64) {
             const int c = c0 + lane;
             bool hit = false;
-            int j = 0, f0 = 0, f1 = 0, f2 = 0;
+            int j = 0, f0 = 0, f1 = 0, f2 = 0, sj = 0;
             if (c < total) {
                 // largest b with pref[b] <= c  (empty bins share a prefix value: take the last)
                 int lo = 0, hi = 63;
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
                 const int k = s_start[wave][lo] + (c - s_pref[wave][lo]);
                 const int cd = s_code[wave][lo];
                 j = b_idx[k];
+                sj = b_slot[k];
                 f0 = (int)(int8_t)(cd & 0xff) - b_wrap[3 * k] + wi0;
                 f1 = (int)(int8_t)((cd >> 8) & 0xff) - b_wrap[3 * k + 1] + wi1;
                 f2 = (int)(int8_t)((cd >> 16) & 0xff) - b_wrap[3 * k + 2] + wi2;
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
                 const int slot = base + __popcll(m & lt);
                 if (slot < maxnn) {
                     nbr_j[(size_t)i * maxnn + slot] = j;
-                    nbr_shift[(size_t)i * maxnn + slot] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16);
+                    nbr_shift[(size_t)i * maxnn + slot] =
+                        (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);  // + species slot
                 }
             }
             base += __popcll(m);
@@ -312,7 +318,7 @@ void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_
     a.N = p.N; a.nwg = (p.N + 255) / 256; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
     for (int k = 0; k < 3; k++) a.pbc[k] = p.pbc[k];
     a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_start = s.bin_start; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
-    a.b_wrap = s.b_wrap; a.bin_of = s.bin_of; a.rank_of = s.rank_of; a.wrap = s.wrap; a.hist = s.hist; a.offs = s.offs;
+    a.b_wrap = s.b_wrap; a.b_slot = s.b_slot; a.slot = s.slot; a.bin_of = s.bin_of; a.rank_of = s.rank_of; a.wrap = s.wrap; a.hist = s.hist; a.offs = s.offs;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
     hipLaunchKernelGGL(nl_bin1_kernel, dim3(a.nwg), dim3(256), 0, st, a);
     hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, st, a);
@@ -320,6 +326,6 @@ void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_
     if (p.count > 0)
         hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first,
                            p.stride > 0 ? p.stride : 1, p.count, pos, cell, rc, (const NlGrid *)s.grid, s.bin_of,
-                           s.bin_start, s.b_idx, s.b_pos, s.b_wrap, s.wrap, p.maxnn, nn, nn_local, nbr_j, nbr_shift,
+                           s.bin_start, s.b_idx, s.b_pos, s.b_wrap, s.b_slot, s.wrap, p.maxnn, nn, nn_local, nbr_j, nbr_shift,
                            s.nn_raw);
 }

@@ -50,6 +50,8 @@ struct NlScratch {
     int *b_idx;        // [N]    binned copies (slot k of the bin-sorted order)
     double *b_pos;     // [N][3]
     int *b_wrap;       // [N][3]
+    int *b_slot;       // [N]
+    const int *slot;   // [N] species slot by sorted index (input)
     int *wrap;         // [N][3]
     int *stat;         // [4]
     int *rank_of;      // [N]
@@ -72,6 +74,7 @@ struct DescParams {
     int maxnn;
     int Dc, Dpad;     // packed row length and padded stride
     int CS;           // c stride per atom = S*(nmax+1)*(lmax+1)^2
+    double radii_v[SGPR_MAX_S];  // length unit per species slot
     double rc;
 };
 

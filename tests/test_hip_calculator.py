@@ -153,3 +153,62 @@ def test_full_size_properties():
     want = vir.flat[[0, 4, 8, 5, 2, 1]] / abs(np.linalg.det(cell))
     assert np.abs(d["stress"] - want).max() <= 1e-8 * np.abs(want).max()
     mdl.close()
+
+
+def _workload_model(kind, m, seed=1):
+    from autoforce_amd import SGPRModel
+    from autoforce_amd import workloads as wl
+    make = {"li": wl.li_bcc, "oxide": wl.oxide}[kind]
+    numbers, pos, cell, pbc = make(seed=0)
+    mdl = SGPRModel(3, 3, 4, 6.0, species=sorted(set(numbers.tolist())))
+    n2, p2, c2, b2 = make(seed=seed)
+    mdl.set_inducing(wl.inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=seed))
+    rng = np.random.default_rng(2)
+    mdl.solve(rng.normal(size=(64, m)), rng.normal(size=64))
+    mdl.set_weights(rng.normal(size=m), choli=mdl.choli, vscale=mdl.make_vscale())
+    return mdl, numbers, pos, cell, pbc
+
+
+def _oracle_frame(mdl, numbers, pos, cell, nl):
+    from oracle import oracle as orc
+    X = mdl.X
+    species = np.array(mdl.species, np.int32)
+    ind_z = np.array([x.number for x in X], np.int32)
+    ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
+    Pm, nnm = orc.inducing_descriptors(3, 3, 6.0, species, ind_z, ind_ptr, np.concatenate([x._b for x in X]),
+                                       np.concatenate([x._r for x in X]))
+    return orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mdl.mu, choli=mdl.choli)
+
+
+def test_baseline_config2_li256_m128():
+    """BASELINE configs[1]: 256-atom bcc Li, 128 inducing points: forces within 1e-6 eV/A (relative) of
+    the CPU path; held to 1e-8.  One species: packed row 40 of 64."""
+    from oracle import oracle as orc
+    mdl, numbers, pos, cell, pbc = _workload_model("li", 128)
+    out = mdl.predict(numbers, pos, cell, pbc, cov=True)
+    nl = orc.neighbors(pos, cell, pbc, 6.0)
+    p, j, off = mdl.neighbors(len(numbers))
+    assert p[-1] == nl[0][-1]
+    ref = _oracle_frame(mdl, numbers, pos, cell, nl)
+    np.testing.assert_allclose(out["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
+    assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
+    assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
+    assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
+    mdl.close()
+
+
+def test_baseline_config5_oxide16384_m1024():
+    """BASELINE configs[4] sizes: 16384 atoms, 4 species, 1024 inducing points (single GPU, one
+    frame): against the oracle (device neighbour list) and Newton's third law."""
+    mdl, numbers, pos, cell, pbc = _workload_model("oxide", 1024)
+    N = len(numbers)
+    out = mdl.predict(numbers, pos, cell, pbc, cov=False)
+    fmax = np.abs(out["forces"]).max()
+    assert np.abs(out["forces"].sum(0)).max() <= 1e-8 * fmax
+    ref = _oracle_frame(mdl, numbers, pos, cell, mdl.neighbors(N))
+    assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
+    assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
+    assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
+    vs = np.sqrt([mdl._vscale[int(z)] for z in numbers])
+    np.testing.assert_allclose(out["beta"], ref["beta"] * vs, rtol=0, atol=5e-6 * vs.max())
+    mdl.close()
