@@ -90,9 +90,10 @@ struct sgpr_model {
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
     DevBuf<char> d_grid;
-    DevBuf<int> d_bin_of, d_bin_start, d_b_idx, d_b_wrap, d_rank_of, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    DevBuf<int> d_bin_of, d_bin_count, d_b_idx, d_b_wrap, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    int bin_cap = 0;  // slots per bin of the binned copies
     DevBuf<double> d_b_pos;
-    DevBuf<int> d_nn_raw, d_hist, d_offs, d_b_slot;
+    DevBuf<int> d_nn_raw, d_b_slot;
     DevBuf<double> d_gpart;
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_dC, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
@@ -140,11 +141,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(int N, int cnt, int first
                                                        const double *csq, int has_beta, const double *vs_sqrt,
                                                        const double *Epart, int nE, const double *virpart, int nV,
                                                        double mean_energy, double *packed, const int *nn_raw,
-                                                       int *stat, double *gpart /*[grid][12]*/, unsigned *ticket)
+                                                       int *stat, double *gpart /*[grid][12]*/, unsigned *ticket,
+                                                       int *bin_count /*[4096]: cleared for the next step*/)
 {
     __shared__ int is_last;
     const int tid = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
     const int i = b * blockDim.x + tid;
+    for (int k = i; k < 4096; k += nb * blockDim.x) bin_count[k] = 0;
     if (i < N) {
         const int c = perm[i];
 #pragma unroll
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(int N, int cnt, int first
             mx = fmax(mx, __shfl_xor(mx, o, 64));
         }
         if (lane == 0) {
-            if (q == 10) stat[0] = (int)mx;
+            if (q == 10) stat[0] = max(stat[0], (int)mx);  // sticky until the host reads and clears it
             else packed[4 * (size_t)N + q] = s + (q == 0 ? mean_energy : 0.0);
         }
     }
@@ -310,7 +313,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     upload_harm_coef(hc);
     h->d_grid.alloc(256);
     h->d_stat.alloc(4);
-    h->d_bin_start.alloc(8200);
+    h->d_bin_count.alloc(4096);
     h->d_cell_in.alloc(9);
     if (getenv("SGPR_STAMPS")) h->d_stamps.alloc(4 * 4096);
     *out = h;
@@ -344,7 +347,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     drop_graph(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
-                         &h->d_lnn, &h->d_bin_of, &h->d_bin_start, &h->d_b_idx, &h->d_b_wrap, &h->d_rank_of, &h->d_b_slot, &h->d_nn_raw, &h->d_hist, &h->d_offs, &h->d_wrap, &h->d_nn,
+                         &h->d_lnn, &h->d_bin_of, &h->d_bin_count, &h->d_b_idx, &h->d_b_wrap, &h->d_b_slot, &h->d_nn_raw, &h->d_wrap, &h->d_nn,
                          &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
@@ -631,6 +634,20 @@ static int ensure_nl(sgpr_model *h, int maxnn)
     return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (neighbour list, maxnn=%d)", maxnn) : 0;
 }
 
+static int ensure_bins(sgpr_model *h, int cap)
+{
+    if (cap <= h->bin_cap && h->d_b_idx.p) return 0;
+    h->bin_cap = cap;
+    drop_graph(h);
+    const size_t slots = (size_t)4096 * cap;
+    int bad = 0;
+    bad |= h->d_b_idx.alloc(slots, false);
+    bad |= h->d_b_slot.alloc(slots, false);
+    bad |= h->d_b_wrap.alloc(3 * slots, false);
+    bad |= h->d_b_pos.alloc(3 * slots, false);
+    return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (bins, cap=%d)", cap) : 0;
+}
+
 extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, const int32_t *pbc, int rank, int world)
 {
     if (!h || N < 0 || (N > 0 && !numbers) || world < 1 || rank < 0 || rank >= world)
@@ -676,17 +693,10 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_pos_in.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_pos.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_bin_of.alloc(std::max(N, 1));
-    bad |= h->d_b_idx.alloc(std::max(N, 1));
-    bad |= h->d_b_wrap.alloc((size_t)3 * std::max(N, 1));
-    bad |= h->d_b_pos.alloc((size_t)3 * std::max(N, 1));
-    bad |= h->d_rank_of.alloc(std::max(N, 1));
-    bad |= h->d_b_slot.alloc(std::max(N, 1));
-    bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
-    bad |= h->d_hist.alloc((size_t)4096 * ((std::max(N, 1) + 255) / 256));
-    bad |= h->d_offs.alloc((size_t)4096 * ((std::max(N, 1) + 255) / 256));
     bad |= h->d_nn_raw.alloc(h->cnt_rows);
     bad |= h->d_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_nn.alloc(std::max(N, 1));
+    bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
     if (bad) return fail(SGPR_E_NODEVICE, "hipMalloc failed (system arrays)");
     if (N > 0) {
         HIPCHK(hipMemcpy(h->d_perm.p, h->perm.data(), sizeof(int) * N, hipMemcpyHostToDevice));
@@ -738,8 +748,8 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     NlParams np = {};
     np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
-    NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_start.p, h->d_b_idx.p, h->d_b_pos.p, h->d_b_wrap.p,
-                    h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_rank_of.p, h->d_hist.p, h->d_offs.p, h->d_nn_raw.p};
+    NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_count.p, h->bin_cap, h->d_b_idx.p, h->d_b_pos.p,
+                    h->d_b_wrap.p, h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_nn_raw.p};
     launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
                          h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, st);
     stamp(h, "neighbor_list", st);
@@ -803,7 +813,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
                        h->world, h->d_perm.p, h->d_slot.p, h->d_F.p, h->d_F.p + 3 * (size_t)N, h->d_csq.p,
                        beta ? 1 : 0, h->d_vs_sqrt.p, h->d_Epart.p, predict ? h->epart_len : 0, h->d_virpart.p,
                        predict ? h->virpart_len : 0, h->mean_energy, packed_dev, h->d_nn_raw.p, h->d_stat.p,
-                       h->d_gpart.p, (unsigned *)(h->d_stat.p + 2));
+                       h->d_gpart.p, (unsigned *)(h->d_stat.p + 2), h->d_bin_count.p);
     stamp(h, "finalize", st);
     return SGPR_OK;
 }
@@ -816,15 +826,29 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         const int rc_ = ensure_nl(h, 64);
         if (rc_) return rc_;
     }
-    for (int attempt = 0; attempt < 6; attempt++) {
+    if (h->bin_cap == 0) {
+        const int rc_ = ensure_bins(h, 64);
+        if (rc_) return rc_;
+    }
+    for (int attempt = 0; attempt < 12; attempt++) {
+        HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 2 * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 4096 * sizeof(int), st));
         const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st);
         if (rc_) return rc_;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         int stat[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpy(stat, h->d_stat.p, sizeof(stat), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(stat, h->d_stat.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        if (stat[1] > h->bin_cap) {  // a bin overflowed: grow the bins, the lists of this attempt are incomplete
+            int cap = h->bin_cap;
+            while (cap < stat[1] + stat[1] / 4) cap *= 2;
+            const int rc2 = ensure_bins(h, cap);
+            if (rc2) return rc2;
+            continue;
+        }
         if (stat[0] <= h->maxnn) {
             h->nn_max_seen = stat[0];
+            HIPCHK(hipMemset(h->d_stat.p, 0, 2 * sizeof(int)));
             return SGPR_OK;
         }
         if (stat[0] > 100000) return fail(SGPR_E_OVERFLOW, "neighbour count %d is unreasonable", stat[0]);
@@ -929,12 +953,12 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     int stat[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(stat, h->d_stat.p, sizeof(stat), hipMemcpyDeviceToHost));
-    if (stat[0] > h->maxnn) {
-        const int need = stat[0];
+    HIPCHK(hipMemcpy(stat, h->d_stat.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stat.p, 0, 2 * sizeof(int)));
+    if (stat[0] > h->maxnn || stat[1] > h->bin_cap) {
         h->warm = false;  // next step re-sizes eagerly
-        (void)ensure_nl(h, rup(need + need / 8 + 4, 8));
-        return fail(SGPR_E_OVERFLOW, "neighbour capacity exceeded (%d); results of the last steps are invalid", need);
+        return fail(SGPR_E_OVERFLOW, "neighbour-list capacity exceeded (neighbours %d/%d, bin %d/%d); results of "
+                    "the steps since the last check are invalid", stat[0], h->maxnn, stat[1], h->bin_cap);
     }
     h->nn_max_seen = stat[0];
     return SGPR_OK;

@@ -5,22 +5,22 @@
 // |x_j - x_i + off.cell| < rc and (j,off) != (i,0); periodic self-images are kept.
 // General triclinic cells, any pbc combination, atoms may sit outside the cell.
 //
-// Four launches (a one-workgroup version of the binning measured 37 us at 4096 atoms: a single
-// CU moves ~10 B/clk, so the binning is spread over N/256 workgroups instead):
-//   nl_bin1_kernel    species-sort gather of the caller's positions, bin grid from the
-//                     (device-resident) cell, bin/wrap per atom, deterministic in-workgroup rank
-//                     of each atom among its bin-mates, per-(bin, workgroup) counts; also clears
-//                     the step's accumulators.
-//   nl_scan_kernel    one workgroup: exclusive scan of the counts in (bin, workgroup) order.
-//   nl_scatter_kernel binned copies (index, position, wrap): index-sorted inside every bin, no
-//                     sort pass, no atomics -> neighbour order is reproducible run to run.
+// Two launches (every kernel boundary costs ~3-5 us here: dispatch + write-back of what the
+// kernel dirtied; an earlier count -> scan -> scatter binning was three launches, 21 us):
+//   nl_bin_kernel   256 atoms per workgroup: species-sort gather of the caller's positions, bin
+//                   grid from the (device-resident) cell, and direct placement into fixed-capacity
+//                   bins through one returning atomic per atom (binned copies: index, position,
+//                   wrap, species slot).  Also clears the step's accumulators.
 //   nl_build_kernel one wave64 per atom: the (2R+1)^3 neighbouring bins are flattened into one
-//                   candidate range (lane-parallel prefix over bins), swept 64 candidates at a
-//                   time from the binned copies (one coalesced load level), and the hits are
-//                   ballot/popcount-compacted into nbr_j/nbr_shift[i][:].
+//                   candidate range (lane-parallel prefix over bins) and swept 64 candidates at a
+//                   time from the binned copies; hits are ballot/popcount-compacted into LDS,
+//                   SORTED by (j, image) with an in-wave bitonic network — the atomic placement
+//                   order inside a bin is not reproducible, the sorted list is — and written out.
+// The bin counters are re-zeroed by the step's last kernel (finalize).
 #include "sgpr_internal.h"
 
 #define NL_MAX_BINS 4096
+#define NL_SORT_MAX 256  // lists up to this length are sorted in LDS (longer ones keep sweep order)
 
 struct NlGrid {
     double inv[9];   // inverse cell (columns = reciprocal vectors): frac = pos . inv
@@ -36,7 +36,7 @@ __device__ __forceinline__ double det3d(const double *h)
 }
 
 struct BinArgs {
-    int N, nwg;
+    int N, cap;
     const int *perm;        // sorted -> caller (may be null: identity)
     const double *pos_in;   // caller order
     const double *cell;
@@ -44,17 +44,15 @@ struct BinArgs {
     double rc;
     NlGrid *grid;
     double *pos;            // [N][3] sorted order (out)
-    int *bin_start;         // [NL_MAX_BINS+1]
-    int *b_idx;             // [N] atom (sorted index) at binned slot k
-    double *b_pos;          // [N][3] its position
-    int *b_wrap;            // [N][3] its wrap (floor of the fractional coordinate)
-    int *b_slot;            // [N] its species slot
+    int *bin_count;         // [NL_MAX_BINS] atoms per bin (zero on entry)
+    int *b_idx;             // [nbins][cap] atom (sorted index)
+    double *b_pos;          // [nbins][cap][3] its position
+    int *b_wrap;            // [nbins][cap][3] its wrap (floor of the fractional coordinate)
+    int *b_slot;            // [nbins][cap] its species slot
     const int *slot;        // [N] species slot by sorted index
     int *bin_of;            // [N]
-    int *rank_of;           // [N] rank of the atom among the same-bin atoms of its workgroup
     int *wrap;              // [N][3]
-    int *hist;              // [nbins][nwg] same-bin counts per workgroup (zero between steps)
-    int *offs;              // [nbins][nwg] exclusive prefix of hist in (bin, workgroup) order
+    int *stat;              // [4]: [1] = largest bin population seen beyond cap (overflow)
     double *zero_a; int n_zero_a;   // accumulators to clear for this step
     double *zero_b; int n_zero_b;
 };
@@ -97,13 +95,9 @@ __device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGr
     g.nbins = g.nb[0] * g.nb[1] * g.nb[2];
 }
 
-// K1: 256 atoms per workgroup.  Species-sort gather, bin + wrap, and a DETERMINISTIC rank of every
-// atom among the same-bin atoms of its workgroup (counting lower lanes; index order is kept, so
-// the binned lists come out index-sorted with no sort pass and no atomics).
-__global__ __launch_bounds__(256) void nl_bin1_kernel(BinArgs a)
+__global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
 {
     __shared__ NlGrid g;
-    __shared__ int sbin[256];
     const int tid = threadIdx.x, wg = blockIdx.x;
     if (tid == 0) {
         nl_make_grid(a.cell, a.pbc, a.rc, g);
@@ -114,113 +108,47 @@ __global__ __launch_bounds__(256) void nl_bin1_kernel(BinArgs a)
     for (int k = gid; k < a.n_zero_b; k += gsz) a.zero_b[k] = 0.0;
     __syncthreads();
     const int i = gid;
-    int bin = -1;
-    if (i < a.N) {
-        const int c = a.perm ? a.perm[i] : i;
-        const double x = a.pos_in[3 * c], y = a.pos_in[3 * c + 1], z = a.pos_in[3 * c + 2];
-        a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
-        int bidx[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            double f = x * g.inv[k] + y * g.inv[3 + k] + z * g.inv[6 + k];
-            int w = 0;
-            bidx[k] = 0;
-            if (a.pbc[k] && (g.inv[k] != 0.0 || g.inv[3 + k] != 0.0 || g.inv[6 + k] != 0.0)) {
-                const double fl = floor(f);
-                w = (int)fl;
-                f -= fl;
-                const int b = (int)(f * g.nb[k]);
-                bidx[k] = b >= g.nb[k] ? g.nb[k] - 1 : (b < 0 ? 0 : b);
-            }
-            a.wrap[3 * i + k] = w;
-        }
-        bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
-        a.bin_of[i] = bin;
-    }
-    sbin[tid] = bin;
-    __syncthreads();
-    if (i < a.N) {
-        int below = 0, total = 0;
-        for (int t = 0; t < 256; t++) {
-            const int same = sbin[t] == bin;
-            total += same;
-            below += same & (t < tid);
-        }
-        a.rank_of[i] = below;
-        if (below == 0) a.hist[bin * a.nwg + wg] = total;
-    }
-}
-
-// K2: one workgroup scans hist in (bin, workgroup) order, emits offs and bin_start, and clears
-// hist for the next step.
-__global__ __launch_bounds__(1024) void nl_scan_kernel(BinArgs a)
-{
-    __shared__ int part[16];
-    __shared__ int carry;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const NlGrid g = *a.grid;
-    const int n = g.nbins * a.nwg;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 4096) {
-        int v[4], loc = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = base + tid * 4 + k;
-            v[k] = e < n ? a.hist[e] : 0;
-            loc += v[k];
-        }
-        int incl = loc;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) part[wv] = incl;
-        __syncthreads();
-        int run = carry + incl - loc;
-        for (int w = 0; w < wv; w++) run += part[w];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int e = base + tid * 4 + k;
-            if (e < n) {
-                a.offs[e] = run;
-                a.hist[e] = 0;
-                if (e % a.nwg == 0) a.bin_start[e / a.nwg] = run;
-                run += v[k];
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) carry = run;
-        __syncthreads();
-    }
-    if (tid == 0) a.bin_start[g.nbins] = a.N;
-}
-
-// K3: scatter into the binned copies (index, position, wrap).
-__global__ __launch_bounds__(256) void nl_scatter_kernel(BinArgs a)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.N) return;
-    const int k = a.offs[a.bin_of[i] * a.nwg + blockIdx.x] + a.rank_of[i];
-    a.b_idx[k] = i;
-    a.b_slot[k] = a.slot[i];
+    const int c = a.perm ? a.perm[i] : i;
+    const double x = a.pos_in[3 * c], y = a.pos_in[3 * c + 1], z = a.pos_in[3 * c + 2];
+    a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
+    int bidx[3], w[3];
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        a.b_pos[3 * k + q] = a.pos[3 * i + q];
-        a.b_wrap[3 * k + q] = a.wrap[3 * i + q];
+    for (int k = 0; k < 3; k++) {
+        double f = x * g.inv[k] + y * g.inv[3 + k] + z * g.inv[6 + k];
+        w[k] = 0;
+        bidx[k] = 0;
+        if (a.pbc[k] && (g.inv[k] != 0.0 || g.inv[3 + k] != 0.0 || g.inv[6 + k] != 0.0)) {
+            const double fl = floor(f);
+            w[k] = (int)fl;
+            f -= fl;
+            const int b = (int)(f * g.nb[k]);
+            bidx[k] = b >= g.nb[k] ? g.nb[k] - 1 : (b < 0 ? 0 : b);
+        }
+        a.wrap[3 * i + k] = w[k];
     }
+    const int bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
+    a.bin_of[i] = bin;
+    const int k = atomicAdd(&a.bin_count[bin], 1);
+    if (k < a.cap) {
+        const size_t e = (size_t)bin * a.cap + k;
+        a.b_idx[e] = i;
+        a.b_slot[e] = a.slot[i];
+        a.b_pos[3 * e] = x; a.b_pos[3 * e + 1] = y; a.b_pos[3 * e + 2] = z;
+        a.b_wrap[3 * e] = w[0]; a.b_wrap[3 * e + 1] = w[1]; a.b_wrap[3 * e + 2] = w[2];
+    } else
+        atomicMax(&a.stat[1], k + 1);  // rare: capacity exceeded, the host grows it and reruns
 }
 
 __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int stride, int count, const double *pos,
                                                        const double *cell, double rc, const NlGrid *grid,
-                                                       const int *bin_of, const int *bin_start, const int *b_idx,
-                                                       const double *b_pos, const int *b_wrap, const int *b_slot,
-                                                       const int *wrap,
-                                                       int maxnn, int *nn, int *nn_local, int *nbr_j,
-                                                       int *nbr_shift, int *nn_raw)
+                                                       const int *bin_of, const int *bin_count, int cap,
+                                                       const int *b_idx, const double *b_pos, const int *b_wrap,
+                                                       const int *b_slot, const int *wrap, int maxnn, int *nn,
+                                                       int *nn_local, int *nbr_j, int *nbr_shift, int *nn_raw)
 {
     __shared__ int s_start[4][64], s_pref[4][65], s_code[4][64];
+    __shared__ unsigned long long s_key[4][NL_SORT_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int il = blockIdx.x * 4 + wave;
     if (il >= count) return;
@@ -237,6 +165,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     const int nbox = w0 * w1 * w2;
     int base = 0;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long *keys = s_key[wave];
     for (int q0 = 0; q0 < nbox; q0 += 64) {
         // lane -> one neighbouring bin (image-aware)
         const int q = q0 + lane;
@@ -247,8 +176,8 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
             const int c0 = (int)floor((double)t0 / g.nb[0]), c1 = (int)floor((double)t1 / g.nb[1]),
                       c2 = (int)floor((double)t2 / g.nb[2]);
             const int nbin = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
-            sb = bin_start[nbin];
-            cntb = bin_start[nbin + 1] - sb;
+            sb = nbin * cap;
+            cntb = min(bin_count[nbin], cap);
             code = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16);
         }
         int incl = cntb;
@@ -292,15 +221,49 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int slot = base + __popcll(m & lt);
-                if (slot < maxnn) {
+                // key: neighbour index, then the image triple (biased to sort as unsigned), then slot
+                const unsigned code = (unsigned)((f0 + 128) & 0xff) << 16 | (unsigned)((f1 + 128) & 0xff) << 8 |
+                                      (unsigned)((f2 + 128) & 0xff) | (unsigned)sj << 24;
+                const unsigned long long key = ((unsigned long long)(unsigned)j << 32) | code;
+                if (slot < NL_SORT_MAX) keys[slot] = key;
+                else if (slot < maxnn) {  // very long lists: keep sweep order beyond the sortable part
                     nbr_j[(size_t)i * maxnn + slot] = j;
-                    nbr_shift[(size_t)i * maxnn + slot] =
-                        (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);  // + species slot
+                    nbr_shift[(size_t)i * maxnn + slot] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
                 }
             }
             base += __popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    // bitonic sort of the first min(base, NL_SORT_MAX) keys in LDS, then coalesced write-out
+    const int ns = min(base, NL_SORT_MAX);
+    int np2 = 1;
+    while (np2 < ns) np2 <<= 1;
+    for (int t = ns + lane; t < np2; t += 64) keys[t] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int k2 = 2; k2 <= np2; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = lane; t < np2; t += 64) {
+                const int p = t ^ j2;
+                if (p > t) {
+                    const unsigned long long a0 = keys[t], a1 = keys[p];
+                    const bool up = (t & k2) == 0;
+                    if ((a0 > a1) == up) { keys[t] = a1; keys[p] = a0; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    for (int t = lane; t < ns && t < maxnn; t += 64) {
+        const unsigned long long key = keys[t];
+        const unsigned code = (unsigned)key;
+        const int f0 = (int)((code >> 16) & 0xff) - 128, f1 = (int)((code >> 8) & 0xff) - 128,
+                  f2 = (int)(code & 0xff) - 128, sj = (int)(code >> 24);
+        nbr_j[(size_t)i * maxnn + t] = (int)(key >> 32);
+        nbr_shift[(size_t)i * maxnn + t] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
     }
     if (lane == 0) {
         nn[i] = base < maxnn ? base : maxnn;
@@ -315,17 +278,15 @@ void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_
 {
     if (p.N <= 0) return;
     BinArgs a = {};
-    a.N = p.N; a.nwg = (p.N + 255) / 256; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
+    a.N = p.N; a.cap = s.cap; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
     for (int k = 0; k < 3; k++) a.pbc[k] = p.pbc[k];
-    a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_start = s.bin_start; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
-    a.b_wrap = s.b_wrap; a.b_slot = s.b_slot; a.slot = s.slot; a.bin_of = s.bin_of; a.rank_of = s.rank_of; a.wrap = s.wrap; a.hist = s.hist; a.offs = s.offs;
+    a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_count = s.bin_count; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
+    a.b_wrap = s.b_wrap; a.b_slot = s.b_slot; a.slot = s.slot; a.bin_of = s.bin_of; a.wrap = s.wrap; a.stat = s.stat;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
-    hipLaunchKernelGGL(nl_bin1_kernel, dim3(a.nwg), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(nl_scan_kernel, dim3(1), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(nl_scatter_kernel, dim3(a.nwg), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
     if (p.count > 0)
         hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first,
                            p.stride > 0 ? p.stride : 1, p.count, pos, cell, rc, (const NlGrid *)s.grid, s.bin_of,
-                           s.bin_start, s.b_idx, s.b_pos, s.b_wrap, s.b_slot, s.wrap, p.maxnn, nn, nn_local, nbr_j, nbr_shift,
-                           s.nn_raw);
+                           s.bin_count, s.cap, s.b_idx, s.b_pos, s.b_wrap, s.b_slot, s.wrap, p.maxnn, nn, nn_local, nbr_j,
+                           nbr_shift, s.nn_raw);
 }

@@ -46,16 +46,15 @@ struct NlParams {
 struct NlScratch {
     void *grid;        // >= 128 B
     int *bin_of;       // [N]
-    int *bin_start;    // [4097]
-    int *b_idx;        // [N]    binned copies (slot k of the bin-sorted order)
-    double *b_pos;     // [N][3]
-    int *b_wrap;       // [N][3]
-    int *b_slot;       // [N]
+    int *bin_count;    // [4096] atoms per bin; zero on entry (finalize re-zeroes it)
+    int cap;           // slots per bin of the binned copies below
+    int *b_idx;        // [4096][cap]    binned copies
+    double *b_pos;     // [4096][cap][3]
+    int *b_wrap;       // [4096][cap][3]
+    int *b_slot;       // [4096][cap]
     const int *slot;   // [N] species slot by sorted index (input)
     int *wrap;         // [N][3]
-    int *stat;         // [4]
-    int *rank_of;      // [N]
-    int *hist, *offs;  // [4096 * ceil(N/256)] each; hist must be zero on entry (the scan re-zeroes it)
+    int *stat;         // [4]: [0] max neighbour count, [1] max bin population beyond cap (both sticky)
     int *nn_raw;       // [count] unclamped neighbour counts (overflow check)
 };
 
