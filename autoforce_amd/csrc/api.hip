@@ -1,9 +1,9 @@
 // api.hip — C ABI (include/sgpr_hip.h) and step orchestration of the gfx950 SGPR evaluator.
 //
 // One handle = one model on one GPU, one HIP stream.  A step is the fixed launch sequence
-//   gather -> nl_bin -> nl_build -> desc_fwd -> gemm<KERNEL> -> gemm<STORE> -> desc_bwd
+//   nl_bin -> nl_build -> desc_fwd -> gemm<KERNEL> -> gemm<STORE> -> desc_dc -> desc_pair
 //          -> gemm<ROWSQ> -> finalize
-// which sgpr_step_dev captures once into a HIP graph and replays.
+// launched eagerly (or, with option "graph", captured once into a HIP graph and replayed).
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -750,9 +750,11 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
     NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_count.p, h->bin_cap, h->d_b_idx.p, h->d_b_pos.p,
                     h->d_b_wrap.p, h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_nn_raw.p};
-    launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
-                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, st);
-    stamp(h, "neighbor_list", st);
+    for (int phase = 1; phase <= 2; phase++) {
+        launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
+                             h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, phase, st);
+        stamp(h, phase == 1 ? "neighbor_bin" : "neighbor_build", st);
+    }
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
     dp.stride = h->world; dp.maxnn = h->maxnn; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
@@ -797,11 +799,14 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         g.tiles = h->t_w.p; g.ntiles = (int)h->t_w.n;
         launch_gemm_nt(g, EPI_STORE, st);
         stamp(h, "gemm_w", st);
-        rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
-                                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
-                                         h->d_C.p, h->d_shear.p, h->d_W.p, h->d_dC.p, h->d_F.p, h->d_virpart.p, st);
-        if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
-        stamp(h, "descriptor_bwd", st);
+        for (int phase = 1; phase <= 2; phase++) {
+            rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
+                                             h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
+                                             h->d_C.p, h->d_shear.p, h->d_W.p, h->d_dC.p, h->d_F.p, h->d_virpart.p,
+                                             phase, st);
+            if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
+            stamp(h, phase == 1 ? "descriptor_dc" : "descriptor_pair", st);
+        }
     }
     if (fork)
         (void)hipStreamWaitEvent(st, h->ev_join, 0);

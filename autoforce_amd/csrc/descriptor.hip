@@ -131,6 +131,7 @@ struct Harm {
 // ---------------------------------------------------------------- kernel arguments
 struct DescArgs {
     int N, Nall, first, stride, maxnn, S, Dc, Dpad, CS;
+    int phase;              // reverse pass: 0 = dE/dc then pair kernel, 1 = dE/dc only, 2 = pair kernel only
     double rc;
     const double *pos;      // [Nall][3] (sorted order)
     const double *cell;     // [9]
@@ -650,7 +651,8 @@ static int run_bwd(const DescArgs &a, hipStream_t st)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         attr_set = lds1;
     }
-    hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
+    if (a.phase != 2) hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
+    if (a.phase == 1) return 0;
     const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + 64 * (WL::LL + 2) + 9 * 64);
     if (a.stride == 1 && a.first == 0 && a.N == a.Nall)
         hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, true>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
@@ -721,12 +723,12 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
                                const int *shear, const double *W, double *dC, double *F, double *virial,
-                               hipStream_t st)
+                               int phase, hipStream_t st)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
     a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = (double *)Pn; a.norm = (double *)norm; a.C = (double *)C;
-    a.shear = (int *)shear; a.W = W; a.dC = dC;
+    a.shear = (int *)shear; a.W = W; a.dC = dC; a.phase = phase;
     // F points at [Fnbr | Fself], virial at the per-wave partial array (see api.hip)
     a.Fnbr = F;
     a.Fself = F + 3 * (size_t)p.Nall;

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
 
 void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_in, double *pos, const double *cell,
                           double rc, NlScratch s, int *nn, int *nn_local, int *nbr_j, int *nbr_shift,
-                          double *zero_a, int n_zero_a, double *zero_b, int n_zero_b, hipStream_t st)
+                          double *zero_a, int n_zero_a, double *zero_b, int n_zero_b, int phase, hipStream_t st)
 {
     if (p.N <= 0) return;
     BinArgs a = {};
@@ -283,8 +283,8 @@ void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_
     a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_count = s.bin_count; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
     a.b_wrap = s.b_wrap; a.b_slot = s.b_slot; a.slot = s.slot; a.bin_of = s.bin_of; a.wrap = s.wrap; a.stat = s.stat;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
-    hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
-    if (p.count > 0)
+    if (phase != 2) hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
+    if (phase != 1 && p.count > 0)
         hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first,
                            p.stride > 0 ? p.stride : 1, p.count, pos, cell, rc, (const NlGrid *)s.grid, s.bin_of,
                            s.bin_count, s.cap, s.b_idx, s.b_pos, s.b_wrap, s.b_slot, s.wrap, p.maxnn, nn, nn_local, nbr_j,

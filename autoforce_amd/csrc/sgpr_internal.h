@@ -63,7 +63,7 @@ struct NlScratch {
 void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_in, double *pos, const double *cell,
                           double rc, NlScratch s, int *nn /*[N] by sorted index*/, int *nn_local /*[count]*/,
                           int *nbr_j, int *nbr_shift, double *zero_a, int n_zero_a, double *zero_b, int n_zero_b,
-                          hipStream_t st);
+                          int phase /*0 both, 1 binning, 2 list build*/, hipStream_t st);
 
 struct DescParams {
     int lmax, nmax, S;
@@ -94,7 +94,8 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const double *norm, const double *C, const int *shear,
                                const double *W /*[N][Dpad] dE/dp-hat*/, double *dC /*[N][CS] scratch*/,
                                double *F /*[2][Nall][3]: atomic part | own part*/,
-                               double *virial /*[9][workgroups]*/, hipStream_t st);
+                               double *virial /*[9][workgroups]*/, int phase /*0 both, 1 dE/dc, 2 pair*/,
+                               hipStream_t st);
 
 // Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
 void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,

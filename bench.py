@@ -49,12 +49,17 @@ def build_model(device, numbers, pos, cell, pbc, m, workload_seed=1):
 
 
 def algorithmic_bytes(N, nn, D, m):
-    """Per-kernel algorithmic HBM bytes of one step (SURVEY.md §8d formula, split by kernel)."""
+    """Per-kernel algorithmic HBM bytes of one step: the SURVEY.md §8d step formula
+    N nn 44 x2 + N nn 24 + 4 (8 N D) + 8 m D + 2 (8 N m) + 24 N, split by the kernel that moves each term
+    (+ the list the build kernel writes and the triangular factor the covloss product reads)."""
     return {
+        "neighbor_bin": N * (24 + 24 + 16),
+        "neighbor_build": N * nn * 8 + N * 24,
         "descriptor_fwd": N * nn * 44 + 8 * N * D,
         "gemm_knm": 8 * N * D + 8 * m * D + 8 * N * m,
         "gemm_w": 8 * N * m + 8 * m * D + 8 * N * D,
-        "descriptor_bwd": N * nn * 44 + N * nn * 24 + 8 * N * D + 24 * N,
+        "descriptor_dc": 8 * N * D,
+        "descriptor_pair": N * nn * 44 + N * nn * 24 + 24 * N,
         "gemm_covloss": 8 * N * m + 8 * m * m,
     }
 
@@ -173,6 +178,17 @@ def main():
             acc[k] = acc.get(k, 0.0) + v
     mdl.profile(False)
     stage_ms = {k: v / nprof for k, v in acc.items()}
+    # An event-to-event interval holds one launch's marker/dispatch overhead besides the kernel.
+    # Calibration: the same steps without the markers (and without the collective) take t_plain;
+    # the markers therefore cost (sum of intervals - t_plain) / n_stages per stage.
+    torch.cuda.synchronize(dev)
+    tp = time.perf_counter()
+    for _ in range(nprof):
+        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+    torch.cuda.synchronize(dev)
+    t_plain_ms = (time.perf_counter() - tp) / nprof * 1e3
+    overhead_ms = max((sum(stage_ms.values()) - t_plain_ms) / max(len(stage_ms), 1), 0.0)
+    stage_ms = {k: max(v - overhead_ms, 0.0) for k, v in stage_ms.items()}
     dims = mdl.dims
     out_host = packed.cpu().numpy()
     # PCIe-inclusive rate of the host-array entry point (never `value`): numpy in, numpy out
@@ -197,6 +213,10 @@ def main():
         dom = max((k for k in stage_ms if k in ab), key=lambda k: stage_ms[k])
         dom_s = stage_ms[dom] * 1e-3
         # dense flops actually required by the block-diagonal packed formulation
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_lips{N}_m{m}.json")
+        if world == 1 and os.path.exists(tpath):  # PMC counters come from separate rocprofv3 --pmc passes
+            traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("fetch_x2_plus_write")
         roof = {
             "kernel": dom,
             "bound": "hbm",
@@ -204,10 +224,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ab[dom] / dom_s / 1e9 / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes": ab[dom],
             "avg_launch_us": stage_ms[dom] * 1e3,
-            "timing": f"hip events on the launch stream, {nprof} eager steps after the timed region",
+            "timing": f"hip events on the launch stream, {nprof} eager steps after the timed region, minus the "
+                      f"per-stage marker overhead ({overhead_ms * 1e3:.2f} us = (sum of intervals - marker-free step time) / stages)",
             "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
             "step_bytes_packed_layout": sum(ab.values()),
             "step_bytes_survey_formula": sum(ab_survey.values()),
