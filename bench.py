@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     ap.add_argument("--no-fork", action="store_true", help="keep the covloss GEMM on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -115,10 +116,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsgpr_hip has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()  # dry runs may put several ranks on one GPU (gloo only)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     numbers, pos, cell, pbc = lips(args.atoms_side, seed=0)
     N, m = len(numbers), args.inducing
@@ -166,6 +171,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = N * args.steps / dt
+    out_host = packed.cpu().numpy()  # the reduced result of the last timed step
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps run eagerly
     mdl.profile(True)
@@ -190,7 +196,6 @@ def main():
     overhead_ms = max((sum(stage_ms.values()) - t_plain_ms) / max(len(stage_ms), 1), 0.0)
     stage_ms = {k: max(v - overhead_ms, 0.0) for k, v in stage_ms.items()}
     dims = mdl.dims
-    out_host = packed.cpu().numpy()
     # PCIe-inclusive rate of the host-array entry point (never `value`): numpy in, numpy out
     host_rate = None
     if world == 1:
