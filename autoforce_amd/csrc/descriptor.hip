@@ -480,7 +480,10 @@ __device__ __forceinline__ void pair_grad(const double r[3], double u, double rc
     gr[2] = (-ang * gys + gzs + dEdd * z / d) / u;
 }
 
-template <int LMAX, int NMAX, int ST, bool MIRROR>
+// PASS 0: own terms + atomic scatter (sharded form); 3: own then mirrored terms in one launch (the
+// single-process form); 1 / 2: the two halves as separate launches (measured 17.5 + 17.5 us against
+// 29.8 us fused: both halves still need ~220 VGPRs, so splitting buys no occupancy).
+template <int LMAX, int NMAX, int ST, int PASS>
 __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
 {
     using WL = WaveLds<LMAX, NMAX>;
@@ -501,8 +504,11 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
     const bool active = ia < a.N;
     const int gi = a.first + (active ? ia : 0) * a.stride;
     const int nn = active ? a.nn[gi] : 0;
+    constexpr bool MIRROR = PASS == 2 || PASS == 3;
     if (active && nn > 0) {
-        for (int k = lane; k < a.CS; k += 64) dcl[k] = a.dC[(size_t)ia * a.CS + k];
+        if (PASS != 2) {
+            for (int k = lane; k < a.CS; k += 64) dcl[k] = a.dC[(size_t)ia * a.CS + k];
+        }
         wave_sync();
         const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
         const int sc = a.slot[gi];
@@ -513,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
 #pragma unroll
         for (int k = 0; k < 9; k++) cell[k] = uniform(a.cell[k]);
         // pass 1: own terms g_t = dE_j/dr_jt (dE/dc of this atom from LDS)
+        if constexpr (PASS != 2)
         for (int t0 = 0; t0 < nn; t0 += 64) {
             const int t = t0 + lane;
             if (t < nn) {
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
                     for (int q = 0; q < 3; q++) lv[(3 * p + q) * 64 + lane] += r[p] * gr[q];
 #pragma unroll
                 for (int k = 0; k < 3; k++) fsum[k] += gr[k];
-                if constexpr (!MIRROR) {
+                if constexpr (PASS == 0) {
 #pragma unroll
                     for (int k = 0; k < 3; k++) unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
                 }
@@ -575,6 +582,13 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) fsum[k] = wave_sum(fsum[k]);
+    if constexpr (PASS == 2) {
+        // mirrored half: subtract from the forces the own-term launch stored (same wave owns the atom)
+        if (lane == 0 && active)
+#pragma unroll
+            for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] += fsum[k];
+        return;
+    }
     double vir[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) vir[k] = wave_sum(lv[k * 64 + lane]);
@@ -654,10 +668,10 @@ static int run_bwd(const DescArgs &a, hipStream_t st)
     if (a.phase != 2) hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
     if (a.phase == 1) return 0;
     const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + 64 * (WL::LL + 2) + 9 * 64);
-    if (a.stride == 1 && a.first == 0 && a.N == a.Nall)
-        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, true>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
-    else
-        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, false>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
+    if (a.stride == 1 && a.first == 0 && a.N == a.Nall) {
+        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, 3>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
+    } else
+        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, 0>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
     return 0;
 }
 
