@@ -100,7 +100,8 @@ struct sgpr_model {
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
-    DevBuf<int4> t_knm, t_w, t_cov, t_kmm;  // working-tile tables of the four GEMMs
+    DevBuf<int4> t_knm, t_w, t_cov, t_kmm, t_wcov;  // working-tile tables of the GEMMs
+    std::vector<int4> h_t_w, h_t_cov;
     // graph
     hipGraphExec_t gexec = nullptr;
     const void *g_pos = nullptr, *g_cell = nullptr, *g_out = nullptr;
@@ -409,6 +410,26 @@ static int build_tiles(sgpr_model *h, int kind)
     for (int x = 0; x < 8; x++)
         for (size_t j = 0; j < bucket[x].size(); j++) list[j * 8 + x] = bucket[x][j];
     DevBuf<int4> &dst = kind == 0 ? h->t_knm : kind == 1 ? h->t_w : kind == 2 ? h->t_cov : h->t_kmm;
+    if (kind == 1) h->h_t_w = list;
+    if (kind == 2) h->h_t_cov = list;
+    if (kind == 1 || kind == 2) {
+        // grouped table W + covloss: same XCD rule (position % 8 == row tile % 8), covloss entries tagged
+        std::vector<std::vector<int4>> bk(8);
+        for (const int4 &t : h->h_t_w)
+            if (t.w > t.z) bk[t.x % 8].push_back(t);
+        for (const int4 &t : h->h_t_cov)
+            if (t.w > t.z) bk[t.x % 8].push_back(make_int4(t.x | (1 << 16), t.y, t.z, t.w));
+        size_t dp = 0;
+        for (auto &b : bk) dp = std::max(dp, b.size());
+        std::vector<int4> both(dp * 8, make_int4(0, 0, 0, 0));
+        for (int x = 0; x < 8; x++)
+            for (size_t j = 0; j < bk[x].size(); j++) both[j * 8 + x] = bk[x][j];
+        h->t_wcov.release();
+        if (!both.empty()) {
+            if (h->t_wcov.alloc(both.size(), false)) return -1;
+            if (hipMemcpy(h->t_wcov.p, both.data(), sizeof(int4) * both.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        }
+    }
     dst.release();
     if (list.empty()) return 0;
     if (dst.alloc(list.size(), false)) return -1;
@@ -771,34 +792,30 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
                        h->has_mu ? h->d_mu.p : nullptr, h->d_Epart.p, st);
         stamp(h, "gemm_knm", st);
     }
-    // The covloss product needs only K_nm; the reverse pass needs only Aw.  Each of these kernels
-    // leaves CUs idle (a few hundred tiles, one wave per SIMD), so the covloss GEMM is forked onto a
-    // side stream and runs beside W -> dE/dc -> pair forces (a parallel branch of the captured
-    // graph); finalize joins both.  Profiling mode keeps everything on one stream (stage times).
-    const bool fork = beta && predict && !h->profile && h->side != nullptr && h->use_fork;
-    auto covloss = [&](hipStream_t s2) {
-        GemmParams g = {};
-        g.M = cnt; g.N = h->m; g.K = h->m_pad;
-        g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = 0;
-        g.A = h->d_K.p; g.B = h->d_choli.p; g.C = nullptr;
-        g.tiles = h->t_cov.p; g.ntiles = (int)h->t_cov.n;
-        g.rowsq = h->d_csq.p;
-        launch_gemm_nt(g, EPI_ROWSQ, s2);
-    };
-    if (fork) {
-        (void)hipEventRecord(h->ev_fork, st);
-        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
-        covloss(h->side);
-        (void)hipEventRecord(h->ev_join, h->side);
+    // W = Aw.Pm (reverse-pass seed) and the covloss product K.choli^T depend only on the K_nm
+    // kernel and share the row dimension: they go out as ONE grouped launch (582 tiles instead of
+    // 320 + 262, one kernel boundary less).  A side-stream fork of the two measured neutral.
+    GemmParams gw = {}, gc = {};
+    gw.M = cnt; gw.N = h->Dpad; gw.K = h->m_pad;
+    gw.lda = h->m_pad; gw.ldb = h->m_pad; gw.ldc = h->Dpad;
+    gw.A = h->d_Aw.p; gw.B = h->d_PmT.p; gw.C = h->d_W.p;
+    gw.tiles = h->t_w.p; gw.ntiles = (int)h->t_w.n;
+    gc.M = cnt; gc.N = h->m; gc.K = h->m_pad;
+    gc.lda = h->m_pad; gc.ldb = h->m_pad; gc.ldc = 0;
+    gc.A = h->d_K.p; gc.B = h->d_choli.p; gc.C = nullptr;
+    gc.tiles = h->t_cov.p; gc.ntiles = (int)h->t_cov.n;
+    gc.rowsq = h->d_csq.p;
+    if (predict && beta) {
+        launch_gemm_wcov(gw, gc, h->t_wcov.p, (int)h->t_wcov.n, st);
+        stamp(h, "gemm_w_covloss", st);
+    } else if (predict) {
+        launch_gemm_nt(gw, EPI_STORE, st);
+        stamp(h, "gemm_w", st);
+    } else if (beta) {
+        launch_gemm_nt(gc, EPI_ROWSQ, st);
+        stamp(h, "gemm_covloss", st);
     }
     if (predict) {
-        GemmParams g = {};
-        g.M = cnt; g.N = h->Dpad; g.K = h->m_pad;
-        g.lda = h->m_pad; g.ldb = h->m_pad; g.ldc = h->Dpad;
-        g.A = h->d_Aw.p; g.B = h->d_PmT.p; g.C = h->d_W.p;
-        g.tiles = h->t_w.p; g.ntiles = (int)h->t_w.n;
-        launch_gemm_nt(g, EPI_STORE, st);
-        stamp(h, "gemm_w", st);
         for (int phase = 1; phase <= 2; phase++) {
             rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
                                              h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
@@ -807,12 +824,6 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
             if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
             stamp(h, phase == 1 ? "descriptor_dc" : "descriptor_pair", st);
         }
-    }
-    if (fork)
-        (void)hipStreamWaitEvent(st, h->ev_join, 0);
-    else if (beta) {
-        covloss(st);
-        stamp(h, "gemm_covloss", st);
     }
     hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256), dim3(256), 0, st, N, cnt, h->rank,
                        h->world, h->d_perm.p, h->d_slot.p, h->d_F.p, h->d_F.p + 3 * (size_t)N, h->d_csq.p,
@@ -973,7 +984,6 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
 {
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
-    if (!strcmp(name, "fork")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     return fail(SGPR_E_INVALID, "sgpr_set_option: unknown option %s", name);
 }
 

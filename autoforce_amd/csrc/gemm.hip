@@ -29,6 +29,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     GemmParams p;
+    GemmParams p2;   // EPI_WCOV: second problem of the group (tile table entries with bit 16 of .x set)
     int ieta;        // integer exponent or -1
     const int *row_slot, *col_slot;
     double *Epart;
@@ -46,7 +47,10 @@ __device__ __forceinline__ double ipow_d(double x, int n)
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 {
-    const GemmParams &p = g.p;
+    // EPI_WCOV: one launch serves two independent products that share the row dimension (W = Aw.Pm with
+    // a plain store, covloss = K.choli^T with the row-square epilogue); the tile table says which.
+    const bool second = (EPI == EPI_WCOV) && ((g.p.tiles[blockIdx.x].x >> 16) & 1);
+    const GemmParams &p = second ? g.p2 : g.p;
     __shared__ double As[2][BM * 34];
     __shared__ double Bs[2][BN * 34];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -58,9 +62,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     // the grid is dense, row tile fastest (same XCD property).
     const long long t_start = g.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
     int rt, ct, kbeg = 0, kend = p.K;
-    if (p.tiles) {
-        const int4 t = p.tiles[blockIdx.x];
-        rt = t.x; ct = t.y; kbeg = t.z; kend = t.w;
+    if (g.p.tiles) {
+        const int4 t = g.p.tiles[blockIdx.x];
+        rt = t.x & 0xffff; ct = t.y; kbeg = t.z; kend = t.w;
         if (kend <= kbeg) return;  // padding entry
     } else {
         rt = blockIdx.x % g.rows_pad;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                 for (int r = 0; r < 4; r++) {
                     const int row = row0 + wr * 32 + tm * 16 + (lane >> 4) + 4 * r;
                     const double v = acc[tm][tn][r];
-                    if (EPI == EPI_STORE) {
+                    if (EPI == EPI_STORE || (EPI == EPI_WCOV && !second)) {
                         if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = v;
                     } else if (EPI == EPI_SUBLOWER) {
                         if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] -= v;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                     }
                 }
             }
-            if (EPI == EPI_ROWSQ) {
+            if (EPI == EPI_ROWSQ || (EPI == EPI_WCOV && second)) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     double s = rsq[r];
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         // one energy partial per WAVE (no workgroup barrier: the waves retire independently)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
-        if (lane == 0) g.Epart[(size_t)(p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct) * 4 + wave] = esum;
+        if (lane == 0) g.Epart[(size_t)(g.p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct) * 4 + wave] = esum;
     }
     if (g.stamps && threadIdx.x == 0) {
         long long *o = g.stamps + (size_t)blockIdx.x * 4;
@@ -239,10 +243,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     }
 }
 
+void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st)
+{
+    if (ntiles <= 0) return;
+    GemmArgs g = {};
+    g.p = pw;
+    g.p2 = pc;
+    g.p.tiles = tiles;
+    g.p.ntiles = ntiles;
+    g.ieta = -1;
+    hipLaunchKernelGGL(gemm_nt_kernel<EPI_WCOV>, dim3(ntiles), dim3(256), 0, st, g);
+}
+
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return;
-    GemmArgs g;
+    GemmArgs g = {};
     g.p = p;
     g.ieta = (p.eta == (double)(int)p.eta && p.eta >= 1.0 && p.eta <= 64.0) ? (int)p.eta : -1;
     g.row_slot = p.row_slot;

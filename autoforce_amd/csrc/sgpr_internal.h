@@ -102,7 +102,7 @@ void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpa
                                const double *Pp, double *Pdense, hipStream_t st);
 
 // ---- fp64 MFMA GEMM family (C = A * B^T, both operands row-major with K contiguous) --------
-enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3 };
+enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4 };
 
 struct GemmParams {
     int M, N, K;          // C is M x N, reduction K
@@ -128,6 +128,9 @@ struct GemmParams {
     long long *stamps;    // diagnostic only
 };
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st);
+// one launch for two products sharing the row dimension: pw with EPI_STORE, pc with EPI_ROWSQ;
+// tiles[].x carries the row tile in its low 16 bits and the problem (0 = pw, 1 = pc) in bit 16
+void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st);
 
 // ---- dense solve side ---------------------------------------------------------------------
 // All on one stream, m x m row-major with leading dimension ld.

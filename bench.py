@@ -57,10 +57,9 @@ def algorithmic_bytes(N, nn, D, m):
         "neighbor_build": N * nn * 8 + N * 24,
         "descriptor_fwd": N * nn * 44 + 8 * N * D,
         "gemm_knm": 8 * N * D + 8 * m * D + 8 * N * m,
-        "gemm_w": 8 * N * m + 8 * m * D + 8 * N * D,
+        "gemm_w_covloss": 8 * N * m + 8 * m * D + 8 * N * D + 8 * N * m + 8 * m * m,
         "descriptor_dc": 8 * N * D,
         "descriptor_pair": N * nn * 44 + N * nn * 24 + 24 * N,
-        "gemm_covloss": 8 * N * m + 8 * m * m,
     }
 
 
@@ -97,7 +96,6 @@ def main():
     ap.add_argument("--atoms-side", type=int, default=16, help="simple-cubic sites per edge (16 -> 4096 atoms)")
     ap.add_argument("--inducing", type=int, default=512)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
-    ap.add_argument("--no-fork", action="store_true", help="keep the covloss GEMM on the main stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
@@ -131,8 +129,6 @@ def main():
     lib = _lib.load()
     h = mdl.handle
     _lib.check(lib.sgpr_set_option(h, b"graph", 1 if args.graph else 0))
-    if args.no_fork:
-        _lib.check(lib.sgpr_set_option(h, b"fork", 0))
 
     dev = torch.device("cuda", local_rank)
     pos_d = torch.from_numpy(pos).to(dev)

@@ -151,8 +151,7 @@ int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell
  * steps' results are invalid; capacity has been grown, the next step re-sizes eagerly). */
 int sgpr_sync_check(sgpr_model *h, void *stream);
 /* Options: "graph" = 0/1 (replay sgpr_step_dev from a captured HIP graph; default 0: eager launches
- * pipeline well while a step is >100 us of kernels and measured faster than replay);
- * "fork" = 0/1 (covloss GEMM on a side stream beside the reverse pass; default 0). */
+ * pipeline well while a step is >100 us of kernels and measured faster than replay). */
 int sgpr_set_option(sgpr_model *h, const char *name, int value);
 /* stress[6] (Voigt, eV/A^3) from a (summed) packed buffer on the host:
  * calculator/active.py:604-610, volume = |det cell| or -2 for a rank-deficient cell. */
