@@ -1,0 +1,158 @@
+"""GPU tests that force the less-travelled code paths of the HIP library, each against the pinned CPU
+oracle on identical inputs: 5 species (the 8-slot kernel instantiation), lmax=nmax=4, environments
+with more than 64 neighbours (multi-tile descriptor passes, neighbour capacity growth), a cell much
+smaller than the cutoff (many periodic images, more than 64 bins in the sweep), a dense cluster in
+ONE bin (bin-capacity growth), degenerate inputs (no atoms, no inducing set)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_frame(rng, n, box, species, dmin=1.4, pbc=True, cell=None):
+    pos = rng.random((n, 3)) * box
+    cell = np.eye(3) * box if cell is None else cell
+    from oracle import oracle as orc
+    for _ in range(300):  # push apart close pairs
+        ptr, j, off = orc.neighbors(pos, cell, [pbc] * 3, dmin)
+        if len(j) == 0:
+            break
+        i = np.repeat(np.arange(n), np.diff(ptr))
+        d = pos[j] - pos[i] + off.astype(float) @ cell
+        np.add.at(pos, i, -0.2 * d / np.linalg.norm(d, axis=1, keepdims=True))
+    numbers = rng.choice(species, size=n).astype(np.int32)
+    return numbers, pos, cell
+
+
+def build(lmax, nmax, eta, rc, species, numbers, pos, cell, pbc, m, seed):
+    from autoforce_amd import Local, SGPRModel
+    from oracle import oracle as orc
+    rng = np.random.default_rng(seed)
+    ptr, j, off = orc.neighbors(pos, cell, pbc, rc)
+    idx = rng.choice(len(numbers), size=m, replace=False)
+    X = []
+    for a in idx:
+        s = slice(ptr[a], ptr[a + 1])
+        r = pos[j[s]] - pos[a] + off[s].astype(float) @ cell + 0.03 * rng.normal(size=(ptr[a + 1] - ptr[a], 3))
+        keep = np.linalg.norm(r, axis=1) < rc - 1e-3
+        X.append(Local(int(numbers[a]), numbers[j[s]][keep], r[keep]))
+    mdl = SGPRModel(lmax, nmax, eta, rc, species=species)
+    mdl.set_inducing(X)
+    return mdl, (ptr, j, off)
+
+
+def compare(mdl, lmax, nmax, eta, rc, numbers, pos, cell, pbc, nl, tol=1e-8):
+    from oracle import oracle as orc
+    X = mdl.X
+    species = np.array(mdl.species, np.int32)
+    ind_z = np.array([x.number for x in X], np.int32)
+    ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
+    Pm, nnm = orc.inducing_descriptors(lmax, nmax, rc, species, ind_z, ind_ptr,
+                                       np.concatenate([x._b for x in X]), np.concatenate([x._r for x in X]))
+    M = orc.kernel_matrix(ind_z, nnm, Pm, ind_z, nnm, Pm, eta)
+    np.testing.assert_allclose(mdl.M, M, rtol=1e-9, atol=1e-12)
+    L, ridge = orc.jitcholesky(M)
+    choli = orc.tril_inverse(L)
+    mu = np.random.default_rng(9).normal(size=len(X))
+    mdl.set_weights(mu, choli=choli)
+    out = mdl.predict(numbers, pos, cell, pbc, cov=True)
+    N = len(numbers)
+    p, j, off = mdl.neighbors(N)
+    i = np.repeat(np.arange(N), np.diff(p))
+    i0 = np.repeat(np.arange(N), np.diff(nl[0]))
+    got = set(map(tuple, np.column_stack([i, j, off]).tolist()))
+    want = set(map(tuple, np.column_stack([i0, nl[1], nl[2]]).tolist()))
+    assert got == want
+    ref = orc.frame(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mu, choli=choli)
+    np.testing.assert_allclose(out["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
+    assert abs(out["energy"] - ref["energy"]) <= 1e-9 * max(1.0, abs(ref["energy"]))
+    assert np.abs(out["forces"] - ref["forces"]).max() <= tol * np.abs(ref["forces"]).max()
+    assert np.abs(out["stress"] - ref["stress"]).max() <= tol * max(np.abs(ref["stress"]).max(), 1e-12)
+    np.testing.assert_allclose(out["beta"], ref["beta"], rtol=0, atol=3e-6)
+    return out
+
+
+def test_five_species_uses_the_8_slot_kernels():
+    rng = np.random.default_rng(1)
+    species = [1, 6, 7, 8, 16]
+    numbers, pos, cell = random_frame(rng, 96, 9.5, species)
+    mdl, nl = build(3, 3, 4.0, 5.0, species, numbers, pos, cell, [True] * 3, 20, 2)
+    compare(mdl, 3, 3, 4.0, 5.0, numbers, pos, cell, [True] * 3, nl)
+    mdl.close()
+
+
+def test_lmax4_nmax4():
+    rng = np.random.default_rng(3)
+    species = [13, 8]
+    numbers, pos, cell = random_frame(rng, 60, 8.4, species)
+    mdl, nl = build(4, 4, 2.0, 5.0, species, numbers, pos, cell, [True] * 3, 12, 4)
+    compare(mdl, 4, 4, 2.0, 5.0, numbers, pos, cell, [True] * 3, nl)
+    mdl.close()
+
+
+def test_more_than_64_neighbours_and_capacity_growth():
+    """rc = 7.5 on a dense frame: ~110 neighbours per atom (two descriptor tiles, list capacity grows
+    from its initial 64)."""
+    rng = np.random.default_rng(5)
+    species = [3, 16]
+    numbers, pos, cell = random_frame(rng, 120, 12.0, species, dmin=1.8)
+    mdl, nl = build(3, 3, 4.0, 7.5, species, numbers, pos, cell, [True] * 3, 16, 6)
+    assert np.diff(nl[0]).max() > 64
+    compare(mdl, 3, 3, 4.0, 7.5, numbers, pos, cell, [True] * 3, nl)
+    assert mdl.dims["maxnn"] >= np.diff(nl[0]).max()
+    mdl.close()
+
+
+def test_tiny_cell_many_images():
+    """3-atom triclinic cell with heights ~2.6 A and rc = 6: every neighbour is a periodic image,
+    the sweep covers 5x5x5 = 125 (> 64) image bins, lists hold > 256 entries."""
+    species = [29]
+    cell = np.array([[2.7, 0.0, 0.0], [0.4, 2.8, 0.0], [0.3, -0.5, 2.9]])
+    pos = np.array([[0.1, 0.2, 0.1], [1.4, 1.5, 1.2], [2.2, 0.3, 2.0]])
+    numbers = np.array([29, 29, 29], np.int32)
+    from autoforce_amd import Local, SGPRModel
+    from oracle import oracle as orc
+    nl = orc.neighbors(pos, cell, [True] * 3, 6.0)
+    assert np.diff(nl[0]).min() > 100
+    rng = np.random.default_rng(7)
+    X = []
+    for a in range(3):
+        s = slice(nl[0][a], nl[0][a + 1])
+        r = pos[nl[1][s]] - pos[a] + nl[2][s].astype(float) @ cell + 0.02 * rng.normal(size=(nl[0][a + 1] - nl[0][a], 3))
+        keep = np.linalg.norm(r, axis=1) < 6.0 - 1e-3
+        X.append(Local(29, numbers[nl[1][s]][keep], r[keep]))
+    mdl = SGPRModel(3, 3, 4.0, 6.0, species=species)
+    mdl.set_inducing(X)
+    compare(mdl, 3, 3, 4.0, 6.0, numbers, pos, cell, [True] * 3, nl)
+    mdl.close()
+
+
+def test_dense_cluster_in_one_bin():
+    """150 atoms, no periodicity: one bin holds everything (bin capacity grows from 64)."""
+    rng = np.random.default_rng(11)
+    species = [79, 47]
+    numbers, pos, cell = random_frame(rng, 150, 14.0, species, dmin=2.2, pbc=False)
+    zero = np.zeros((3, 3))
+    mdl, nl = build(3, 3, 4.0, 6.0, species, numbers, pos, zero, [False] * 3, 14, 12)
+    compare(mdl, 3, 3, 4.0, 6.0, numbers, pos, zero, [False] * 3, nl)
+    mdl.close()
+
+
+def test_degenerate_inputs():
+    from autoforce_amd import SGPRModel, SgprError
+    mdl = SGPRModel(3, 3, 4.0, 6.0, species=[14])
+    # no atoms
+    out = mdl.predict(np.zeros(0, np.int32), np.zeros((0, 3)), np.eye(3) * 5, [True] * 3)
+    assert out["energy"] == 0.0 and out["forces"].shape == (0, 3)
+    # atoms but no inducing set: zero energy and forces, lists still built
+    pos = np.array([[0.0, 0, 0], [1.5, 1.5, 1.5]])
+    out = mdl.predict(np.array([14, 14], np.int32), pos, np.eye(3) * 4.0, [True] * 3)
+    assert out["energy"] == 0.0 and np.all(out["forces"] == 0.0)
+    p, j, off = mdl.neighbors(2)
+    assert p[-1] > 0
+    with pytest.raises(SgprError):
+        mdl.set_weights(np.zeros(0))
+    mdl.close()
+    with pytest.raises(SgprError) as e:
+        SGPRModel(5, 3, 4.0, 6.0, species=[14])  # not compiled in
+    assert e.value.code == -6
