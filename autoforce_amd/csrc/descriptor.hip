@@ -381,9 +381,15 @@ __global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
     const int ia = blockIdx.x * 4 + wave;
     if (ia >= a.N) return;
     const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
-    const int perwave = ST * NSLOT + a.Dpad;
-    double *cl = smem + (size_t)wave * perwave;  // [ST][NSLOT]  c
-    double *gl = cl + ST * NSLOT;                // [Dpad]       dE/dp~ * coef * (1 or 2)
+    // Up to 4 species the packed gradient is expanded into the full symmetric [u][v][l] array in LDS,
+    // which turns the contraction below into stride-1 addressing; 8 slots would need 32 KB per wave
+    // and keep the packed form with computed pair indices.
+    constexpr bool EXPAND = ST <= 4;
+    constexpr int UT = ST * N1, L1 = LMAX + 1;
+    constexpr int GS = EXPAND ? UT * UT * L1 : 0;
+    const int perwave = ST * NSLOT + (EXPAND ? GS : a.Dpad);
+    double *cl = smem + (size_t)wave * perwave;  // [ST][NSLOT]  c  ( = [u][lm], u = s*N1+n )
+    double *gl = cl + ST * NSLOT;                // EXPAND: [UT][UT][L1] else [Dpad]:  dE/dp~ * coef * (1 or 2)
     const int gi = a.first + ia * a.stride;
     const int nn = a.nn[gi];
     const double nrm = a.norm[ia];
@@ -401,7 +407,12 @@ __global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
     const double corr = pw * sden / nrm;
     for (int e = lane; e < a.Dc; e += 64) {
         const PackEntry pe = a.pack[e];
-        gl[e] = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+        const double gv = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+        if constexpr (EXPAND) {
+            gl[(pe.u * UT + pe.v) * L1 + pe.l] = gv;
+            gl[(pe.v * UT + pe.u) * L1 + pe.l] = gv;
+        } else
+            gl[e] = gv;
     }
 #pragma unroll
     for (int s = 0; s < ST; s++)
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
                 cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
         }
     wave_sync();
-    // dE/dc[u][lm] = sum_v G[pair(u,v)][l] c[v][lm]
+    // dE/dc[u][lm] = sum_v G[u][v][l] c[v][lm]
 #pragma unroll
     for (int s = 0; s < ST; s++)
 #pragma unroll
@@ -425,10 +436,16 @@ __global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
                 for (int q = 1; q <= LMAX; q++) l += (lm >= q * q) ? 1 : 0;
                 const int u = s * N1 + n;
                 double d = 0.0;
-                for (int v = 0; v < Ur; v++) {
-                    const int lo = min(u, v), hi = max(u, v);
-                    const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
-                    d += gl[pair * (LMAX + 1) + l] * cl[(v / N1) * NSLOT + (v % N1) * LL + lm];
+                if constexpr (EXPAND) {
+                    const double *gu = gl + u * UT * L1 + l;
+#pragma unroll 4
+                    for (int v = 0; v < Ur; v++) d += gu[v * L1] * cl[v * LL + lm];
+                } else {
+                    for (int v = 0; v < Ur; v++) {
+                        const int lo = min(u, v), hi = max(u, v);
+                        const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
+                        d += gl[pair * L1 + l] * cl[v * LL + lm];
+                    }
                 }
                 dC[s * NSLOT + slot] = d;
             }
@@ -658,7 +675,7 @@ static int run_bwd(const DescArgs &a, hipStream_t st)
 {
     if (a.N <= 0) return 0;
     using WL = WaveLds<LMAX, NMAX>;
-    const size_t lds1 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + a.Dpad);
+    const size_t lds1 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + (ST <= 4 ? (ST * WL::N1) * (ST * WL::N1) * (LMAX + 1) : a.Dpad));
     static size_t attr_set = 0;
     if (attr_set < lds1) {
         (void)hipFuncSetAttribute((const void *)desc_dc_kernel<LMAX, NMAX, ST>,
