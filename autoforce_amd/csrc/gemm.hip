@@ -44,9 +44,12 @@ __device__ __forceinline__ double ipow_d(double x, int n)
     return y;
 }
 
-template <int EPI>
+// TM = MFMA row tiles per wave: 2 -> 64-row workgroup tiles, 1 -> 32-row tiles (twice the tiles, half
+// the latency of each: used when a launch would otherwise leave most CUs empty).
+template <int EPI, int TM = 2>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 {
+    constexpr int BMT = 32 * TM;
     // EPI_WCOV: one launch serves two independent products that share the row dimension (W = Aw.Pm with
     // a plain store, covloss = K.choli^T with the row-square epilogue); the tile table says which.
     const bool second = (EPI == EPI_WCOV) && ((g.p.tiles[blockIdx.x].x >> 16) & 1);
@@ -71,26 +74,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         ct = blockIdx.x / g.rows_pad;
         if (rt >= g.row_tiles) return;
     }
-    const int row0 = rt * BM, col0 = ct * BN;
+    const int row0 = rt * BMT, col0 = ct * BN;
     const bool skip = (EPI == EPI_SUBLOWER && col0 > row0);  // symmetric update: lower tiles only
 
-    v4d acc[2][2];
+    v4d acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     // EPI_KERNEL: species slot / neighbour count per row, slot / count / weight per column of this
     // lane's 8 rows and 2 columns, requested now so the latency hides under the main loop
     // (all arrays are padded to whole tiles by the allocator).
-    int e_rs[2][4], e_rn[2][4], e_cs[2], e_cn[2];
+    int e_rs[TM][4], e_rn[TM][4], e_cs[2], e_cn[2];
     double e_mu[2];
     if (EPI == EPI_KERNEL) {
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++)
+        for (int tm = 0; tm < TM; tm++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const int row = row0 + wr * 32 + tm * 16 + (lane >> 4) + 4 * r;
+                const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
                 e_rs[tm][r] = g.row_slot[row];
                 e_rn[tm][r] = p.row_nn ? p.row_nn[row] : 1;
             }
@@ -121,30 +124,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         double2 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;  // stage "q"
 #define GLOAD(S, K0)                                                                             \
     if ((K0) < kend) {                                                                           \
+        if (TM == 2 || lr < BMT) {                                                               \
         S##a0 = *(const double2 *)(Ag + (K0)); S##a1 = *(const double2 *)(Ag + (K0) + 2);        \
         S##a2 = *(const double2 *)(Ag + (K0) + 4); S##a3 = *(const double2 *)(Ag + (K0) + 6);    \
+        }                                                                                        \
         S##b0 = *(const double2 *)(Bg + (K0)); S##b1 = *(const double2 *)(Bg + (K0) + 2);        \
         S##b2 = *(const double2 *)(Bg + (K0) + 4); S##b3 = *(const double2 *)(Bg + (K0) + 6);    \
     }
 #define LSTORE(S, BUF)                                                                           \
     {                                                                                            \
         double *da = &As[BUF][lr * LD + lk], *db = &Bs[BUF][lr * LD + lk];                       \
+        if (TM == 2 || lr < BMT) {                                                               \
         *(double2 *)(da) = S##a0; *(double2 *)(da + 2) = S##a1;                                  \
         *(double2 *)(da + 4) = S##a2; *(double2 *)(da + 6) = S##a3;                              \
+        }                                                                                        \
         *(double2 *)(db) = S##b0; *(double2 *)(db + 2) = S##b1;                                  \
         *(double2 *)(db + 4) = S##b2; *(double2 *)(db + 6) = S##b3;                              \
     }
-        const int fa = (wr * 32 + (lane & 15)) * LD + (lane >> 4);
+        const int fa = (wr * 16 * TM + (lane & 15)) * LD + (lane >> 4);
         const int fb = (wc * 32 + (lane & 15)) * LD + (lane >> 4);
         auto compute = [&](int buf) {
 #pragma unroll
             for (int kk = 0; kk < KS; kk += 4) {
-                const double a0 = As[buf][fa + kk], a1 = As[buf][fa + 16 * LD + kk];
                 const double b0 = Bs[buf][fb + kk], b1 = Bs[buf][fb + 16 * LD + kk];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < TM; tm++) {
+                    const double a0 = As[buf][fa + tm * 16 * LD + kk];
+                    acc[tm][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[tm][0], 0, 0, 0);
+                    acc[tm][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[tm][1], 0, 0, 0);
+                }
             }
         };
         // prologue: stage 0 -> LDS buffer 0, stage 1 and 2 in flight in registers
@@ -179,14 +187,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     double esum = 0.0;
     if (!skip) {
 #pragma unroll
-        for (int tm = 0; tm < 2; tm++) {
+        for (int tm = 0; tm < TM; tm++) {
             double rsq[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int tn = 0; tn < 2; tn++) {
                 const int col = col0 + wc * 32 + tn * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int row = row0 + wr * 32 + tm * 16 + (lane >> 4) + 4 * r;
+                    const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
                     const double v = acc[tm][tn][r];
                     if (EPI == EPI_STORE || (EPI == EPI_WCOV && !second)) {
                         if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = v;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                     s += __shfl_xor(s, 2, 64);
                     s += __shfl_xor(s, 4, 64);
                     s += __shfl_xor(s, 8, 64);
-                    const int row = row0 + wr * 32 + tm * 16 + (lane >> 4) + 4 * r;
+                    const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
                     if ((lane & 15) == 0 && row < p.M && s != 0.0) unsafeAtomicAdd(&p.rowsq[row], s);
                 }
             }
@@ -252,7 +260,8 @@ void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *ti
     g.p.tiles = tiles;
     g.p.ntiles = ntiles;
     g.ieta = -1;
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI_WCOV>, dim3(ntiles), dim3(256), 0, st, g);
+    if (pw.bm == 32) hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 1>), dim3(ntiles), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 2>), dim3(ntiles), dim3(256), 0, st, g);
 }
 
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
@@ -270,7 +279,10 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
     g.rows_pad = (g.row_tiles + 7) / 8 * 8;
     dim3 grid(p.tiles ? p.ntiles : g.rows_pad * g.col_tiles), block(256);
     if (p.tiles && p.ntiles <= 0) return;
-    if (epi == EPI_STORE) hipLaunchKernelGGL(gemm_nt_kernel<EPI_STORE>, grid, block, 0, st, g);
+    if (epi == EPI_STORE && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_STORE, 1>), grid, block, 0, st, g);
+    else if (epi == EPI_ROWSQ && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_ROWSQ, 1>), grid, block, 0, st, g);
+    else if (epi == EPI_STORE) hipLaunchKernelGGL(gemm_nt_kernel<EPI_STORE>, grid, block, 0, st, g);
+    else if (epi == EPI_KERNEL && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_KERNEL, 1>), grid, block, 0, st, g);
     else if (epi == EPI_KERNEL) hipLaunchKernelGGL(gemm_nt_kernel<EPI_KERNEL>, grid, block, 0, st, g);
     else if (epi == EPI_SUBLOWER) hipLaunchKernelGGL(gemm_nt_kernel<EPI_SUBLOWER>, grid, block, 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWSQ>, grid, block, 0, st, g);

@@ -113,6 +113,7 @@ struct GemmParams {
     // {row tile, col tile, kbeg, kend} (kend <= kbeg marks a padding entry); null = dense.
     const int4 *tiles;
     int ntiles;
+    int bm;               // rows per tile of the table: 64 (default when 0) or 32
     int tri;              // unused by the kernel (the tile table carries the trimmed k range)
     // EPI_KERNEL extras
     double eta;
