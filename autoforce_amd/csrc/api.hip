@@ -77,6 +77,7 @@ struct sgpr_model {
     DevBuf<int> d_ind_slot, d_ind_nn, d_qoff;
     DevBuf<double> d_Pm, d_PmT, d_pm_norm, d_M, d_mu, d_choli;
     bool has_mu = false, has_choli = false, choli_lower = true;
+    const double *rows_mu = nullptr;  // sgpr_kernel_rows: unit weights for the K_nm pass, no reverse pass
     std::vector<double> mean_w, vscale;
     DevBuf<double> d_vs_sqrt;  // sqrt(vscale) per slot
     // bound system
@@ -793,11 +794,11 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
                                         h->d_C.p, h->d_shear.p, st);
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
     stamp(h, "descriptor_fwd", st);
-    const bool predict = h->m > 0 && h->has_mu && cnt > 0;
-    const bool beta = h->m > 0 && h->has_choli && cnt > 0;
+    const bool predict = h->m > 0 && h->has_mu && cnt > 0 && !h->rows_mu;
+    const bool beta = h->m > 0 && h->has_choli && cnt > 0 && !h->rows_mu;
     if (h->m > 0 && cnt > 0) {
         gemm_kernel_pm(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->t_knm, h->d_K.p, h->d_Aw.p,
-                       h->has_mu ? h->d_mu.p : nullptr, h->d_Epart.p, st);
+                       h->rows_mu ? h->rows_mu : (h->has_mu ? h->d_mu.p : nullptr), h->d_Epart.p, st);
         stamp(h, "gemm_knm", st);
     }
     // W = Aw.Pm (reverse-pass seed) and the covloss product K.choli^T depend only on the K_nm

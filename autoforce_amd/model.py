@@ -140,6 +140,36 @@ class SGPRModel:
         self.make_vscale()
         return mu
 
+    def kernel_rows(self, numbers, positions, cell, pbc):
+        """(Ke[m], Kf[3N,m], Kv[6,m]) of one data frame (gppotential.py:63-84, :495-497)."""
+        numbers = i32(numbers)
+        N = len(numbers)
+        positions = f64(positions).reshape(N, 3)
+        cell = f64(np.asarray(cell, float).reshape(3, 3))
+        pbc = i32(np.asarray(pbc, bool).astype(np.int32))
+        Ke, Kf, Kv = np.zeros(self.m), np.zeros((3 * N, self.m)), np.zeros((6, self.m))
+        check(_lib.load().sgpr_kernel_rows(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), ptr(Ke),
+                                           ptr(Kf), ptr(Kv)))
+        return Ke, Kf, Kv
+
+    def fit(self, frames, noise=0.01):
+        """set_data + make_munu (gppotential.py:484-509, :548-605) for a list of labelled frames
+        dict(numbers, positions, cell, pbc, energy, forces[, stress]): builds K = [Ke; Kf; Kv] and
+        Y = [E - mean; F; V * stress] and solves for mu on the device.  Frames without `stress`
+        contribute no virial rows."""
+        Ke, Kf, Kv, Ye, Yf, Yv = [], [], [], [], [], []
+        for fr in frames:
+            ke, kf, kv = self.kernel_rows(fr["numbers"], fr["positions"], fr["cell"], fr["pbc"])
+            Ke.append(ke[None]); Kf.append(kf)
+            mean = sum(self.mean.get(int(z), 0.0) for z in fr["numbers"])
+            Ye.append([fr["energy"] - mean]); Yf.append(np.asarray(fr["forces"], float).reshape(-1))
+            if fr.get("stress") is not None:
+                vol = abs(np.linalg.det(np.asarray(fr["cell"], float).reshape(3, 3)))
+                Kv.append(kv); Yv.append(np.asarray(fr["stress"], float) * vol)
+        K = np.concatenate(Ke + Kf + Kv)
+        Y = np.concatenate([np.concatenate(Ye)] + Yf + Yv)
+        return self.solve(K, Y, noise=noise)
+
     def make_vscale(self):
         out = np.zeros(len(self.species))
         check(_lib.load().sgpr_make_vscale(self._h, ptr(out)))

@@ -104,6 +104,20 @@ int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, cons
 int sgpr_solve(sgpr_model *h, int rows, const double *K, const double *Y, double noise0,
                double *mu_out, double *choli_out, double *ridge_out, double *sigma_out);
 
+/*
+ * Training rows of one data frame against the inducing set, on the device
+ * (regression/gppotential.py:63-84 energy_energy / forces_energy / virial_energy through
+ * similarity/universal.py:109-183 get_func / get_leftgrad / get_virial; used by set_data :495-497
+ * and add_data :728-737):
+ *   Ke[m]     = sum_i k(i,q)
+ *   Kf[3N][m] = -d(sum_i k(i,q))/dx   (row 3*atom+component, caller atom order)
+ *   Kv[6][m]  = sum_pairs r (x) dk/dr, Voigt xx,yy,zz,yz,xz,xy (pairs with stress * volume)
+ * computed as m reverse passes with mu = e_q (exact derivative; the reference's analytic path
+ * carries an fp32-rounded table and agrees to ~1e-6).  Any output may be NULL.
+ */
+int sgpr_kernel_rows(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
+                     const double *cell, const int32_t *pbc, double *Ke, double *Kf, double *Kv);
+
 /* vscale[S] = mean_{q: Z_q = z} mu_q (K_mm mu)_q (regression/gppotential.py:644-649);
  * +inf where a species has no inducing point. Installs it in the handle as well. */
 int sgpr_make_vscale(sgpr_model *h, double *vscale_out);

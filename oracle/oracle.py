@@ -144,6 +144,25 @@ def frame(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm, 
     return dict(p=P, cov=K, energy=E.value, forces=F, dcell=dcell, stress=stress, beta=beta)
 
 
+def kernel_rows(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm):
+    """Training rows of one frame against the inducing set (regression/gppotential.py:63-84 with
+    similarity/universal.py:109-183): Ke[q] = sum_i k(i,q); Kf[:,q] = -d(sum_i k(i,q))/dx (= the forces for
+    mu = e_q); Kv[:,q] = sum_pairs r (x) dk/dr in Voigt order (= stress * volume for mu = e_q)."""
+    m, N = len(ind_z), len(numbers)
+    Ke, Kf, Kv = np.zeros(m), np.zeros((3 * N, m)), np.zeros((6, m))
+    cell = np.asarray(cell, float).reshape(3, 3)
+    vol = abs(np.linalg.det(cell))
+    vol = vol if vol > 0 else -2.0
+    for q in range(m):
+        mu = np.zeros(m)
+        mu[q] = 1.0
+        out = frame(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mu, want_p=False)
+        Ke[q] = out["energy"]
+        Kf[:, q] = out["forces"].reshape(-1)
+        Kv[:, q] = out["stress"] * vol
+    return Ke, Kf, Kv
+
+
 def jitcholesky(M):
     M = np.ascontiguousarray(M, np.float64)
     n = len(M)

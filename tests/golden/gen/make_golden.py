@@ -410,6 +410,41 @@ def frames():
     mu = np.random.default_rng(42).normal(size=10)
     frame_outputs("g5_slab18_nearz", numbers, pos, cell, [True, True, False], ind, mu)
 
+    # cells at least 2*rc wide in every periodic direction: no atom appears twice in a neighbour list.
+    # Needed for the training-row fixtures: the reference's get_leftgrad scatters with `g[j] += f`
+    # (similarity/universal.py:148), which drops contributions when j repeats (periodic self images).
+    rng = np.random.default_rng(60)
+    cell = np.eye(3) * 12.6
+    pos = rng.random((40, 3)) * 12.6
+    for _ in range(300):
+        ptr, J, O = brute_force_nl(pos, cell, [True] * 3, 1.9)
+        if len(J) == 0:
+            break
+        i = np.repeat(np.arange(40), np.diff(ptr))
+        d = pos[J] - pos[i] + O.astype(float) @ cell
+        np.add.at(pos, i, -0.15 * d / np.linalg.norm(d, axis=1, keepdims=True))
+    numbers = rng.choice([3, 16], size=40)
+    rng1 = np.random.default_rng(61)
+    ind = inducing_from(rng1, numbers, rattle(rng1, pos, 0.1), cell, [True] * 3, 6.0, 12)
+    mu = np.random.default_rng(62).normal(size=12)
+    frame_outputs("g5_big40", numbers, pos, cell, [True] * 3, ind, mu)
+
+    rng = np.random.default_rng(70)
+    cell = np.array([[13.0, 0.0, 0.0], [3.0, 13.2, 0.0], [-2.0, 2.5, 13.5]])
+    pos = rng.random((36, 3)) @ cell
+    for _ in range(300):
+        ptr, J, O = brute_force_nl(pos, cell, [True] * 3, 1.9)
+        if len(J) == 0:
+            break
+        i = np.repeat(np.arange(36), np.diff(ptr))
+        d = pos[J] - pos[i] + O.astype(float) @ cell
+        np.add.at(pos, i, -0.15 * d / np.linalg.norm(d, axis=1, keepdims=True))
+    numbers = rng.choice([8, 40, 1], size=36)
+    rng1 = np.random.default_rng(71)
+    ind = inducing_from(rng1, numbers, rattle(rng1, pos, 0.1), cell, [True] * 3, 6.0, 10)
+    mu = np.random.default_rng(72).normal(size=10)
+    frame_outputs("g5_bigtric36", numbers, pos, cell, [True] * 3, ind, mu)
+
     # small-basis variant (lmax=2, nmax=2, eta=2, rc=4.5) on the Si frame
     rng = np.random.default_rng(0)
     pos = np.concatenate([basis + np.array([i, j, 0]) * a for i in range(2) for j in range(2)])
@@ -530,8 +565,44 @@ def g9_distributer():
     print("g9_distributer done")
 
 
+# ----------------------------------------------------------------------------- training rows
+def kernel_rows(name):
+    """K_e, K_f, K_v of one data frame against the inducing set, by the reference's ANALYTIC
+    gradient path (similarity/universal.py:109-183 get_func / get_leftgrad / get_virial through
+    regression/gppotential.py:63-84): Ke = sum_i k(i,q); Kf = -d(sum_i k(i,q))/dx; Kv = sum r (x) dk/dr."""
+    g = np.load(os.path.join(OUT, name + ".npz"))
+    kern, efk = make_kernel(int(g["lmax"]), int(g["nmax"]), int(g["eta"]), float(g["rc"]))
+    numbers, pos, cell = g["numbers"], g["positions"], g["cell"]
+    ptr, J, O = g["nl_ptr"], g["nl_j"], g["nl_off"]
+    N = len(numbers)
+    xyz = torch.tensor(pos)
+    lll = torch.tensor(cell)
+    locs = []
+    for a in range(N):
+        n = J[ptr[a]:ptr[a + 1]].astype(np.int64)
+        assert len(set(n.tolist())) == len(n), "repeated neighbour: the reference's g[j] += f would drop terms"
+        off = O[ptr[a]:ptr[a + 1]]
+        r = xyz[n] - xyz[a] + (torch.from_numpy(off[..., None].astype(float)) * lll).sum(dim=1)
+        loc = Local(a, n, numbers[a], numbers[n], r, off, efk.kernels, dont_save_grads=False)
+        loc.natoms = N
+        locs.append(loc)
+    X = []
+    ip = g["ind_ptr"]
+    for q, zc in enumerate(g["ind_z"]):
+        k = int(ip[q + 1] - ip[q])
+        X.append(Local(0, np.arange(1, k + 1), int(zc), g["ind_nbr_z"][ip[q]:ip[q + 1]].astype(np.int64),
+                       torch.tensor(g["ind_nbr_r"][ip[q]:ip[q + 1]].reshape(k, 3)), None, efk.kernels, True))
+    m = len(X)
+    Ke = efk.base_kerns(locs, X, "func").detach().numpy().sum(0)                       # [m]
+    lg = efk.base_kerns(locs, X, "leftgrad").detach().numpy().reshape(N, 3 * N, m).sum(0)
+    Kf = -lg                                                                            # [3N, m]
+    Kv = efk.base_kerns(locs, X, "virial").detach().numpy().reshape(N, 6, m).sum(0)     # [6, m]
+    np.savez_compressed(os.path.join(OUT, name.replace("g5_", "g6_rows_") + ".npz"), Ke=Ke, Kf=Kf, Kv=Kv)
+    print(f"{name}: rows done; |Kf|max={abs(Kf).max():.3f}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "kat", "frames", "g7", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "kat", "frames", "g7", "g9", "rows"]
     if "g1" in which:
         g1_ylm()
     if "g2" in which:
@@ -544,3 +615,6 @@ if __name__ == "__main__":
         g7_regression()
     if "g9" in which:
         g9_distributer()
+    if "rows" in which:
+        for nm in ("g5_big40", "g5_bigtric36", "g5_cluster16"):
+            kernel_rows(nm)

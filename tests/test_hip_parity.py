@@ -14,7 +14,8 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-FRAMES = ["g5_si32", "g5_mixed64", "g5_tric24", "g5_cluster16", "g5_slab18_nearz", "g5_si32_l2n2"]
+FRAMES = ["g5_si32", "g5_mixed64", "g5_tric24", "g5_cluster16", "g5_slab18_nearz", "g5_si32_l2n2", "g5_big40",
+          "g5_bigtric36"]
 
 
 def load(name):

@@ -9,7 +9,8 @@ import pytest
 from conftest import GOLDEN
 from oracle import oracle as orc
 
-FRAMES = ["g5_si32", "g5_mixed64", "g5_tric24", "g5_cluster16", "g5_slab18_nearz", "g5_si32_l2n2"]
+FRAMES = ["g5_si32", "g5_mixed64", "g5_tric24", "g5_cluster16", "g5_slab18_nearz", "g5_si32_l2n2", "g5_big40",
+          "g5_bigtric36"]
 
 
 def load(name):
@@ -191,3 +192,22 @@ def test_distributer(ws):
     np.testing.assert_array_equal(ranks, g[f"ranks_{ws}"])
     ranks2, _, _ = orc.distribute(g["numbers"][::-1], ws, loads, total)
     np.testing.assert_array_equal(ranks2, g[f"ranks2_{ws}"])
+
+
+# ---------------------------------------------------------------- G6: training rows K_e, K_f, K_v
+@pytest.mark.parametrize("name", ["g5_big40", "g5_bigtric36", "g5_cluster16"])
+def test_kernel_rows(name):
+    """The reference builds these rows with its ANALYTIC gradient code (fp32-rounded coefficient
+    table, SURVEY §7 'two gradient paths'): agreement is limited to ~1e-6 by the reference.
+    Frames are at least 2 rc wide: the reference scatters with `g[j] += f`
+    (similarity/universal.py:148), which silently drops terms when an atom appears twice in a
+    neighbour list (periodic self images) — a reference bug that is not reproduced."""
+    g = load(name)
+    rows = load(name.replace("g5_", "g6_rows_"))
+    lmax, nmax, eta, rc = int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"])
+    Pm, nnm = orc.inducing_descriptors(lmax, nmax, rc, g["species"], g["ind_z"], g["ind_ptr"], g["ind_nbr_z"], g["ind_nbr_r"])
+    Ke, Kf, Kv = orc.kernel_rows(lmax, nmax, rc, eta, g["species"], g["numbers"], g["positions"], g["cell"],
+                                 (g["nl_ptr"], g["nl_j"], g["nl_off"]), g["ind_z"], nnm, Pm)
+    np.testing.assert_allclose(Ke, rows["Ke"], rtol=1e-11, atol=1e-13)
+    assert np.abs(Kf - rows["Kf"]).max() <= 2e-6 * np.abs(rows["Kf"]).max()
+    assert np.abs(Kv - rows["Kv"]).max() <= 2e-6 * np.abs(rows["Kv"]).max()
