@@ -38,6 +38,11 @@ SIGNATURES = {
     "sgpr_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_make_vscale": (C.c_int, [_vp, _vp]),
     "sgpr_kernel_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgpr_kernel_columns": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "sgpr_add_inducing": (C.c_int, [_vp, _i32, C.c_int, _vp, _vp]),
+    "sgpr_remove_inducing": (C.c_int, [_vp, C.c_int]),
+    "sgpr_select_inducing": (C.c_int, [_vp, C.c_int, _vp]),
+    "sgpr_kernel_local": (C.c_int, [_vp, _i32, C.c_int, _vp, _vp, _vp, _vp]),
     "sgpr_compute": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "sgpr_bind_system": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
     "sgpr_packed_len": (_i64, [C.c_int]),

@@ -110,3 +110,21 @@ class Calculator:
             self.results = {}
             self.calculate(atoms, [name], all_changes)
         return self.results[name]
+
+
+class SinglePointCalculator(Calculator):
+    """ase.calculators.singlepoint.SinglePointCalculator: stored results for one configuration."""
+    implemented_properties = ["energy", "forces", "stress", "free_energy"]
+
+    def __init__(self, atoms, **results):
+        Calculator.__init__(self)
+        self.atoms = atoms.copy()
+        self.results = {k: (np.array(v, float) if k != "energy" else float(v)) for k, v in results.items()
+                        if v is not None}
+
+    def get_property(self, name, atoms=None):
+        if name not in self.results:
+            raise NotImplementedError(f"SinglePointCalculator holds no {name}")
+        if atoms is not None and self._changed(atoms):
+            raise RuntimeError("SinglePointCalculator: the atoms have changed since the stored calculation")
+        return self.results[name]

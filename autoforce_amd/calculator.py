@@ -1,31 +1,42 @@
-"""ActiveCalculator — the reference's ASE-calculator surface for the SGPR predict hot path,
-backed by libsgpr_hip (MI355X).  Mirrors theforce/calculator/active.py:104-135 (constructor
-keywords), :425-535 (calculate / post_calculate), :548-611 (results), :770-804 (gather, covloss).
+"""ActiveCalculator — the reference's ASE-calculator surface for the SGPR path, backed by
+libsgpr_hip (MI355X).  Mirrors theforce/calculator/active.py:
 
-Scope: prediction (calculator=None in the reference's terms): energy, forces,
-stress, covloss, per-step log line, sharding over a torch.distributed process group.  The
-on-the-fly training loop (teacher calls, data/inducing acceptance tests) is a "next" row and
-raises NotImplementedError when a teacher `calculator` is passed.
+  :104-135   constructor keywords               :425-535   calculate / post_calculate
+  :548-611   results (E, F, stress)             :612-640   initiate_model / get_unique_lces
+  :642-676   sample_rand_lces                   :706-768   _exact / snapshot / head
+  :781-804   covloss                            :806-839   update_lce
+  :841-885   update_inducing                    :887-933   update_data
+  :942-984   update                             :989-1053  include_data / include_tape
+  :1055-1098 build
 
-Works with real ASE when installed (subclasses ase.calculators.calculator.Calculator); otherwise
-with the minimal shim in autoforce_amd.ase_shim.
+All numerics (neighbour list, descriptors, K_nm, forces, covloss, training rows, K_mm edits,
+Cholesky/QR) run on the device through `SGPRModel`; this file is the control flow and the
+acceptance thresholds.  With `calculator=None` it is a pure evaluator; with a teacher
+(`calculator=` any ASE-style calculator giving energy/forces/stress) it learns on the fly.
+
+Works with real ASE when installed; otherwise with the minimal shim in autoforce_amd.ase_shim.
 """
 import datetime
+import os
 import time
 
 import numpy as np
 
 try:  # pragma: no cover - ASE is absent from the build image
     from ase.calculators.calculator import Calculator, all_changes
-    from ase.units import kcal, mol
+    from ase.calculators.singlepoint import SinglePointCalculator
+    from ase.units import GPa, kcal, mol
     kcal_mol = kcal / mol
     HAVE_ASE = True
 except ImportError:
-    from .ase_shim import Calculator, all_changes, kcal_mol
+    from .ase_shim import Calculator, SinglePointCalculator, all_changes, kcal_mol
+    GPa = 1.0 / 160.21766208
     HAVE_ASE = False
 
-from .model import SGPRModel
-from .sharding import pack_partial, unpack_total
+from .model import Local, SGPRModel
+from .posterior import EPS, Frame, PosteriorPotential
+from .sgprio import SgprIO
+from .sharding import pack_partial, rank_of_atoms, unpack_total
 
 inf = float("inf")
 
@@ -37,8 +48,42 @@ def default_kernel(lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, device=
     return SGPRModel(lmax, nmax, exponent, cutoff, species=species, device=device)
 
 
+class Switch:
+    """active.py:82-101: a threshold that depends on the largest force of the frame:
+    Switch([v0, s1, v1, s2, v2]) is v0 below s1, v1 between s1 and s2, v2 above."""
+
+    def __init__(self, value):
+        self._value = value
+        seq = list(value) if hasattr(value, "__iter__") else [value]
+        self.switches = (-inf, *seq[1::2], inf)
+        self.values = seq[0::2]
+        if any(a > b for a, b in zip(self.switches, self.switches[1:])):
+            raise RuntimeError("Switch is not ordered!")
+
+    def __repr__(self):
+        return f"{self._value}"
+
+    def __call__(self, x):
+        k = 0
+        for k, (lo, hi) in enumerate(zip(self.switches, self.switches[1:])):
+            if lo < x < hi:
+                break
+        return self.values[k]
+
+
+def _switched(name):
+    def get(self):
+        return getattr(self, "_" + name)(self.maximum_force)
+
+    def put(self, value):
+        setattr(self, "_" + name, value if isinstance(value, Switch) else Switch(value))
+
+    return property(get, put)
+
+
 class ActiveCalculator(Calculator):
     implemented_properties = ["energy", "forces", "stress", "free_energy"]
+    ediff, ediff_lb, ediff_ub, fdiff = (_switched(n) for n in ("ediff", "ediff_lb", "ediff_ub", "fdiff"))
 
     def __init__(self, covariance=None, calculator=None, process_group=None, meta=None, logfile="active.log",
                  pckl=None, tape=None, test=None, stdout=False, ediff=2 * kcal_mol, ediff_lb=None, ediff_ub=None,
@@ -46,57 +91,85 @@ class ActiveCalculator(Calculator):
                  max_inducing=inf, kernel_kw=None, veto=None, include_params=None, eps_dr=0.1, ignore=None,
                  report_timings=False, step0_forced_fp=False, nbeads=1, engine=None):
         """
-        covariance:    SGPRModel | path to a model .npz (autoforce_amd.modelio) | None (+ kernel_kw
-                       with a `species` entry -> empty default kernel)
-        calculator:    must be None (prediction only; the active-learning loop is not built yet)
+        covariance:    SGPRModel | PosteriorPotential | path to a saved model (.npz,
+                       autoforce_amd.modelio) | None (+ kernel_kw with a `species` entry -> empty model)
+        calculator:    None (evaluate only) | teacher: any ASE-style calculator (energy/forces/stress)
         process_group: None | torch.distributed process group over which atoms are sharded
-        engine:        test hook — any object with predict(numbers, positions, cell, pbc, rank, world,
-                       cov, beta) and attributes m, species; defaults to the HIP-backed model
-        The remaining keywords are accepted for signature compatibility with the reference.
+        pckl:          None | path of the .npz the model is saved to after every update
+        tape:          None | path of the .sgpr tape that accepted data / LCEs are appended to
+        engine:        test hook — an object with SGPRModel's methods
+        The remaining keywords have the reference's meaning (active.py:137-287).
         """
         Calculator.__init__(self)
-        if calculator is not None:
-            raise NotImplementedError(
-                "on-the-fly learning with a teacher calculator is outside this build's scope (SURVEY.md §8f); "
-                "pass calculator=None and a trained model")
-        self._calc = None
+        self._calc = calculator
         self.process_group = process_group
-        if engine is not None:
-            self.model = engine
-        elif isinstance(covariance, SGPRModel):
-            self.model = covariance
-        elif isinstance(covariance, str):
-            from .modelio import load_model
-            self.model = load_model(covariance)
-        else:
-            kw = dict(kernel_kw or {})
-            if not kw.get("species"):
-                raise ValueError("kernel_kw={'species': [...]} is required to build an empty model")
-            self.model = default_kernel(**kw)
+        self.pckl = pckl
+        self.maximum_force = inf
+        self.logfile, self.stdout, self._logpref = logfile, stdout, ""
+        self.step = 0
+        self.get_model(engine if engine is not None else covariance, kernel_kw or {})
         self.ediff = ediff
         self.ediff_lb = ediff_lb or ediff
         self.ediff_ub = ediff_ub or ediff
         self.ediff_tot, self.fdiff, self.noise_f = ediff_tot, fdiff, noise_f
-        self.logfile, self.stdout = logfile, stdout
-        self.report_timings = report_timings
-        self.step = 0
-        self.deltas = None
-        self.updated = False
-        self.covlog = ""
-        self.cov = None
-        self.maximum_force = inf
+        self.ioptim, self._ioptim = ioptim, 0
+        self.max_data, self.max_inducing = max_data, max_inducing
         self.meta = meta
         self.log("active calculator says Hello!", mode="w")
+        self.log_settings()
         self.log("model size: {} {}".format(*self.size))
+        self.tape = None if tape is None else SgprIO(tape, rank=self.rank)
+        self.test, self._last_test, self._ktest = test, 0, 0
+        self.updated = False
+        self._update_args = {}
+        self._veto = {} if veto is None else dict(veto)
+        self.include_params = {"fmax": inf}
+        self.include_params.update(include_params or {})
+        self.tune_for_md = True
+        self.eps_dr = eps_dr
+        self.ignore = [] if ignore is None else list(ignore)
+        self.report_timings = report_timings
+        self.step0_forced_fp = step0_forced_fp
+        self.nbeads = nbeads
+        self.deltas, self.covlog, self.cov = None, "", None
+        self.blind = False
+        self._saved_for_tape = None
+        self._beta = None
+        self._nl = None
+        if self.nbeads > 1:
+            self.log(f"You are going quantum (PIMD)! Number of beads: {self.nbeads}")
 
-    # ------------------------------------------------------------------ properties of the surface
+    # ------------------------------------------------------------------ model plumbing
+    def get_model(self, model, kernel_kw):
+        """active.py:338-362."""
+        if isinstance(model, str):
+            from .modelio import load_model
+            model = load_model(model)
+        elif model is None:
+            if self.pckl and os.path.isfile(self.pckl):
+                from .modelio import load_model
+                model = load_model(self.pckl)
+            else:
+                kw = dict(kernel_kw)
+                if not kw.get("species"):
+                    raise ValueError("kernel_kw={'species': [...]} is required to build an empty model")
+                model = default_kernel(**kw)
+        if not isinstance(model, PosteriorPotential):
+            model = PosteriorPotential(model)
+        model._sync = self._broadcast if self.process_group is not None else None
+        self.model = model
+
+    @property
+    def engine(self):
+        return self.model.engine
+
     @property
     def active(self):
         return self._calc is not None
 
     @property
     def size(self):
-        return 0, self.model.m  # (n_data, n_inducing), calculator/active.py:375-376
+        return self.model.ndata, len(self.model.X)  # active.py:375-376
 
     @property
     def rank(self):
@@ -112,61 +185,494 @@ class ActiveCalculator(Calculator):
         import torch.distributed as dist
         return dist.get_rank(self.process_group), dist.get_world_size(self.process_group)
 
+    def _tensor(self, a):
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        return t.cuda() if dist.get_backend(self.process_group) == "nccl" else t
+
+    def _broadcast(self, arrays):
+        """rank 0's mu / choli / ridge / mean weights become everyone's (gppotential.py:592-596)."""
+        import torch.distributed as dist
+        for a in arrays:
+            t = self._tensor(a)
+            dist.broadcast(t, 0, group=self.process_group)
+            a[...] = t.cpu().numpy()
+
     # ------------------------------------------------------------------ the hot path
-    def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
-        timings = [time.time()]
-        if self.size[1] == 0 and not self.active:
-            raise RuntimeError("you forgot to assign a DFT calculator!")  # calculator/active.py:429-430
-        Calculator.calculate(self, atoms, properties, system_changes)
-        a = self.atoms
-        numbers = np.asarray(a.numbers, dtype=np.int32)
-        positions = np.asarray(a.positions, dtype=float)
-        cell = np.asarray(getattr(a.cell, "array", a.cell), dtype=float).reshape(3, 3)
-        pbc = np.asarray(a.pbc, dtype=bool)
+    def _system(self, atoms):
+        cell = np.asarray(getattr(atoms.cell, "array", atoms.cell), dtype=float).reshape(3, 3)
+        return (np.asarray(atoms.numbers, dtype=np.int32), np.asarray(atoms.positions, dtype=float), cell,
+                np.asarray(atoms.pbc, dtype=bool))
+
+    def update_results(self, retain_graph=False, covloss_only=False):
+        """active.py:548-611 + :781-804 in one device pass: E, F, stress, covloss, cov.
+        covloss_only: refresh `cov` and the covloss after the model changed but leave `results`
+        alone — inside update_inducing the reference extends cov by a column and keeps the
+        pre-update predictions, which update_data then offers as 'fake' labels."""
+        numbers, positions, cell, pbc = self._system(self.atoms)
         N = len(numbers)
         rank, world = self._dist()
-        out = self.model.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=True, beta=True)
-        timings.append(time.time())
-        self.cov = out["cov"]
-        if world > 1:
-            import torch
-            import torch.distributed as dist
-            v = torch.from_numpy(pack_partial(out, N))
-            backend = dist.get_backend(self.process_group)
-            if backend == "nccl":
-                v = v.cuda()
-            dist.all_reduce(v, group=self.process_group)  # active.py:562,601,602,777 in one collective
-            out = unpack_total(v.cpu().numpy(), N)
+        ready = self.engine.m > 0 and self.engine.mu is not None
+        if not ready:
+            # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
+            out = dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf),
+                       cov=np.zeros((N, 0)))
+        else:
+            out = self.engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=True, beta=True)
+            self.cov = out["cov"]
+            if world > 1:
+                import torch.distributed as dist
+                v = self._tensor(pack_partial(out, N))
+                dist.all_reduce(v, group=self.process_group)  # active.py:562,601,602,777 in one collective
+                out = unpack_total(v.cpu().numpy(), N)
+        self._nl = None
+        self._beta = out["beta"]
+        if covloss_only:
+            return
         self.results["energy"] = np.asarray(out["energy"])
         self.results["forces"] = np.asarray(out["forces"])
         self.results["stress"] = np.asarray(out["stress"])
-        self.results["free_energy"] = self.results["energy"]  # calculator/active.py:527
         self.maximum_force = float(np.abs(self.results["forces"]).max()) if N else 0.0
-        self._beta = out["beta"]
+
+    def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
+        timings = [time.time()]
+        if self.size[1] == 0 and not self.active:
+            raise RuntimeError("you forgot to assign a DFT calculator!")  # active.py:429-430
+        Calculator.calculate(self, atoms, properties, system_changes)
+        self.maximum_force = inf
         timings.append(time.time())
-        # inactive branch of calculator/active.py:492-499
-        covloss_max = float(np.max(self._beta)) if N else 0.0
-        self.covlog = f"{covloss_max}"
+        if self.step == 0 and self.active and self.model.ndata == 0:
+            self.initiate_model()
+            self._update_args = dict(data=False)
+        timings.append(time.time())
+        self.update_results(self.active or (self.meta is not None))
+        timings.append(time.time())
         self.deltas = None
+        self.covlog = ""
+        if self.active and not self.veto():
+            if (self.step + 1) % self.nbeads == 1 or self.nbeads == 1:  # PIMD: only the first bead samples
+                pre = dict(self.results)
+                m, n = self.update(**self._update_args)
+                if n > 0 or m > 0:
+                    self.update_results(self.meta is not None)
+                    if self.step > 0:
+                        self.deltas = {q: self.results[q] - pre[q] for q in ("energy", "forces", "stress")}
+        else:
+            covloss_max = float(np.max(self.get_covloss())) if len(self.atoms) else 0.0
+            self.covlog = f"{covloss_max}"
+            if covloss_max > self.ediff and HAVE_ASE and self.rank == 0:  # pragma: no cover
+                import ase.io
+                tmp = self.atoms.copy()
+                tmp.calc = None
+                ase.io.Trajectory("active_uncertain.traj", "a").write(tmp)
         timings.append(time.time())
+        self.post_calculate(timings)
+
+    def post_calculate(self, timings):
+        """active.py:504-535."""
+        energy = self.results["energy"]
+        if self.active and self.test and self.step - self._last_test > self.test:
+            self._test()
+        meta = ""
+        if self.meta is not None:
+            energies, kwargs = self.meta(self)
+            if energies is not None:
+                meta = f"meta: {float(np.sum(energies))}"
         try:
-            temperature = a.get_temperature()
+            temperature = self.atoms.get_temperature()
         except Exception:
             temperature = 0.0
-        self.log("{} {} {} {}".format(float(self.results["energy"]), temperature, self.covlog, ""))
+        self.log("{} {} {} {}".format(float(energy), temperature, self.covlog, meta))
         self.step += 1
+        self.results["free_energy"] = self.results["energy"]  # active.py:527
+        timings.append(time.time())
         if self.report_timings:
             d = np.diff(timings)
             self.log(("timings:" + len(d) * " {:0.2g}").format(*d) + f" total: {d.sum():0.2g}")
 
+    def veto(self):
+        """active.py:537-546."""
+        if self.size[0] < 2 or "forces" not in self._veto:
+            return False
+        if np.abs(self.results["forces"]).max() >= self._veto["forces"]:
+            self.log("an update is vetoed!")
+            return True
+        return False
+
     def get_covloss(self):
-        """calculator/active.py:781-804 for the last calculated frame."""
+        """active.py:781-804 for the last evaluated frame (computed with it on the device)."""
         return self._beta
 
-    # ------------------------------------------------------------------ logging (active.py:1129-1134)
+    # ------------------------------------------------------------------ LCEs of the current frame
+    def _neighbors(self):
+        if self._nl is None:
+            self._nl = self.engine.neighbors(len(self.atoms))
+        return self._nl
+
+    def _local_here(self, k, system=None):
+        numbers, positions, cell, _ = system or self._system(self.atoms)
+        ptr, j, off = self._neighbors()
+        a, b = int(ptr[k]), int(ptr[k + 1])
+        r = positions[j[a:b]] - positions[k] + off[a:b].astype(float) @ cell  # descriptor/atoms.py:367-368
+        return Local(int(numbers[k]), numbers[j[a:b]], r)
+
+    def local(self, k):
+        """atoms.local(k, detach=True) (descriptor/atoms.py:365-382); in a sharded run the owner of
+        atom k hands the LCE to everyone."""
+        rank, world = self._dist()
+        if world == 1:
+            return self._local_here(k)
+        import torch.distributed as dist
+        owner = int(rank_of_atoms(self.atoms.numbers, self.engine.species, world)[k])
+        box = [self._local_here(k) if rank == owner else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.process_group, owner), group=self.process_group)
+        return box[0]
+
+    def _locals_of(self, numbers, positions, cell, pbc, indices=None):
+        """LCEs of an arbitrary configuration (device neighbour list, unsharded)."""
+        N = len(numbers)
+        self.engine.predict(numbers, positions, cell, pbc, cov=False, beta=False)
+        self._nl = self.engine.neighbors(N)
+        sysm = (numbers, positions, cell, pbc)
+        out = [self._local_here(k, sysm) for k in (range(N) if indices is None else indices)]
+        self._nl = None
+        return out
+
+    # ------------------------------------------------------------------ teacher calls
+    def _exact(self, atoms):
+        """active.py:706-738: one teacher (ab initio) calculation."""
+        tmp = atoms.copy()
+        tmp.calc = self._calc
+        energy = tmp.get_potential_energy()
+        forces = tmp.get_forces()
+        stress = tmp.get_stress()
+        self.log("exact energy: {}".format(energy))
+        self.log("exact stress[GPa]: {}  {}  {}".format(*(stress[:3] / GPa)))
+        if self.model.ndata > 0 and "energy" in self.results:
+            dE = self.results["energy"] - energy
+            df = np.abs(self.results["forces"] - forces)
+            self.log("predicted stress[GPa]: {}  {}  {}".format(*(self.results["stress"][:3] / GPa)))
+            self.log("errors (pre):  del-E: {:.2g}  max|del-F|: {:.2g}  mean|del-F|: {:.2g}".format(
+                float(dE), df.max(), df.mean()))
+        self._last_test = self.step
+        return energy, forces, stress
+
+    def snapshot(self, fake=False, atoms=None):
+        """active.py:740-751: the current frame with exact (teacher) or fake (own prediction) labels."""
+        atoms = self.atoms if atoms is None else atoms
+        if fake:
+            e, f, s = self.results["energy"], self.results["forces"], self.results["stress"]
+        else:
+            e, f, s = self._exact(atoms)
+        fr = Frame.from_atoms(atoms, e, f, s)
+        if not fake and self.tape:
+            self._saved_for_tape = fr
+        return fr
+
+    def head(self):
+        """active.py:753-762: replace the fake labels of the newest datum by exact ones."""
+        e, f, s = self._exact(self._as_atoms(self.model.data[-1]))
+        self.model.refresh_targets(-1, e, f, s)
+        if self.tape:
+            self._saved_for_tape = self.model.data[-1]
+
+    def _test(self):
+        """active.py:678-704 (the trajectory files need ASE; the log line does not)."""
+        energy, forces, stress = self._exact(self.atoms)
+        self._ktest += 1
+        self.log("testing energy: {}".format(energy))
+        dE = self.results["energy"] - energy
+        df = np.abs(self.results["forces"] - forces)
+        ds = np.abs(self.results["stress"] - stress)
+        self.log("errors (test):  del-E: {:.2g}  max|del-F|: {:.2g}  mean|del-F|: {:.2g} mean|del-P|: {:.2g}".format(
+            float(dE), df.max(), df.mean(), np.mean(ds[:3])))
+        self._last_test = self.step
+        return energy, forces
+
+    # ------------------------------------------------------------------ seeding
+    def initiate_model(self):
+        """active.py:612-629."""
+        data = [self.snapshot()]
+        idx = self.get_unique_lces()
+        system = self._system(self.atoms)
+        inducing = self._locals_of(*system, indices=idx)
+        self.model.set_data(data, inducing)
+        if self.tape:
+            if self._saved_for_tape is not None:
+                self.tape.write(self._saved_for_tape)
+                self._saved_for_tape = None
+            for loc in inducing:
+                self.tape.write(loc)
+        details = [(int(j), int(self.atoms.numbers[j])) for j in idx]
+        self.log("seed size: {} {} details: {}".format(*self.size, details))
+        if self.tune_for_md:
+            self.sample_rand_lces(indices=idx, repeat=1)
+        self.optimize()
+
+    def get_unique_lces(self, thresh=0.95):
+        """active.py:631-654: greedy cover — atom i is kept unless k(i, j) >= thresh for a kept j.
+        k(atoms, atoms) is K_mm of the frame's own LCEs, one device GEMM."""
+        system = self._system(self.atoms)
+        locs = self._locals_of(*system)
+        scratch = self.engine.scratch()
+        scratch.set_inducing(locs)
+        k = scratch.M
+        scratch.close()
+        unique = []
+        for i in range(len(locs)):
+            if all(k[i, j] < thresh for j in unique):
+                unique.append(i)
+        return unique
+
+    def sample_rand_lces(self, indices=None, repeat=1):
+        """active.py:656-676: LCEs of a slightly rattled copy, offered to update_lce."""
+        added = 0
+        numbers, positions, cell, pbc = self._system(self.atoms)
+        for _ in range(repeat):
+            rattled = positions + np.random.uniform(-0.05, 0.05, size=positions.shape)
+            order = np.random.permutation(len(numbers)) if indices is None else indices
+            for loc in self._locals_of(numbers, rattled, cell, pbc, indices=order):
+                added += abs(self.update_lce(loc))
+        self.log(f"added {added} randomly displaced LCEs")
+
+    # ------------------------------------------------------------------ the sampling rules
+    def update_lce(self, loc, beta=None):
+        """active.py:806-839."""
+        if loc.number not in self.engine.species:
+            return 0
+        if beta is None:
+            if self.engine.m > 0 and self.model.choli is not None:
+                k, _ = self.engine.kernel_local(loc)
+                b = self.model.choli @ k
+                vscale = self.model._vscale.get(loc.number, inf)
+                with np.errstate(invalid="ignore"):
+                    beta = np.sqrt(np.maximum((1.0 - b @ b) * vscale, 0.0))
+            else:
+                beta = inf
+        added = 0
+        m = self.model.indu_counts[loc.number]
+        if beta >= self.ediff_ub:
+            self.model.add_inducing(loc)
+            added = -1 if m < 2 else 1
+        elif beta < self.ediff_lb:
+            if m < 2 and beta > EPS:
+                self.model.add_inducing(loc)
+                added = -1
+        else:
+            ediff = self.ediff if m > 1 else EPS
+            added, _ = self.model.add_1inducing(loc, ediff)
+        if added != 0:
+            if self.model.ridge > 0.0:
+                self.model.pop_1inducing()
+                added = 0
+            else:
+                if self.tape:
+                    self.tape.write(loc)
+                if self.ioptim == 0:
+                    self.optimize()
+        return added
+
+    def update_inducing(self):
+        """active.py:841-885: greedy — offer the atom with the largest covloss until one is refused."""
+        added_beta = added_diff = 0
+        chosen = []
+        added_covloss = None
+        N = len(self.atoms)
+        while len(chosen) < N:
+            beta = self.get_covloss()
+            order = np.argsort(-beta, kind="stable")
+            k = next((int(i) for i in order if int(i) not in chosen and int(i) not in self.ignore), int(order[-1]))
+            if np.isclose(beta[k], 1.0):
+                self.blind = True
+            loc = self.local(k)
+            added = self.update_lce(loc, beta=beta[k])
+            if added == 0:
+                break
+            if added == -1:
+                self.blind = True
+                added_beta += 1
+            else:
+                added_diff += 1
+            chosen.append(k)
+            added_covloss = beta[k]
+            self.update_results(covloss_only=True)  # cov gains a column, choli changed: every covloss moves
+        added = added_beta + added_diff
+        if added > 0:
+            self.log("added indu: {} ({},{}) -> size: {} {} details: {:.2g} {}".format(
+                added, added_beta, added_diff, *self.size, float(added_covloss), ""))
+            if self.blind:
+                self.log("model may be blind -> go robust")
+        self.covlog = f"{float(np.max(self.get_covloss()))}"
+        return added
+
+    def update_data(self, try_fake=True, internal=False, save_model=True):
+        """active.py:887-933."""
+        if self.tune_for_md and len(self.model.data) > 2:
+            last = self.model.data[-1]
+            if last.natoms == len(self.atoms) and (last.numbers == self.atoms.numbers).all() and \
+                    (np.abs(last.positions - self.atoms.positions) < self.eps_dr).all():
+                return 0
+        n = self.model.ndata
+        new = self.snapshot(fake=try_fake)
+        _, de, df = self.model.add_1atoms_fast(new, self.ediff_tot, self.fdiff)
+        added = self.model.ndata - n
+        self.log(f"DF: {df}  accept: {added}")
+        if added > 0:
+            if try_fake:
+                self.head()
+            if self.tape and self._saved_for_tape is not None:
+                self.tape.write(self._saved_for_tape)
+                self._saved_for_tape = None
+            self.log("added data: {} -> size: {} {}".format(added, *self.size))
+            if self.ioptim in (0, 2):
+                self.optimize()
+            elif self.ioptim > 2:
+                self._ioptim += 1
+                if self._ioptim % (self.ioptim - 1) == 0:
+                    self.optimize()
+                    self._ioptim = 0
+            if save_model:
+                self.save_model()
+        return added
+
+    def optimize(self):
+        self.model.make_munu(algo=3, noise_f=self.noise_f)  # active.py:939-940
+
+    def update(self, inducing=True, data=True):
+        """active.py:942-984."""
+        self.updated = False
+        self.blind = False
+        m = self.update_inducing() if inducing else 0
+        try_real = self.blind or isinstance(self._calc, SinglePointCalculator)
+        update_data = (m > 0 and data) or not inducing
+        if update_data and not inducing:  # include_tape
+            update_data = np.max(self.get_covloss()) > self.ediff
+        n = self.update_data(try_fake=not try_real, internal=True, save_model=False) if update_data else 0
+        if self.step == 0 and self.step0_forced_fp and data and n == 0:
+            self.log("forced data addition")
+            self.model.add_data([self.snapshot()])
+            self.log("added data: {} -> size: {} {}".format(1, *self.size))
+            n = 1
+        if m > 0 or n > 0:
+            ch1, ch2 = self.model.downsize(self.max_data, self.max_inducing, first=True, lii=True)
+            if ch1 or ch2:
+                self.log("downsized -> size: {} {}".format(*self.size))
+            if self.ioptim == 1:
+                self.optimize()
+            self.log("fit error (mean,mae): E: {:.2g} {:.2g}   F: {:.2g} {:.2g}   R2: {:.4g}".format(
+                *(float(v) for v in self.model._stats)))
+            self.log(f"noise: {self.model.scaled_noise}")
+            self.log(f"mean: {self.model.mean}")
+            self.save_model()
+            self.updated = True
+        self._update_args = {}
+        return m, n
+
+    def save_model(self):
+        if self.pckl and self.rank == 0:
+            from .modelio import save_model
+            save_model(self.pckl, self.model)
+
+    # ------------------------------------------------------------------ training from stored data
+    def _as_atoms(self, fr):
+        if HAVE_ASE:  # pragma: no cover
+            from ase import Atoms
+            return Atoms(numbers=fr.numbers, positions=fr.positions, cell=fr.cell, pbc=fr.pbc)
+        from .ase_shim import Atoms
+        return Atoms(fr.numbers, fr.positions, fr.cell, fr.pbc)
+
+    def _learn_from(self, atoms, calc):
+        saved = self._calc
+        self._calc = calc
+        try:
+            atoms.calc = self
+            atoms.get_potential_energy()
+        finally:
+            atoms.calc = calc
+            self._calc = saved
+
+    def include_data(self, data):
+        """active.py:989-1004: `data` = labelled frames (Frame objects, or atoms whose .calc holds
+        energy/forces/stress); each one is offered to the learner as if met during MD."""
+        for item in data:
+            if isinstance(item, Frame):
+                atoms = self._as_atoms(item)
+                calc = SinglePointCalculator(atoms, energy=item.energy, forces=item.forces, stress=item.stress)
+            else:
+                atoms, calc = item, item.calc
+            atoms.calc = calc
+            if np.abs(atoms.get_forces()).max() > self.include_params["fmax"]:
+                continue
+            self._learn_from(atoms, calc)
+
+    def include_tape(self, tape, ndata=None):
+        """active.py:1006-1053: replay another run's tape — its LCEs through update_lce, its frames
+        through the data-acceptance test (inducing=False)."""
+        if isinstance(tape, str):
+            if self.tape is not None and os.path.abspath(tape) == self.tape.path:
+                raise RuntimeError("ActiveCalculator can not include it own .sgpr tape!")
+            tape = SgprIO(tape, rank=self.rank)
+        tune_for_md, self.tune_for_md = self.tune_for_md, False
+        added_lce = [0, 0]
+
+        def _save():
+            if added_lce[0] > 0:
+                if self.ioptim == 1:
+                    self.optimize()
+                self.save_model()
+                self.log("added lone indus: {}/{} -> size: {} {}".format(*added_lce, *self.size))
+                self.log("fit error (mean,mae): E: {:.2g} {:.2g}   F: {:.2g} {:.2g}   R2: {:.4g}".format(
+                    *(float(v) for v in self.model._stats)))
+
+        cdata = 0
+        try:
+            for cls, obj in tape.read(exclude=self.tape):
+                if cls == "atoms":
+                    if np.abs(obj.forces).max() > self.include_params["fmax"] and len(self.model.data) > 0:
+                        continue
+                    _save()
+                    self._update_args = dict(inducing=False)
+                    atoms = self._as_atoms(obj)
+                    self._learn_from(atoms, SinglePointCalculator(atoms, energy=obj.energy, forces=obj.forces,
+                                                                  stress=obj.stress))
+                    cdata += 1
+                    if ndata and cdata >= ndata:
+                        break
+                    added_lce = [0, 0]
+                elif cls == "local":
+                    added_lce[0] += abs(self.update_lce(obj))
+                    added_lce[1] += 1
+            _save()
+        finally:
+            self.tune_for_md = tune_for_md
+
+    def build(self):
+        """active.py:1055-1098: rebuild the model from this calculator's own tape in one shot."""
+        if self.pckl and os.path.exists(self.pckl):
+            raise RuntimeError(f"{self.pckl} already exists and can not be overwritten by build!"
+                               " remove this file and try again.")
+        blocks = self.tape.read()
+        data = [obj for cls, obj in blocks if cls == "atoms"]
+        lce = [obj for cls, obj in blocks if cls == "local"]
+        self.model.set_data(data, lce)
+        self.optimize()
+        self.log("built from tape {} {} -> size: {} {}".format(len(data), len(lce), *self.size))
+        self.log("fit error (mean,mae): E: {:.2g} {:.2g}   F: {:.2g} {:.2g}   R2: {:.4g}".format(
+            *(float(v) for v in self.model._stats)))
+        self.save_model()
+
+    # ------------------------------------------------------------------ logging (active.py:1117-1134)
+    def log_settings(self):
+        self.log(f"kernel: lmax={self.engine.lmax} nmax={self.engine.nmax} exponent={self.engine.exponent} "
+                 f"cutoff={self.engine.cutoff} species={list(self.engine.species)}")
+        self.log(f"ediff: {self._ediff}  ediff_lb: {self._ediff_lb}  ediff_ub: {self._ediff_ub}  "
+                 f"ediff_tot: {self.ediff_tot}  fdiff: {self._fdiff}  noise_f: {self.noise_f}  ioptim: {self.ioptim}")
+
     def log(self, mssge, mode="a"):
         if self.logfile and self.rank == 0:
             with open(self.logfile, mode) as f:
-                f.write("{} {} {}\n".format(datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"), self.step, mssge))
+                f.write("{}{} {} {}\n".format(self._logpref, datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"),
+                                              self.step, mssge))
         if self.stdout and self.rank == 0:
             print(mssge)

@@ -71,6 +71,9 @@ struct sgpr_model {
     DevBuf<double> d_radii;
     // inducing set (device arrays in species-sorted order)
     int m = 0, m_pad = 0, m_rows = 0;
+    std::vector<int32_t> env_zc, env_z;  // the caller's LCE list (caller order), kept for add/remove/select
+    std::vector<int64_t> env_ptr;
+    std::vector<double> env_r;
     std::vector<int> ind_perm;  // sorted -> caller
     std::vector<int> ind_slot;  // sorted
     std::vector<int> qoff;      // [S+1]
@@ -503,6 +506,14 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
         ptr[k + 1] = (int64_t)eslot.size();
     }
     for (int s = 0; s < h->S; s++) h->qoff[s + 1] += h->qoff[s];
+    {   // keep the caller's list for the edit entry points (copy first: the inputs may alias h->env_*)
+        const int64_t lo = m > 0 ? nbr_ptr[0] : 0, hi = m > 0 ? nbr_ptr[m] : 0;
+        std::vector<int32_t> ezc(zc, zc + m), ez(nbr_z + lo, nbr_z + hi);
+        std::vector<double> evr(nbr_r + 3 * lo, nbr_r + 3 * hi);
+        std::vector<int64_t> eptr(m + 1, 0);
+        for (int q = 0; q < m; q++) eptr[q + 1] = nbr_ptr[q + 1] - lo;
+        h->env_zc.swap(ezc); h->env_z.swap(ez); h->env_ptr.swap(eptr); h->env_r.swap(evr);
+    }
     if (h->d_ind_slot.alloc(h->m_rows) || h->d_ind_nn.alloc(h->m_rows) || h->d_qoff.alloc(h->S + 1) ||
         h->d_Pm.alloc((size_t)h->m_rows * h->Dpad) || h->d_PmT.alloc((size_t)rup(h->Dpad, 64) * h->m_pad) ||
         h->d_pm_norm.alloc(h->m_rows) || h->d_M.alloc((size_t)h->m_rows * h->m_pad) || h->d_mu.alloc(std::max(h->m_pad, h->m_rows)) ||

@@ -71,6 +71,12 @@ class SGPRModel:
     def handle(self):
         return self._h
 
+    def scratch(self):
+        """A second, empty model with the same kernel on the same device (used for one-off
+        K(atoms, atoms) evaluations that must not disturb this model's inducing set)."""
+        return SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=self.species, radii=self.radii,
+                         device=self.device)
+
     # ------------------------------------------------------------------ inducing set
     def set_inducing(self, X):
         """model.X = inducing LCEs; builds descriptors and K_mm on the device
@@ -84,6 +90,38 @@ class SGPRModel:
         check(_lib.load().sgpr_set_inducing(self._h, m, ptr(zc), ptr(nptr), ptr(nz), ptr(nr)))
         self.mu = None
         self.choli = None
+
+    def _weights_dropped(self):
+        self.mu = None
+        self.choli = None
+
+    def add_inducing(self, loc):
+        """Append one LCE (PosteriorPotential.add_inducing, gppotential.py:745-772, without the
+        data columns — those are `kernel_columns`)."""
+        check(_lib.load().sgpr_add_inducing(self._h, loc.number, len(loc._b), ptr(loc._b), ptr(loc._r)))
+        self.X.append(loc)
+        self._weights_dropped()
+
+    def remove_inducing(self, index=-1):
+        """pop_1inducing / popfirst_1inducing (gppotential.py:782-813)."""
+        check(_lib.load().sgpr_remove_inducing(self._h, int(index)))
+        del self.X[index]
+        self._weights_dropped()
+
+    def select_inducing(self, indices):
+        """Keep `indices` in the given order (gppotential.py:1037-1046)."""
+        idx = i32(indices)
+        check(_lib.load().sgpr_select_inducing(self._h, len(idx), ptr(idx)))
+        self.X = [self.X[int(j)] for j in idx]
+        self._weights_dropped()
+
+    def kernel_local(self, loc):
+        """(k(loc, X)[m], k(loc, loc)) for an LCE outside the inducing set (active.py:806-818)."""
+        k = np.zeros(self.m)
+        kxx = C.c_double(0)
+        check(_lib.load().sgpr_kernel_local(self._h, loc.number, len(loc._b), ptr(loc._b), ptr(loc._r), ptr(k),
+                                            C.addressof(kxx)))
+        return k, kxx.value
 
     @property
     def m(self):
@@ -150,6 +188,19 @@ class SGPRModel:
         Ke, Kf, Kv = np.zeros(self.m), np.zeros((3 * N, self.m)), np.zeros((6, self.m))
         check(_lib.load().sgpr_kernel_rows(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), ptr(Ke),
                                            ptr(Kf), ptr(Kv)))
+        return Ke, Kf, Kv
+
+    def kernel_columns(self, numbers, positions, cell, pbc, q_first, q_count):
+        """The same rows restricted to inducing columns [q_first, q_first+q_count): the bordering
+        step of add_inducing (gppotential.py:745-763)."""
+        numbers = i32(numbers)
+        N = len(numbers)
+        positions = f64(positions).reshape(N, 3)
+        cell = f64(np.asarray(cell, float).reshape(3, 3))
+        pbc = i32(np.asarray(pbc, bool).astype(np.int32))
+        Ke, Kf, Kv = np.zeros(q_count), np.zeros((3 * N, q_count)), np.zeros((6, q_count))
+        check(_lib.load().sgpr_kernel_columns(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc),
+                                              int(q_first), int(q_count), ptr(Ke), ptr(Kf), ptr(Kv)))
         return Ke, Kf, Kv
 
     def fit(self, frames, noise=0.01):

@@ -118,6 +118,30 @@ int sgpr_solve(sgpr_model *h, int rows, const double *K, const double *Y, double
 int sgpr_kernel_rows(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
                      const double *cell, const int32_t *pbc, double *Ke, double *Kf, double *Kv);
 
+/* The same for the inducing columns [q_first, q_first + q_count) only: outputs are Ke[q_count],
+ * Kf[3N][q_count], Kv[6][q_count].  This is the bordering step of add_inducing
+ * (gppotential.py:745-772: one new column of K_e, K_f, K_v per data frame). */
+int sgpr_kernel_columns(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
+                        const double *cell, const int32_t *pbc, int q_first, int q_count, double *Ke,
+                        double *Kf, double *Kv);
+
+/*
+ * Inducing-set edits (PosteriorPotential.add_inducing / pop_1inducing / popfirst_1inducing /
+ * select_inducing, gppotential.py:745-842, :1037-1046).  The caller's order is kept: a new LCE is
+ * appended as index m; `remove` deletes one index (-1 = last); `select` keeps `indices` in the
+ * given order.  K_mm and the descriptors are rebuilt on the device; weights are invalidated
+ * (call sgpr_solve / sgpr_set_weights next, as the reference calls make_munu).
+ */
+int sgpr_add_inducing(sgpr_model *h, int32_t zc, int nn, const int32_t *nbr_z, const double *nbr_r);
+int sgpr_remove_inducing(sgpr_model *h, int index);
+int sgpr_select_inducing(sgpr_model *h, int count, const int32_t *indices);
+
+/* k(loc, X)[m] and k(loc, loc) for one LCE that is not (yet) in the inducing set
+ * (gp.kern(loc, X) in ActiveCalculator.update_lce, active.py:806-818, and
+ * PosteriorPotential.leakage, gppotential.py:706-713).  Either output may be NULL. */
+int sgpr_kernel_local(sgpr_model *h, int32_t zc, int nn, const int32_t *nbr_z, const double *nbr_r,
+                      double *k_out, double *kxx_out);
+
 /* vscale[S] = mean_{q: Z_q = z} mu_q (K_mm mu)_q (regression/gppotential.py:644-649);
  * +inf where a species has no inducing point. Installs it in the handle as well. */
 int sgpr_make_vscale(sgpr_model *h, double *vscale_out);

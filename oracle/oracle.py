@@ -223,3 +223,8 @@ def distribute(numbers, world_size, loads=None, total=None):
         loads[z][rank] += 1
         total[rank] += 1
     return np.array(ranks, np.int32), loads, total
+
+
+def set_num_threads(n):
+    """One thread = a fixed summation order in orc_frame (bit-reproducible runs)."""
+    lib().orc_set_num_threads(C.c_int(int(n)))

@@ -698,3 +698,14 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* Tests that compare decision sequences need run-to-run identical sums: with one thread the
+ * dynamic schedule + critical-section merge of orc_frame is a fixed summation order. */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}

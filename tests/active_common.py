@@ -1,0 +1,83 @@
+"""Shared scenario for the on-the-fly learning tests: a small two-species periodic cell that
+random-walks under a smooth pair-potential teacher (tests/helpers.py::PairTeacher)."""
+import os
+
+import numpy as np
+
+from autoforce_amd.ase_shim import Atoms
+from autoforce_amd.calculator import ActiveCalculator
+from helpers import PairTeacher
+
+SPECIES = [3, 9]
+KW = dict(ediff=0.02, ediff_tot=0.05, fdiff=0.05, noise_f=0.02)
+
+
+def start(seed=0):
+    rng = np.random.default_rng(seed)
+    a = 3.0
+    sites = np.array([[i, j, k] for i in range(3) for j in range(3) for k in range(2)], float) * a
+    numbers = np.array([3, 9] * 9)
+    cell = np.diag([3 * a, 3 * a, 2 * a + 3.0])
+    return rng, numbers, sites + 0.1 * rng.normal(size=sites.shape), cell
+
+
+def run(engine, tmp, steps=6, seed=0, tape=True, **kw):
+    """Returns (calc, trace): trace[k] = (size, energy, forces, covlog, deltas is not None)."""
+    np.random.seed(1234)  # sample_rand_lces draws from the global generator, like the reference
+    from oracle import oracle as orc
+    orc.set_num_threads(1)  # fixed summation order in the oracle (teacher neighbour lists, OracleModel)
+    rng, numbers, pos, cell = start(seed)
+    teacher = PairTeacher(rc=4.0)
+    args = dict(KW)
+    args.update(kw)
+    calc = ActiveCalculator(engine=engine, calculator=teacher, logfile=str(tmp / "active.log"),
+                            tape=str(tmp / "model.sgpr") if tape else None, pckl=str(tmp / "model.npz"), **args)
+    trace = []
+    try:
+        for _ in range(steps):
+            pos = pos + 0.06 * rng.normal(size=pos.shape)
+            at = Atoms(numbers, pos, cell, True)
+            at.calc = calc
+            e, f = at.get_potential_energy(), at.get_forces()
+            trace.append((calc.size, e, f.copy(), calc.covlog, calc.deltas is not None, at))
+    finally:
+        orc.set_num_threads(os.cpu_count() or 1)
+    return calc, teacher, trace
+
+
+def check_g8_edit_sequence(engine):
+    """The reference's fitted state after every inducing-set edit (tests/golden/g8_edits.npz, made by
+    gppotential.py's _regression on the reference's own K rows) against PosteriorPotential driving
+    `engine` through the same edits."""
+    from autoforce_amd.model import Local
+    from autoforce_amd.posterior import Frame, PosteriorPotential
+    from helpers import load
+    want, g = load("g8_edits"), load("g5_big40")
+    ptr = g["ind_ptr"]
+    locs = [Local(int(z), g["ind_nbr_z"][ptr[q]:ptr[q + 1]], g["ind_nbr_r"][ptr[q]:ptr[q + 1]])
+            for q, z in enumerate(g["ind_z"])]
+    fr = Frame(g["numbers"], g["positions"], g["cell"], g["pbc"], float(want["energy"]), want["forces"], want["stress"])
+    p = PosteriorPotential(engine)
+
+    def check(k):
+        assert [x is locs[i] for x, i in zip(p.X, want[f"idx_{k}"])] == [True] * len(p.X)
+        np.testing.assert_allclose(p.M, want[f"M_{k}"], rtol=1e-10, atol=1e-13)
+        assert p.ridge == float(want[f"ridge_{k}"])
+        assert abs(p.scaled_noise["all"] - float(want[f"sigma_{k}"])) <= 1e-12 * float(want[f"sigma_{k}"])
+        # the reference's K_f/K_v come from its fp32-tainted analytic gradients (1e-6): compare the
+        # fitted values, not mu itself (K is ill-conditioned; mu is not unique to that precision)
+        pred = p.K @ p.mu
+        assert np.abs(pred - want[f"pred_{k}"]).max() <= 2e-5 * np.abs(want[f"pred_{k}"]).max()
+
+    p.set_data([fr], locs[:8])
+    check(0)
+    p.add_inducing(locs[8])
+    check(1)
+    p.add_inducing(locs[9])
+    check(2)
+    p.pop_1inducing()
+    check(3)
+    p.popfirst_1inducing()
+    check(4)
+    p.select_inducing([4, 0, 7, 2])  # = original numbers 5, 1, 8, 3
+    check(5)

@@ -27,6 +27,8 @@ Reference call sites exercised (file:line under /root/reference/theforce):
 """
 import os
 import sys
+
+sys.dont_write_bytecode = True  # never write __pycache__ into the read-only reference tree
 from types import SimpleNamespace
 
 import numpy as np
@@ -601,8 +603,147 @@ def kernel_rows(name):
     print(f"{name}: rows done; |Kf|max={abs(Kf).max():.3f}")
 
 
+# ----------------------------------------------------------------------------- G8 inducing-set edits
+def _ref_locals(g, efk):
+    numbers, pos, cell = g["numbers"], g["positions"], g["cell"]
+    ptr, J, O = g["nl_ptr"], g["nl_j"], g["nl_off"]
+    N = len(numbers)
+    xyz, lll = torch.tensor(pos), torch.tensor(cell)
+    locs = []
+    for a in range(N):
+        n = J[ptr[a]:ptr[a + 1]].astype(np.int64)
+        off = O[ptr[a]:ptr[a + 1]]
+        r = xyz[n] - xyz[a] + (torch.from_numpy(off[..., None].astype(float)) * lll).sum(dim=1)
+        loc = Local(a, n, numbers[a], numbers[n], r, off, efk.kernels, dont_save_grads=False)
+        loc.natoms = N
+        locs.append(loc)
+    X = []
+    ip = g["ind_ptr"]
+    for q, zc in enumerate(g["ind_z"]):
+        k = int(ip[q + 1] - ip[q])
+        X.append(Local(0, np.arange(1, k + 1), int(zc), g["ind_nbr_z"][ip[q]:ip[q + 1]].astype(np.int64),
+                       torch.tensor(g["ind_nbr_r"][ip[q]:ip[q + 1]].reshape(k, 3)), None, efk.kernels, True))
+    return locs, X
+
+
+def g8_edits(name="g5_big40"):
+    """The states a model passes through under add_inducing / pop_1inducing / popfirst_1inducing /
+    select_inducing (gppotential.py:745-813, :1037-1046), each one refitted by the reference's
+    _regression on the reference's own K_e/K_f/K_v and K_mm of that inducing subset.  Labels are a
+    fixed synthetic target so that every state fits the same data."""
+    g = np.load(os.path.join(OUT, name + ".npz"))
+    kern, efk = make_kernel(int(g["lmax"]), int(g["nmax"]), int(g["eta"]), float(g["rc"]))
+    locs, X = _ref_locals(g, efk)
+    N, numbers = len(g["numbers"]), g["numbers"]
+    rng = np.random.default_rng(80)
+    energy = float(rng.normal()) * 2.0
+    forces = rng.normal(size=(N, 3)) * 0.3
+    stress = rng.normal(size=6) * 0.01
+    vol = abs(np.linalg.det(g["cell"]))
+    states = [list(range(8)), list(range(9)), list(range(10)), list(range(9)), list(range(1, 9)), [5, 1, 8, 3]]
+    out = dict(frame=name, energy=energy, forces=forces, stress=stress, n_states=len(states))
+
+    class _A:
+        target_forces = torch.tensor(forces)
+        target_stress = torch.tensor(stress)
+
+        def get_volume(self):
+            return vol
+
+        def counts(self):
+            u, c = np.unique(numbers, return_counts=True)
+            return {int(a): int(b) for a, b in zip(u, c)}
+
+    class _D(list):
+        target_energy = torch.tensor([energy])
+        natoms = [N]
+
+        def counts(self):
+            return self[0].counts()
+
+    data = _D([_A()])
+    for k, idx in enumerate(states):
+        Xs = [X[i] for i in idx]
+        m = len(Xs)
+        M = efk(Xs, Xs).detach()
+        Ke = efk.base_kerns(locs, Xs, "func").detach().sum(0).view(1, m)
+        Kf = -efk.base_kerns(locs, Xs, "leftgrad").detach().view(N, 3 * N, m).sum(0)
+        Kv = efk.base_kerns(locs, Xs, "virial").detach().view(N, 6, m).sum(0)
+        mean = AutoMean()
+        mean.set_data(data)
+        ns = SimpleNamespace(
+            ignore_forces=False, M=M, Ke=Ke, Kf=Kf, Kv=Kv, X=[SimpleNamespace(number=int(x.number)) for x in Xs],
+            data=data, gp=SimpleNamespace(noise=White(signal=0.01, requires_grad=False),
+                                          mean=lambda dat, forces=False: torch.stack([mean(a) for a in dat])),
+            mean=mean)
+        ns.K = torch.cat([Ke, Kf, Kv])
+        _regression(ns, optimize=False)
+        out[f"idx_{k}"] = np.array(idx, np.int32)
+        out[f"M_{k}"] = M.numpy()
+        out[f"mu_{k}"] = ns.mu.numpy()
+        out[f"pred_{k}"] = (ns.K @ ns.mu).numpy()
+        out[f"ridge_{k}"] = float(ns.ridge)
+        out[f"sigma_{k}"] = float(ns.scaled_noise["all"])
+    np.savez_compressed(os.path.join(OUT, "g8_edits.npz"), **out)
+    print("g8_edits done:", [len(s) for s in states], "ridges", [out[f"ridge_{k}"] for k in range(len(states))])
+
+
+# ----------------------------------------------------------------------------- G10 .sgpr tape
+def g10_tape():
+    """Text produced by the reference's own tape writer (io/sgprio.py:16-22, :67-90) for three
+    LCEs and a params block.  The `atoms` block cannot be produced here (the reference delegates
+    it to ase.io's extended-XYZ writer and ASE is absent): it is written below in that format's
+    documented layout (Lattice / Properties / energy / stress 3x3 / pbc, species + pos + forces)."""
+    from theforce.io.sgprio import SgprIO
+    path = os.path.join(OUT, "g10_tape.sgpr")
+    if os.path.exists(path):
+        os.remove(path)
+    g = np.load(os.path.join(OUT, "g5_mixed64.npz"))
+    kern, efk = make_kernel()
+    ip = g["ind_ptr"]
+    tape = SgprIO(path)
+    rng = np.random.default_rng(100)
+    numbers = np.array([3, 15, 16, 16], np.int32)
+    pos = rng.uniform(0, 5, size=(4, 3))
+    cell = np.array([[6.0, 0, 0], [0.5, 6.5, 0], [0, 0.25, 7.0]])
+    forces = rng.normal(size=(4, 3))
+    stress = rng.normal(size=6) * 0.01
+    energy = -12.345678901234
+    sym = {3: "Li", 15: "P", 16: "S"}
+    voigt = [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]
+    s33 = np.zeros((3, 3))
+    for v, (i, j) in zip(stress, voigt):
+        s33[i, j] = s33[j, i] = v
+    with open(path, "a") as f:
+        f.write("\nstart: atoms\n4\n")
+        f.write('Lattice="{}" Properties=species:S:1:pos:R:3:forces:R:3 energy={!r} stress="{}" pbc="T T F"\n'.format(
+            " ".join(repr(float(v)) for v in cell.reshape(-1)), energy, " ".join(repr(float(v)) for v in s33.reshape(-1))))
+        for z, p, fo in zip(numbers, pos, forces):
+            f.write("{:<2s}      {:16.8f} {:16.8f} {:16.8f} {:16.8f} {:16.8f} {:16.8f}\n".format(sym[int(z)], *p, *fo))
+        f.write("end: atoms\n")
+    loc_z, loc_ptr, loc_b, loc_r = [], [0], [], []
+    for q in (0, 5, 11):
+        k = int(ip[q + 1] - ip[q])
+        b = g["ind_nbr_z"][ip[q]:ip[q + 1]].astype(np.int64)
+        r = g["ind_nbr_r"][ip[q]:ip[q + 1]].reshape(k, 3)
+        loc = Local(0, np.arange(1, k + 1), int(g["ind_z"][q]), b, torch.tensor(r), None, efk.kernels, True)
+        tape.write(loc)
+        loc_z.append(int(g["ind_z"][q]))
+        loc_b.append(b)
+        loc_r.append(r)
+        loc_ptr.append(loc_ptr[-1] + k)
+    tape.write_params(ediff=0.086, fdiff=0.129)
+    # what the %16.8f text can hold of the positions / forces
+    np.savez_compressed(os.path.join(OUT, "g10_tape.npz"), n_local=3, loc_z=np.array(loc_z, np.int32),
+                        loc_ptr=np.array(loc_ptr, np.int64), loc_b=np.concatenate(loc_b).astype(np.int32),
+                        loc_r=np.concatenate(loc_r), at_numbers=numbers, at_positions=np.round(pos, 8),
+                        at_forces=np.round(forces, 8), at_stress=stress, at_cell=cell, at_energy=energy,
+                        at_pbc=np.array([True, True, False]))
+    print("g10_tape done:", path)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "kat", "frames", "g7", "g9", "rows"]
+    which = sys.argv[1:] or ["g1", "g2", "kat", "frames", "g7", "g9", "rows", "g8", "g10"]
     if "g1" in which:
         g1_ylm()
     if "g2" in which:
@@ -618,3 +759,7 @@ if __name__ == "__main__":
     if "rows" in which:
         for nm in ("g5_big40", "g5_bigtric36", "g5_cluster16"):
             kernel_rows(nm)
+    if "g8" in which:
+        g8_edits()
+    if "g10" in which:
+        g10_tape()

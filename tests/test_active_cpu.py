@@ -1,0 +1,246 @@
+"""Host logic of the on-the-fly learner driven through the CPU
+oracle engine: PosteriorPotential bookkeeping, acceptance rules, tape and model files.
+The same scenario runs on the HIP engine in tests/test_hip_active.py."""
+import os
+
+import numpy as np
+import pytest
+
+import active_common as ac
+from autoforce_amd.ase_shim import Atoms
+from autoforce_amd.calculator import ActiveCalculator, Switch
+from autoforce_amd.posterior import Frame, PosteriorPotential
+from autoforce_amd.sgprio import SgprIO
+from helpers import OracleModel, PairTeacher, load
+
+
+def engine():
+    return OracleModel(3, 3, 4, 4.5, species=ac.SPECIES)
+
+
+def test_learning_loop(tmp_path):
+    calc, teacher, trace = ac.run(engine(), tmp_path)
+    sizes = [t[0] for t in trace]
+    assert sizes[0][0] == 1 and sizes[0][1] >= 2          # seeded from the first frame
+    assert sizes[-1][1] > sizes[0][1] and sizes[-1][0] >= 2  # LCEs and data were sampled later on
+    assert all(a[1] <= b[1] for a, b in zip(sizes, sizes[1:]))
+    # the model tracks the teacher on the frames it has just seen
+    at = trace[-1][5]
+    ref = Atoms(at.numbers, at.positions, at.cell, True)
+    ref.calc = teacher
+    assert np.abs(trace[-1][2] - ref.get_forces()).max() < 0.3
+    assert abs(trace[-1][1] - ref.get_potential_energy()) < 0.05
+    # every step's covloss ended below the sampling threshold (that is what update_inducing enforces)
+    assert all(float(t[3]) < 1.5 * ac.KW["ediff"] for t in trace)
+    # deltas are reported exactly on the steps (> 0) where the model changed
+    changed = [b[0] != a[0] for a, b in zip(trace, trace[1:])]
+    assert [t[4] for t in trace[1:]] == changed
+    log = open(tmp_path / "active.log").read()
+    for token in ("seed size:", "added indu:", "added data:", "fit error (mean,mae):", "exact energy:", "DF:"):
+        assert token in log
+    # results stay a fixed point: asking again does not call the engine or the teacher
+    n = teacher.calls
+    trace[-1][5].get_forces()
+    assert teacher.calls == n
+
+
+def test_tape_replay_and_build(tmp_path):
+    calc, teacher, trace = ac.run(engine(), tmp_path)
+    blocks = SgprIO(str(tmp_path / "model.sgpr")).read()
+    kinds = [k for k, _ in blocks]
+    assert kinds.count("atoms") == calc.size[0] and kinds.count("local") >= calc.size[1]
+    assert kinds[0] == "atoms"  # the seed frame comes first (active.py:618-623)
+    # frames on the tape carry the teacher's labels
+    fr = next(o for k, o in blocks if k == "atoms")
+    at = Atoms(fr.numbers, fr.positions, fr.cell, fr.pbc)
+    at.calc = PairTeacher(rc=4.0)
+    assert abs(at.get_potential_energy() - fr.energy) < 1e-9
+    assert np.abs(at.get_forces() - fr.forces).max() < 1e-9
+    # 1. build(): one-shot model from the calculator's own tape
+    sub = tmp_path / "b"
+    sub.mkdir()
+    os.link(tmp_path / "model.sgpr", sub / "model.sgpr")
+    c2 = ActiveCalculator(engine=engine(), logfile=str(sub / "active.log"), tape=str(sub / "model.sgpr"),
+                          pckl=str(sub / "model.npz"), **ac.KW)
+    c2.build()
+    assert c2.size == (kinds.count("atoms"), kinds.count("local"))
+    last = trace[-1][5]
+    probe = Atoms(last.numbers, last.positions, last.cell, True)
+    probe.calc = c2
+    assert np.abs(probe.get_forces() - trace[-1][2]).max() < 0.35  # same data, different fit history
+    with pytest.raises(RuntimeError, match="already exists"):
+        c2.build()
+    # 2. include_tape(): replay through the acceptance rules of a fresh learner
+    sub3 = tmp_path / "c"
+    sub3.mkdir()
+    c3 = ActiveCalculator(engine=engine(), calculator=None, logfile=str(sub3 / "active.log"),
+                          tape=str(sub3 / "own.sgpr"), pckl=None, **ac.KW)
+    c3._calc = object()  # "active" without a live teacher: labels come from the tape
+    c3.include_tape(str(tmp_path / "model.sgpr"))
+    assert c3.size[0] >= 1 and 2 <= c3.size[1] <= kinds.count("local")
+    with pytest.raises(RuntimeError, match="own .sgpr tape"):
+        c3.include_tape(str(sub3 / "own.sgpr"))
+
+
+def test_model_file_roundtrip(tmp_path):
+    from autoforce_amd.modelio import load_model
+    calc, teacher, trace = ac.run(engine(), tmp_path, steps=3, tape=False)
+    post = load_model(str(tmp_path / "model.npz"), engine=engine())
+    assert (post.ndata, len(post.X)) == calc.size
+    np.testing.assert_allclose(post.Kf, calc.model.Kf, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(post.mu, calc.model.mu)
+    assert post.mean.weights == calc.model.mean.weights
+    c2 = ActiveCalculator(covariance=post, logfile=None)
+    at = trace[-1][5]
+    probe = Atoms(at.numbers, at.positions, at.cell, True)
+    probe.calc = c2
+    np.testing.assert_allclose(probe.get_forces(), trace[-1][2], rtol=0, atol=1e-10)
+    assert abs(probe.get_potential_energy() - trace[-1][1]) < 1e-10
+
+
+def _frames(n, seed=5):
+    rng, numbers, pos, cell = ac.start(seed)
+    teacher = PairTeacher(rc=4.0)
+    out = []
+    for _ in range(n):
+        pos = pos + 0.08 * rng.normal(size=pos.shape)
+        at = Atoms(numbers, pos, cell, True)
+        at.calc = teacher
+        out.append(Frame(numbers, pos, cell, True, at.get_potential_energy(), at.get_forces(), at.get_stress()))
+    return out
+
+
+def _locals(fr, idx, rc=4.5):
+    from oracle import oracle as orc
+    from autoforce_amd.model import Local
+    ptr, j, off = orc.neighbors(fr.positions, fr.cell, fr.pbc, rc)
+    out = []
+    for k in idx:
+        a, b = ptr[k], ptr[k + 1]
+        out.append(Local(fr.numbers[k], fr.numbers[j[a:b]], fr.positions[j[a:b]] - fr.positions[k] + off[a:b] @ fr.cell))
+    return out
+
+
+def test_posterior_edits_equal_rebuilds():
+    """add/pop/select/downsize keep (Ke, Kf, Kv, M, mu) identical to a model built from scratch on
+    the same data and inducing set (gppotential.py:730-842)."""
+    frames = _frames(3)
+    locs = _locals(frames[0], range(0, 18, 2))
+
+    def fresh(data, X):
+        p = PosteriorPotential(engine())
+        p.set_data(data, X)
+        return p
+
+    def same(p, q):
+        for name in ("Ke", "Kf", "Kv"):
+            np.testing.assert_allclose(getattr(p, name), getattr(q, name), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(p.M, q.M, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(p.K @ p.mu, q.K @ q.mu, rtol=0, atol=1e-8)
+
+    p = fresh(frames[:1], locs[:5])
+    p.add_inducing(locs[5])
+    p.add_data([frames[1]])
+    p.add_inducing(locs[6])
+    same(p, fresh(frames[:2], locs[:7]))
+    p.pop_1inducing()
+    p.popfirst_1inducing()
+    same(p, fresh(frames[:2], locs[1:6]))
+    p.add_data([frames[2]])
+    p.popfirst_1data()
+    same(p, fresh(frames[1:3], locs[1:6]))
+    p.select_inducing([4, 0, 2])
+    same(p, fresh(frames[1:3], [locs[5], locs[1], locs[3]]))
+    # downsize(lii): keeps the m LCEs with the smallest K_mm row sums, oldest data go first
+    p = fresh(frames, locs)
+    order = np.argsort(p.M.sum(axis=1), kind="stable")[:4].tolist()
+    ch1, ch2 = p.downsize(2, 4, first=True, lii=True)
+    assert ch1 == 1 and ch2 == order
+    same(p, fresh(frames[1:], [locs[i] for i in order]))
+
+
+def test_acceptance_rules():
+    frames = _frames(3)
+    locs = _locals(frames[0], range(18))
+    p = PosteriorPotential(engine())
+    p.set_data(frames[:1], locs[:4])
+    # an LCE already in the set changes nothing -> refused (and the duplicate makes K_mm singular)
+    assert p.add_1inducing(locs[0], 1e-3)[0] == 0 and len(p.X) == 4
+    # a far threshold refuses, a zero threshold accepts
+    assert p.add_1inducing(locs[9], 1e3)[0] == 0 and len(p.X) == 4
+    added, de = p.add_1inducing(locs[9], 0.0)
+    assert added == 1 and de > 0 and len(p.X) == 5
+    # data: the frame it was fitted on adds nothing; a new frame with generous thresholds is refused,
+    # with tight ones accepted
+    assert p.add_1atoms_fast(frames[0], 1e-4, 1e-4)[0] == 0 and p.ndata == 1
+    assert p.add_1atoms_fast(frames[2], 1e3, 1e3)[0] == 0 and p.ndata == 1
+    assert p.add_1atoms_fast(frames[2], 1e-6, 1e-6)[0] == 1 and p.ndata == 2
+    # leakage of an inducing LCE is ~0, of a new one positive
+    assert abs(p.leakage(locs[0])) < 1e-6 and p.leakage(locs[13]) > 1e-4
+
+
+def test_hpo_meets_noise_target():
+    """make_munu(algo=3): after the noise search the force-fit MAE of the forces-only fit sits at
+    noise_f (gppotential.py:1265-1300), and the mean offsets solve their least-squares problem."""
+    frames = _frames(2)
+    locs = _locals(frames[0], range(18)) + _locals(frames[1], range(0, 18, 2))
+    p = PosteriorPotential(engine())
+    p.set_data(frames, locs)
+    # the reachable force MAE spans 0.0143 (noise -> 0) .. 0.0177 (noise -> 1) on this set; the
+    # search is local (BFGS from the current noise), so start it on the slope
+    p._noise["all"] = 1.0
+    p.make_munu(algo=3, noise_f=0.016)
+    mu = p._solve(with_energies=False)
+    _, f, _ = p.targets()
+    assert abs(np.abs(p.Kf @ mu - f).mean() - 0.016) < 1e-4
+    nat = np.array([fr.natoms for fr in frames], float)
+    res = (np.array([fr.energy for fr in frames]) - p.Ke @ mu - [p.mean(fr.counts()) for fr in frames]) / nat
+    A = np.array([[fr.counts()[z] for z in ac.SPECIES] for fr in frames], float) / nat[:, None]
+    assert np.abs(A.T @ res).max() < 1e-10  # normal equations of the per-atom energy residual
+
+
+def test_switch_thresholds():
+    s = Switch([0.1, 2.0, 0.2, 5.0, 0.4])
+    assert (s(1.0), s(3.0), s(9.0)) == (0.1, 0.2, 0.4)
+    with pytest.raises(RuntimeError, match="not ordered"):
+        Switch([0.1, 5.0, 0.2, 2.0, 0.3])
+    calc = ActiveCalculator(engine=engine(), logfile=None, ediff=[0.1, 2.0, 0.2])
+    calc.maximum_force = 1.0
+    assert calc.ediff == 0.1 and calc.ediff_ub == 0.1
+    calc.maximum_force = 3.0
+    assert calc.ediff == 0.2
+
+
+def test_tape_golden_blocks():
+    """`.sgpr` text written by the reference's own writer (tests/golden/g10_tape.sgpr) parses to
+    the arrays it was written from, and our writer reproduces the reference's `local` text
+    byte for byte (io/sgprio.py:16-22)."""
+    from autoforce_amd.sgprio import format_lce
+    path = os.path.join(os.path.dirname(__file__), "golden", "g10_tape.sgpr")
+    want = load("g10_tape")
+    blocks = SgprIO(path).read()
+    locs = [o for k, o in blocks if k == "local"]
+    assert len(locs) == int(want["n_local"])
+    for q, loc in enumerate(locs):
+        assert loc.number == int(want["loc_z"][q])
+        a, b = want["loc_ptr"][q], want["loc_ptr"][q + 1]
+        np.testing.assert_array_equal(loc._b, want["loc_b"][a:b])
+        np.testing.assert_allclose(loc._r, want["loc_r"][a:b], rtol=0, atol=5e-9)  # {:16.8f}
+    text = open(path).read()
+    for loc in locs:
+        assert "start: local\n" + "".join(format_lce(loc)) + "end: local\n" in text
+    fr = next(o for k, o in blocks if k == "atoms")
+    np.testing.assert_array_equal(fr.numbers, want["at_numbers"])
+    np.testing.assert_allclose(fr.positions, want["at_positions"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fr.forces, want["at_forces"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fr.stress, want["at_stress"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fr.cell, want["at_cell"], rtol=0, atol=1e-12)
+    assert abs(fr.energy - float(want["at_energy"])) < 1e-12 and fr.pbc.tolist() == want["at_pbc"].tolist()
+    params = next(o for k, o in blocks if k == "params")
+    assert params == {"ediff": 0.086, "fdiff": 0.129}
+
+
+def test_edit_sequence_against_reference():
+    g = load("g5_big40")
+    ac.check_g8_edit_sequence(OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                          species=g["species"].tolist()))

@@ -1,0 +1,116 @@
+"""GPU: the inducing-set edit entry points, k(loc, X), and the on-the-fly learner on the HIP
+engine — against the reference's fitted states (g8), against the oracle engine driven through the
+same control flow, and run-to-run."""
+import numpy as np
+import pytest
+
+import active_common as ac
+from test_hip_parity import load, model_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_engine():
+    from autoforce_amd import SGPRModel
+    return SGPRModel(3, 3, 4, 4.5, species=ac.SPECIES)
+
+
+def test_edit_sequence_against_reference():
+    from autoforce_amd import SGPRModel
+    g = load("g5_big40")
+    ac.check_g8_edit_sequence(SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                        species=g["species"].tolist()))
+
+
+@pytest.mark.parametrize("name", ["g5_mixed64", "g5_big40"])
+def test_edit_entry_points_equal_rebuild(name):
+    """sgpr_add/remove/select_inducing leave the library in the state sgpr_set_inducing builds for
+    the same list; sgpr_kernel_columns are columns of sgpr_kernel_rows; sgpr_kernel_local is the
+    row of K_mm the LCE would get."""
+    g = load(name)
+    full = model_from_fixture(g)
+    X = list(full.X)
+    M = full.M
+    rows = full.kernel_rows(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    m = len(X)
+    inc = full.scratch()
+    for x in X[:3]:
+        inc.add_inducing(x)
+    inc.set_inducing(X[:5])
+    for x in X[5:]:
+        inc.add_inducing(x)
+    np.testing.assert_array_equal(inc.M, M)
+    for a, b in zip(inc.kernel_rows(g["numbers"], g["positions"], g["cell"], g["pbc"]), rows):
+        np.testing.assert_array_equal(a, b)
+    cols = inc.kernel_columns(g["numbers"], g["positions"], g["cell"], g["pbc"], 2, 3)
+    np.testing.assert_array_equal(cols[0], rows[0][2:5])
+    np.testing.assert_array_equal(cols[1], rows[1][:, 2:5])
+    np.testing.assert_array_equal(cols[2], rows[2][:, 2:5])
+    # k(loc, X) for a member = its K_mm row; k(loc, loc) = the diagonal
+    k, kxx = inc.kernel_local(X[4])
+    np.testing.assert_allclose(k, M[4], rtol=1e-12, atol=1e-14)
+    assert abs(kxx - M[4, 4]) < 1e-12
+    inc.remove_inducing(-1)
+    np.testing.assert_array_equal(inc.M, M[:-1, :-1])
+    inc.remove_inducing(0)
+    np.testing.assert_array_equal(inc.M, M[1:-1, 1:-1])
+    keep = [m - 3, 0, 2]
+    inc.select_inducing(keep)
+    sel = [k + 1 for k in keep]
+    np.testing.assert_array_equal(inc.M, M[np.ix_(sel, sel)])
+    assert [x is X[i] for x, i in zip(inc.X, sel)] == [True] * 3
+    # errors
+    from autoforce_amd import Local, SgprError
+    with pytest.raises(SgprError):
+        inc.remove_inducing(7)
+    with pytest.raises(SgprError):
+        inc.add_inducing(Local(99, [], np.zeros((0, 3))))
+    with pytest.raises(SgprError):
+        inc.kernel_columns(g["numbers"], g["positions"], g["cell"], g["pbc"], 2, 5)
+    inc.close()
+    full.close()
+
+
+def test_learning_loop_matches_oracle_engine(tmp_path):
+    """Same scenario, same host logic, two engines: the HIP library and the CPU oracle.  The
+    sampled sets must coincide step by step and the predictions agree to solver precision."""
+    from helpers import OracleModel
+    (tmp_path / "hip").mkdir()
+    (tmp_path / "cpu").mkdir()
+    c1, t1, tr1 = ac.run(hip_engine(), tmp_path / "hip")
+    c2, t2, tr2 = ac.run(OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), tmp_path / "cpu")
+    assert [t[0] for t in tr1] == [t[0] for t in tr2]
+    assert t1.calls == t2.calls
+    for a, b in zip(tr1, tr2):
+        assert abs(a[1] - b[1]) < 1e-6
+        assert np.abs(a[2] - b[2]).max() < 1e-6
+        assert a[4] == b[4]
+    for x, y in zip(c1.model.X, c2.model.X):
+        assert x.number == y.number
+        # same environment; the two neighbour-list builders list it in different orders
+        ox, oy = np.lexsort(np.round(x._r, 9).T), np.lexsort(np.round(y._r, 9).T)
+        np.testing.assert_allclose(x._r[ox], y._r[oy], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(x._b[ox], y._b[oy])
+    assert c1.size[0] >= 2 and c1.size[1] > tr1[0][0][1]
+
+
+def test_learning_loop_is_reproducible(tmp_path):
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    _, _, tr1 = ac.run(hip_engine(), tmp_path / "a", steps=4)
+    _, _, tr2 = ac.run(hip_engine(), tmp_path / "b", steps=4)
+    for a, b in zip(tr1, tr2):
+        assert a[0] == b[0] and a[1] == b[1]
+        np.testing.assert_array_equal(a[2], b[2])
+
+
+def test_saved_learner_resumes(tmp_path):
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    calc, teacher, trace = ac.run(hip_engine(), tmp_path, steps=3)
+    c2 = ActiveCalculator(covariance=str(tmp_path / "model.npz"), logfile=None)
+    assert c2.size == calc.size
+    at = trace[-1][5]
+    probe = Atoms(at.numbers, at.positions, at.cell, True)
+    probe.calc = c2
+    np.testing.assert_allclose(probe.get_forces(), trace[-1][2], rtol=0, atol=1e-10)

@@ -46,7 +46,7 @@ def test_model_io_roundtrip(tmp_path):
     path = str(tmp_path / "model.npz")
     save_model(path, mdl)
     mdl.close()
-    m2 = load_model(path)
+    m2 = load_model(path).engine
     out = m2.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
     for k in ("energy", "forces", "stress", "beta"):
         np.testing.assert_array_equal(np.asarray(out[k]), np.asarray(ref[k]))
