@@ -302,6 +302,35 @@ def g2_sesoap():
     print("g2_sesoap done:", names)
 
 
+# ----------------------------------------------------------------------------- G3 SubSeSoap
+def g3_subsesoap():
+    """The fixed-species descriptor of the `species=[...]` kernels (descriptor/sesoap.py:263-391;
+    calculator/active.py:31-38) on the g2 environments: dense p[S,S,n,n',l] over the sorted
+    species list of each case, plus one case whose table holds a species absent from the
+    environment and one where a neighbour species is outside the table (it is ignored)."""
+    from theforce.descriptor.sesoap import SubSeSoap
+    g2 = np.load(os.path.join(OUT, "g2_sesoap.npz"))
+    out, names = {}, []
+    for name in g2["names"]:
+        lmax, nmax = int(g2[name + "_lmax"]), int(g2[name + "_nmax"])
+        r, z = g2[name + "_r"], g2[name + "_z"].astype(np.int64)
+        tables = {"": sorted(set(z.tolist()))}
+        if name == "s3":
+            tables["_extra"] = [3, 8, 15, 16]       # 8 never occurs
+            tables["_drop"] = [3, 16]               # P neighbours are outside the table
+        for tag, table in tables.items():
+            s = SubSeSoap(lmax, nmax, PolyCut(6.0), table, radii=DefaultRadii())
+            p = s(torch.tensor(r), torch.tensor(z), grad=False)
+            key = name + tag
+            names.append(key)
+            out[key + "_case"] = str(name)
+            out[key + "_table"] = np.array(table, np.int32)
+            out[key + "_p"] = p.numpy().reshape(len(table), len(table), nmax + 1, nmax + 1, lmax + 1)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g3_subsesoap.npz"), **out)
+    print("g3_subsesoap done:", names)
+
+
 # ----------------------------------------------------------------------------- KAT
 def kat_absseries():
     """descriptor/soap.py:488-525: inputs and the target tensor, plus what the reference
@@ -743,11 +772,13 @@ def g10_tape():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "kat", "frames", "g7", "g9", "rows", "g8", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "kat", "frames", "g7", "g9", "rows", "g8", "g10"]
     if "g1" in which:
         g1_ylm()
     if "g2" in which:
         g2_sesoap()
+    if "g3" in which:
+        g3_subsesoap()
     if "kat" in which:
         kat_absseries()
     if "frames" in which:

@@ -244,3 +244,47 @@ def test_edit_sequence_against_reference():
     g = load("g5_big40")
     ac.check_g8_edit_sequence(OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
                                           species=g["species"].tolist()))
+
+
+def _al_worker(rank, world, port, tmp, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import pathlib
+
+    import torch.distributed as dist
+    import active_common as ac2
+    from helpers import OracleModel as OM
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = pathlib.Path(tmp) / f"rank{rank}"
+    d.mkdir()
+    calc, teacher, trace = ac2.run(OM(3, 3, 4, 4.5, species=ac2.SPECIES), d, steps=4, tape=(rank == 0),
+                                   process_group=dist.group.WORLD)
+    q.put((rank, [t[0] for t in trace], [t[1] for t in trace], trace[-1][2], calc.model.mu))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_learning_loop_world2_gloo(tmp_path):
+    """Atoms sharded over two ranks (one all-reduce per evaluation, LCEs handed out by their
+    owner, rank 0's solve broadcast): every rank takes the same decisions as a single process."""
+    import torch.multiprocessing as mp
+    (tmp_path / "single").mkdir()
+    _, _, ref = ac.run(engine(), tmp_path / "single", steps=4)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 7) % 500)
+    procs = [ctx.Process(target=_al_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, sizes, energies, forces, mu in got:
+        assert sizes == [t[0] for t in ref]
+        np.testing.assert_allclose(energies, [t[1] for t in ref], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(forces, ref[-1][2], rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(got[0][4], got[1][4])

@@ -226,3 +226,31 @@ def test_mfma_gemm_layout_asymmetric():
     assert out["cov"].shape == (64, 24)
     np.testing.assert_allclose(out["cov"], g["cov"], rtol=1e-10, atol=1e-13)
     mdl.close()
+
+
+def test_fixed_species_table_descriptor():
+    """G3: the reference's SubSeSoap (descriptor/sesoap.py:263-391) on the device, through
+    sgpr_set_inducing + sgpr_get_inducing_descriptors, incl. a table with an absent species."""
+    from autoforce_amd import Local, SGPRModel, SgprError
+    g2, g3 = load("g2_sesoap"), load("g3_subsesoap")
+    compiled = {(3, 3), (2, 2), (4, 4)}
+    seen = 0
+    for key in g3["names"]:
+        name = str(g3[key + "_case"])
+        table = g3[key + "_table"].tolist()
+        lmax, nmax = int(g2[name + "_lmax"]), int(g2[name + "_nmax"])
+        if (lmax, nmax) not in compiled:
+            continue
+        r, z = g2[name + "_r"], g2[name + "_z"]
+        keep = np.isin(z, table)
+        mdl = SGPRModel(lmax, nmax, 4, 6.0, species=table)
+        if not keep.all():
+            with pytest.raises(SgprError):
+                mdl.set_inducing([Local(table[0], z, r)])
+        mdl.set_inducing([Local(table[0], z[keep], r[keep])])
+        S = len(table)
+        p = mdl.inducing_descriptors().reshape(S, S, nmax + 1, nmax + 1, lmax + 1)
+        np.testing.assert_allclose(p.transpose(1, 0, 2, 3, 4), g3[key + "_p"], rtol=1e-10, atol=1e-13, err_msg=str(key))
+        mdl.close()
+        seen += 1
+    assert seen >= 8

@@ -98,6 +98,29 @@ def test_sesoap_values_and_vjp():
             assert np.abs(dr - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-300), name
 
 
+def test_subsesoap_fixed_species_table():
+    """G3: SubSeSoap (descriptor/sesoap.py:263-391), the dense fixed-table variant behind the
+    `species=[...]` kernels (calculator/active.py:31-38), is the same function as the
+    species-table layout used here: p[b][a][n][n'][l] over the table, zero blocks for absent
+    species.  A neighbour whose species is outside the table contributes nothing in the
+    reference; the library's table must list every species it meets (SGPR_E_SPECIES otherwise),
+    so that case is reproduced by dropping those neighbours."""
+    g2, g3 = load("g2_sesoap"), load("g3_subsesoap")
+    for key in g3["names"]:
+        name = str(g3[key + "_case"])
+        table = g3[key + "_table"].tolist()
+        lmax, nmax = int(g2[name + "_lmax"]), int(g2[name + "_nmax"])
+        r, z = g2[name + "_r"], g2[name + "_z"]
+        keep = np.isin(z, table)
+        slots = np.array([table.index(v) for v in z[keep]], np.int32)
+        units = orc.default_radii(table)[slots]
+        S = len(table)
+        p = orc.descriptor(lmax, nmax, 6.0, r[keep], slots, units, S).reshape(S, S, nmax + 1, nmax + 1, lmax + 1)
+        # SubSeSoap indexes its blocks [alpha][beta] (sesoap.py:343-352), SeSoap's COO rows are
+        # (beta, alpha) (sesoap.py:195-203): the same numbers with the two species axes swapped
+        np.testing.assert_allclose(p.transpose(1, 0, 2, 3, 4), g3[key + "_p"], rtol=1e-11, atol=1e-14, err_msg=str(key))
+
+
 def test_sesoap_symmetry():
     """p[b,a,n,n',l] == p[a,b,n',n,l] (what the packed layout of the HIP path relies on)."""
     g = load("g2_sesoap")
