@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgpr_hip.so")
+LIB_PATH = os.environ.get("SGPR_HIP_LIB") or os.path.join(_HERE, "libsgpr_hip.so")  # override: kernel experiments
 
 OK, E_INVALID, E_NODEVICE, E_NOMODEL, E_SPECIES, E_NOT_PD, E_UNSUPPORTED, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7
 
