@@ -99,6 +99,11 @@ struct sgpr_model {
     DevBuf<double> d_b_pos;
     DevBuf<int> d_nn_raw, d_b_slot;
     DevBuf<double> d_gpart;
+    DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
+    // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
+    DevBuf<double> d_L, d_R1;
+    bool chol_valid = false, r1_valid = false;
+    double chol_ridge = 0.0, chol_dmean = 0.0;
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_dC, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
     DevBuf<int> d_shear;
@@ -358,7 +363,8 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
                             &h->d_vs_sqrt, &h->d_gpart, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_dC,
-                            &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed};
+                            &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed,
+                            &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1};
     for (auto b : db) b->release();
     h->d_pack.release();
     h->d_grid.release();
@@ -473,6 +479,7 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     HIPCHK(hipSetDevice(h->device));
     drop_graph(h);
     h->has_mu = h->has_choli = false;
+    h->chol_valid = h->r1_valid = false;
     h->m = m;
     h->m_pad = rup(std::max(m, 1), 32);
     h->m_rows = rup(std::max(m, 1), 64);

@@ -10,6 +10,8 @@
 #include <algorithm>
 
 #include "sgpr_internal.h"
+#include <algorithm>
+#include <vector>
 
 #define NB 64
 
@@ -319,4 +321,244 @@ int launch_lstsq_qr(int rows, int cols, double *A, double *y, double *x, double 
     }
     hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, A, y, x);
     return 0;
+}
+
+
+// ------------------------------------------------------------------ blocked Householder QR (compact WY)
+// Storage: At[c][r] = A[r][c] (each column of the least-squares matrix is a contiguous row of
+// length ldr), so every column operation streams whole cache lines, and both trailing products
+// are NT GEMMs for gemm_nt_kernel:
+//     W  = V^T A_trail      (32 x ntrail, contraction over the rows: split-K + fp64 atomics)
+//     A_trail -= V (T^T W)  (contraction over the 32 reflectors)
+// Panel factorisation (32 columns): two launches per column —
+//   dots:   v_j from the column and its norm; g[c] = v_j . (earlier v_c | later column c)
+//   update: later columns -= scal_j g[c] v_j, and the norm^2 of the next column on the way.
+// Reflectors are kept unnormalised: Q_j = I - scal_j v_j v_j^T, scal_j = 2 / v_j.v_j.
+#define QNB 32
+#define QCH 256  // rows per workgroup in the panel kernels
+
+struct QrPanel {
+    double *At;    // [cols+1 ...][ldr]
+    double *Vt;    // [QNB][ldr]   reflectors, zero above their diagonal
+    double *Vrm;   // [ldr][QNB]   the same, row-major
+    double *G;     // [QNB][QNB]   g of every column step
+    double *scal;  // [QNB]
+    double *nrm2;  // [QNB + 1]    squared norms of the panel columns at their own step
+    int ldr, rows, k0, nb;
+};
+
+__global__ __launch_bounds__(256) void qr_colnorm_kernel(QrPanel q, int j)
+{
+    const int k = q.k0 + j;
+    const int r = k + blockIdx.x * QCH + threadIdx.x;
+    double s = 0.0;
+    if (r < q.rows) {
+        const double a = q.At[(size_t)k * q.ldr + r];
+        s = a * a;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s != 0.0) unsafeAtomicAdd(&q.nrm2[j], s);
+}
+
+__global__ __launch_bounds__(256) void qr_panel_dots_kernel(QrPanel q, int j)
+{
+    __shared__ double red[4][QNB];
+    const int k = q.k0 + j, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = k + blockIdx.x * QCH + tid;  // rows >= k only
+    const double s2 = q.nrm2[j];
+    const double akk = q.At[(size_t)k * q.ldr + k];
+    const double nrm = sqrt(s2);
+    const double alpha = akk > 0.0 ? -nrm : nrm;
+    double v = 0.0;
+    if (r < q.rows) v = q.At[(size_t)k * q.ldr + r] - (r == k ? alpha : 0.0);
+    if (r < q.ldr) {
+        q.Vt[(size_t)j * q.ldr + r] = v;
+        q.Vrm[(size_t)r * QNB + j] = v;
+    }
+    double acc[QNB];
+#pragma unroll
+    for (int c = 0; c < QNB; c++) {
+        double o = 0.0;
+        if (r < q.rows && c != j && c < q.nb)
+            o = c < j ? q.Vt[(size_t)c * q.ldr + r] : q.At[(size_t)(q.k0 + c) * q.ldr + r];
+        acc[c] = v * o;
+    }
+#pragma unroll
+    for (int c = 0; c < QNB; c++) {
+        double t = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) red[wave][c] = t;
+    }
+    __syncthreads();
+    if (tid < QNB && tid != j) {
+        const double t = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (t != 0.0) unsafeAtomicAdd(&q.G[j * QNB + tid], t);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        // v.v = |a|^2 - akk^2 + (akk - alpha)^2
+        const double vv = s2 - akk * akk + (akk - alpha) * (akk - alpha);
+        q.scal[j] = vv > 0.0 ? 2.0 / vv : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void qr_panel_update_kernel(QrPanel q, int j)
+{
+    const int k = q.k0 + j, tid = threadIdx.x;
+    const int r = k + blockIdx.x * QCH + tid;
+    const double sc = q.scal[j];
+    double nxt = 0.0;
+    if (r < q.rows) {
+        const double v = q.Vt[(size_t)j * q.ldr + r];
+        for (int c = j + 1; c < q.nb; c++) {
+            double *a = q.At + (size_t)(q.k0 + c) * q.ldr + r;
+            const double an = *a - sc * q.G[j * QNB + c] * v;
+            *a = an;
+            if (c == j + 1 && r > k) nxt = an * an;
+        }
+        if (r == k) {  // R_kk, and zeros are never read below it
+            const double akk = q.At[(size_t)k * q.ldr + k];
+            const double nrm = sqrt(q.nrm2[j]);
+            q.At[(size_t)k * q.ldr + k] = akk > 0.0 ? -nrm : nrm;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nxt += __shfl_xor(nxt, o, 64);
+    if ((tid & 63) == 0 && nxt != 0.0) unsafeAtomicAdd(&q.nrm2[j + 1], nxt);
+}
+
+// T (upper triangular, Q = I - V T V^T) from scal and the v.v products in G; then clears G.
+__global__ __launch_bounds__(64) void qr_panel_T_kernel(QrPanel q, double *T)
+{
+    __shared__ double Ts[QNB][QNB + 1];
+    const int t = threadIdx.x;
+    for (int e = t; e < QNB * QNB; e += 64) Ts[e / QNB][e % QNB] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < q.nb; j++) {
+        // T[0:j][j] = -scal_j T[0:j][0:j] (V[:,0:j]^T v_j);  G[j][c] (c < j) = v_c . v_j
+        if (t < j) {
+            double s = 0.0;
+            for (int l = t; l < j; l++) s += Ts[t][l] * q.G[j * QNB + l];
+            Ts[t][j] = -q.scal[j] * s;
+        }
+        if (t == j) Ts[j][j] = q.scal[j];
+        __syncthreads();
+    }
+    for (int e = t; e < QNB * QNB; e += 64) T[e] = Ts[e / QNB][e % QNB];
+}
+
+// Zt[c][i] = sum_l T[l][i] W[l][c]   (Z = T^T W)
+__global__ __launch_bounds__(256) void qr_z_kernel(int ncol, const double *T, const double *W, int ldw, double *Zt)
+{
+    __shared__ double Ts[QNB * QNB];
+    for (int e = threadIdx.x; e < QNB * QNB; e += 256) Ts[e] = T[e];
+    __syncthreads();
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), i = threadIdx.x & 31;
+    if (c >= ncol) return;
+    double s = 0.0;
+    for (int l = 0; l <= i; l++) s += Ts[l * QNB + i] * W[(size_t)l * ldw + c];
+    Zt[(size_t)c * QNB + i] = s;
+}
+
+__global__ void qr_gather_r_kernel(int cols, const double *At, int ldr, double *Rm /*[cols][cols]*/, double *z)
+{
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cols && j < cols) Rm[(size_t)i * cols + j] = j >= i ? At[(size_t)j * ldr + i] : 0.0;
+    if (i < cols && j == 0) z[i] = At[(size_t)cols * ldr + i];
+}
+
+size_t lstsq_qr_blocked_work_doubles(int rows, int cols)
+{
+    const size_t ldr = (size_t)(rows + 63) / 64 * 64, cpad = (size_t)(cols + 1 + 63) / 64 * 64 + 64;
+    return 2 * QNB * ldr + 3 * QNB * QNB + 2 * QNB + 8 + QNB * cpad + cpad * QNB + (size_t)cols * cols + cols + 64;
+}
+
+int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st)
+{
+    if (cols > 2048 || rows < cols || ldr % 64 || ldr < rows) return -1;
+    const int cpad = (cols + 1 + 63) / 64 * 64 + 64;
+    QrPanel q = {};
+    q.At = At; q.ldr = ldr; q.rows = rows;
+    double *w = work;
+    q.Vt = w; w += (size_t)QNB * ldr;
+    q.Vrm = w; w += (size_t)QNB * ldr;
+    q.G = w; w += QNB * QNB;
+    double *T = w; w += QNB * QNB;
+    q.scal = w; w += QNB;
+    q.nrm2 = w; w += QNB + 8;
+    double *W = w; w += (size_t)QNB * cpad;
+    double *Zt = w; w += (size_t)cpad * QNB;
+    double *Rm = w; w += (size_t)cols * cols;
+    double *z = w; w += cols;
+    // tile tables of all panels, uploaded once
+    std::vector<int4> tiles;
+    struct Span { size_t w0, wn, u0, un; };
+    std::vector<Span> span;
+    const int KSPLIT = 1024;
+    for (int k0 = 0; k0 < cols; k0 += QNB) {
+        const int ntrail = cols + 1 - (k0 + std::min(QNB, cols - k0));
+        Span sp = {tiles.size(), 0, 0, 0};
+        if (ntrail > 0) {
+            const int ctl = (ntrail + 63) / 64;
+            const int kb0 = k0 / 32 * 32;
+            for (int kb = kb0; kb < ldr; kb += KSPLIT)
+                for (int ct = 0; ct < ctl; ct++) tiles.push_back(make_int4(0, ct, kb, std::min(ldr, kb + KSPLIT)));
+            sp.wn = tiles.size() - sp.w0;
+            sp.u0 = tiles.size();
+            for (int ct = k0 / 64; ct < ldr / 64; ct++)
+                for (int rt = 0; rt < ctl; rt++) tiles.push_back(make_int4(rt, ct, 0, QNB));
+            sp.un = tiles.size() - sp.u0;
+        }
+        span.push_back(sp);
+    }
+    int4 *d_tiles = nullptr;
+    if (!tiles.empty()) {
+        if (hipMalloc(&d_tiles, sizeof(int4) * tiles.size()) != hipSuccess) return -2;
+        (void)hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, st);
+    }
+    int pi = 0;
+    for (int k0 = 0; k0 < cols; k0 += QNB, pi++) {
+        q.k0 = k0;
+        q.nb = std::min(QNB, cols - k0);
+        (void)hipMemsetAsync(q.Vt, 0, sizeof(double) * 2 * (size_t)QNB * ldr, st);  // Vt and Vrm
+        (void)hipMemsetAsync(q.G, 0, sizeof(double) * (2 * QNB * QNB + 2 * QNB + 8), st);  // G, T, scal, nrm2
+        const int nwg0 = (rows - k0 + QCH - 1) / QCH;
+        hipLaunchKernelGGL(qr_colnorm_kernel, dim3(nwg0), dim3(256), 0, st, q, 0);
+        for (int j = 0; j < q.nb; j++) {
+            const int nwg = (ldr - (k0 + j) + QCH - 1) / QCH;
+            hipLaunchKernelGGL(qr_panel_dots_kernel, dim3(nwg), dim3(256), 0, st, q, j);
+            hipLaunchKernelGGL(qr_panel_update_kernel, dim3(nwg), dim3(256), 0, st, q, j);
+        }
+        const int ntrail = cols + 1 - (k0 + q.nb);
+        if (ntrail <= 0) continue;
+        hipLaunchKernelGGL(qr_panel_T_kernel, dim3(1), dim3(64), 0, st, q, T);
+        (void)hipMemsetAsync(W, 0, sizeof(double) * (size_t)QNB * cpad, st);
+        double *Atr = At + (size_t)(k0 + q.nb) * ldr;
+        GemmParams gw = {};
+        gw.M = QNB; gw.N = ntrail; gw.K = ldr; gw.lda = ldr; gw.ldb = ldr; gw.ldc = cpad;
+        gw.A = q.Vt; gw.B = Atr; gw.C = W; gw.bm = 32;
+        gw.tiles = d_tiles + span[pi].w0; gw.ntiles = (int)span[pi].wn;
+        launch_gemm_nt(gw, EPI_ATOMIC, st);
+        hipLaunchKernelGGL(qr_z_kernel, dim3((ntrail + 7) / 8), dim3(256), 0, st, ntrail, T, W, cpad, Zt);
+        GemmParams gu = {};
+        gu.M = ntrail; gu.N = ldr; gu.K = QNB; gu.lda = QNB; gu.ldb = QNB; gu.ldc = ldr;
+        gu.A = Zt; gu.B = q.Vrm; gu.C = Atr; gu.bm = 64;
+        gu.tiles = d_tiles + span[pi].u0; gu.ntiles = (int)span[pi].un;
+        launch_gemm_nt(gu, EPI_SUB, st);
+    }
+    if (x) {
+        hipLaunchKernelGGL(qr_gather_r_kernel, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rm, z);
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rm, z, x);
+    }
+    if (d_tiles) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_tiles);
+    }
+    return 0;
+}
+
+void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st)
+{
+    hipLaunchKernelGGL(qr_gather_r_kernel, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rm, z);
 }

@@ -102,7 +102,8 @@ void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpa
                                const double *Pp, double *Pdense, hipStream_t st);
 
 // ---- fp64 MFMA GEMM family (C = A * B^T, both operands row-major with K contiguous) --------
-enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4 };
+enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4,
+                    EPI_SUB = 5 /*C -= A.B^T*/, EPI_ATOMIC = 6 /*C += A.B^T by fp64 atomics: split-K tiles*/ };
 
 struct GemmParams {
     int M, N, K;          // C is M x N, reduction K
@@ -139,6 +140,15 @@ int launch_cholesky_lower(int m, double *A /*in: M+ridge I, out: L (lower, upper
                           int *info /*device: 0 ok else failing pivot+1*/, hipStream_t st);
 void launch_tril_inverse(int m, const double *L, int ld, double *Li, hipStream_t st);
 void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, hipStream_t st);
+// Blocked Householder QR least squares on the TRANSPOSED matrix At[cols + 1][ldr] (column c of
+// [A | y] is the contiguous row c of At; rows padded with zeros to ldr, a multiple of 64):
+// panels of 32 reflectors, compact-WY trailing updates on the MFMA GEMM.  At is overwritten.
+size_t lstsq_qr_blocked_work_doubles(int rows, int cols);
+int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /*[cols] or NULL: factor only*/,
+                            double *work, hipStream_t st);
+// R (row-major [cols][cols], upper) and z = (Q^T y)[0:cols] out of a factored At
+void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st);
+
 int launch_lstsq_qr(int rows, int cols, double *A /*[rows][cols] overwritten*/, double *y /*[rows] overwritten*/,
                     double *x /*[cols]*/, double *work, hipStream_t st);
 

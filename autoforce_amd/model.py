@@ -178,6 +178,16 @@ class SGPRModel:
         self.make_vscale()
         return mu
 
+    def resolve(self, noise=0.01):
+        """The same regression for another noise, re-using the factored [K | Y] of the last `solve`
+        (the evaluations of _regression(optimize=True), gppotential.py:1265-1300)."""
+        mu, choli = np.zeros(self.m), np.zeros((self.m, self.m))
+        ridge, sigma = C.c_double(0), C.c_double(0)
+        check(_lib.load().sgpr_resolve(self._h, float(noise), ptr(mu), ptr(choli), C.addressof(ridge),
+                                       C.addressof(sigma)))
+        self.mu, self.choli, self.ridge, self.sigma = mu, choli, ridge.value, sigma.value
+        return mu
+
     def kernel_rows(self, numbers, positions, cell, pbc):
         """(Ke[m], Kf[3N,m], Kv[6,m]) of one data frame (gppotential.py:63-84, :495-497)."""
         numbers = i32(numbers)

@@ -297,8 +297,10 @@ class PosteriorPotential:
         from scipy.optimize import minimize
         _, f, _ = self.targets()
 
+        self._solve(with_energies=False)  # factors [Kf; Kv | F; V] once; the search only re-solves
+
         def objective(x):
-            mu = self._solve(with_energies=False, x=float(x[0]))
+            mu = self.engine.resolve(noise=_sigmoid(float(x[0])))
             return (np.abs(self.Kf @ mu - f).mean() - noise_f) ** 2
 
         # forward differences with a step far above the rounding noise of the solve: the objective
@@ -306,7 +308,7 @@ class PosteriorPotential:
         res = minimize(objective, x0=[self._noise["all"]], method="BFGS",
                        options=dict(gtol=1e-9, maxiter=50, eps=1e-4))
         self._noise["all"] = float(res.x[0])
-        mu = self._solve(with_energies=False)
+        mu = self.engine.resolve(noise=_sigmoid(self._noise["all"]))
         keys = sorted(self.mean.weights)
         nat = np.array([fr.natoms for fr in self.data], float)
         A = np.array([[fr.counts().get(z, 0) for z in keys] for fr in self.data], float) / nat[:, None]

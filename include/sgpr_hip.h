@@ -104,6 +104,11 @@ int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, cons
 int sgpr_solve(sgpr_model *h, int rows, const double *K, const double *Y, double noise0,
                double *mu_out, double *choli_out, double *ridge_out, double *sigma_out);
 
+/* The same regression for another noise value, with the design matrix of the last sgpr_solve:
+ * the QR of [K | Y] is kept on the device (R, Q^T Y), the noise only enters a 2m x m second stage.
+ * This is what _regression(optimize=True) evaluates repeatedly (gppotential.py:1265-1300). */
+int sgpr_resolve(sgpr_model *h, double noise0, double *mu, double *choli, double *ridge, double *sigma);
+
 /*
  * Training rows of one data frame against the inducing set, on the device
  * (regression/gppotential.py:63-84 energy_energy / forces_energy / virial_energy through

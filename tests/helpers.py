@@ -100,12 +100,16 @@ class OracleModel:
 
     # ---- weights
     def solve(self, K, Y, noise=0.01):
-        ref = orc.regression(self.M, np.asarray(K, float).reshape(-1, self.m), np.asarray(Y, float), noise0=noise)
+        self._last_K, self._last_Y = np.asarray(K, float).reshape(-1, self.m), np.asarray(Y, float)
+        ref = orc.regression(self.M, self._last_K, self._last_Y, noise0=noise)
         if ref is None:
             raise RuntimeError("cholesky was not successful!")
         self.mu, self.choli, self.ridge, self.sigma = ref["mu"], ref["choli"], ref["ridge"], ref["sigma"]
         self.make_vscale()
         return self.mu
+
+    def resolve(self, noise=0.01):
+        return self.solve(self._last_K, self._last_Y, noise=noise)
 
     def make_vscale(self):
         vs = orc.vscale(self.M, self.mu, self._ind_z, np.array(self.species, np.int32))
