@@ -40,7 +40,7 @@ def save_model(path, model):
             noise_logit=post._noise["all"],
         )
     with open(path, "wb") as f:  # np.savez would append ".npz" to a bare path
-        np.savez_compressed(
+        np.savez(  # uncompressed: a 16384-atom model with data frames is rewritten after every update
             f,
             format="autoforce_amd.sgpr.v2",
             lmax=eng.lmax, nmax=eng.nmax, exponent=eng.exponent, cutoff=eng.cutoff,

@@ -27,6 +27,8 @@ class Frame:
         self.positions = np.asarray(positions, dtype=float).reshape(-1, 3).copy()
         self.cell = np.asarray(cell, dtype=float).reshape(3, 3).copy()
         self.pbc = np.broadcast_to(np.asarray(pbc, dtype=bool), (3,)).copy()
+        z, c = np.unique(self.numbers, return_counts=True)
+        self._counts = Counter({int(a): int(b) for a, b in zip(z, c)})
         self.set_targets(energy, forces, stress)
 
     def set_targets(self, energy, forces, stress):
@@ -47,10 +49,10 @@ class Frame:
         return abs(float(np.linalg.det(self.cell)))
 
     def counts(self):
-        return Counter(int(z) for z in self.numbers)
+        return self._counts
 
     def includes_species(self, species):
-        return any(int(z) in species for z in set(self.numbers.tolist()))  # descriptor/atoms.py:451-452
+        return any(z in species for z in self._counts)  # descriptor/atoms.py:451-452
 
     def system(self):
         return self.numbers, self.positions, self.cell, self.pbc
