@@ -299,17 +299,42 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         }
         wave_sync();
         // lane = output slot (n,lm): c[s][slot] += f[t][n] * Y[t][lm]
+        // The device neighbour list is sorted by (sorted atom index, image) and atoms are sorted by
+        // species, so the species of a tile's neighbours is non-decreasing: one uniform loop per
+        // species segment, no per-neighbour select (28 % fewer wave instructions in this kernel).
+        // Caller-ordered environments (ENV) and anything non-monotone take the select loop.
+        const int sv = t < nn ? s : ST;
+        const int sprev = __shfl_up(sv, 1, 64);
+        const bool sorted = !ENV && !__any(lane > 0 && lane < cnt && sprev > sv);
+        if (sorted) {
+            int beg = 0;
+#pragma unroll
+            for (int q = 0; q < ST; q++) {
+                const int end = beg + __popcll(__ballot(t < nn && s == q));
 #pragma unroll 4
-        for (int tt = 0; tt < cnt; tt++) {
-            const int s = __builtin_amdgcn_readfirstlane(sl[tt]);
+                for (int tt = beg; tt < end; tt++) {
 #pragma unroll
-            for (int k = 0; k < SPL; k++) {
-                const int slot = lane + 64 * k;
-                if (SPL * 64 == NSLOT || slot < NSLOT) {
-                    const double v = fl[tt * N1 + slot / LL] * Yl[tt * LLP + slot % LL];
+                    for (int k = 0; k < SPL; k++) {
+                        const int slot = lane + 64 * k;
+                        if (SPL * 64 == NSLOT || slot < NSLOT)
+                            acc[q][k] += fl[tt * N1 + slot / LL] * Yl[tt * LLP + slot % LL];
+                    }
+                }
+                beg = end;
+            }
+        } else {
+#pragma unroll 4
+            for (int tt = 0; tt < cnt; tt++) {
+                const int s = __builtin_amdgcn_readfirstlane(sl[tt]);
 #pragma unroll
-                    for (int q = 0; q < ST; q++)
-                        if (s == q) acc[q][k] += v;
+                for (int k = 0; k < SPL; k++) {
+                    const int slot = lane + 64 * k;
+                    if (SPL * 64 == NSLOT || slot < NSLOT) {
+                        const double v = fl[tt * N1 + slot / LL] * Yl[tt * LLP + slot % LL];
+#pragma unroll
+                        for (int q = 0; q < ST; q++)
+                            if (s == q) acc[q][k] += v;
+                    }
                 }
             }
         }
