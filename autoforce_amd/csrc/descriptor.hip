@@ -351,33 +351,47 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
             }
         }
     wave_sync();
-    // packed power spectrum: entry e=(u<=v,l): coef * sum_{lm in l} c[u][lm] c[v][lm]
+    // packed power spectrum: entry e = pair(u<=v)*L1 + l : coef * sum_{lm in l} c[u][lm] c[v][lm].
+    // One lane per (u,v) pair, the l shells and their m sums statically unrolled (offsets into the
+    // two LDS rows are compile-time constants; the per-entry form spent most of its instructions on
+    // index arithmetic and a dynamic m loop).
     double nrm2 = 0.0;
+    constexpr int L1 = LMAX + 1;
     constexpr int UMAX = ST * N1;
-    constexpr int MAXE = ((UMAX * (UMAX + 1)) / 2 * (LMAX + 1) + 8 + 63) / 64;  // covers Dpad
-    double pv[MAXE];
+    constexpr int MAXP = ((UMAX * (UMAX + 1)) / 2 + 63) / 64;
+    const int npair = a.Dc / L1;
+    double pv[MAXP][L1];
 #pragma unroll
-    for (int k = 0; k < MAXE; k++) {
-        const int e = lane + 64 * k;
-        pv[k] = 0.0;
-        if (e < a.Dc) {
-            const PackEntry pe = a.pack[e];
-            const double *cu = cl + (pe.u / N1) * NSLOT + (pe.u % N1) * LL + pe.l * pe.l;
-            const double *cv = cl + (pe.v / N1) * NSLOT + (pe.v % N1) * LL + pe.l * pe.l;
-            double sacc = 0.0;
-            for (int mm = 0; mm < 2 * pe.l + 1; mm++) sacc += cu[mm] * cv[mm];
-            pv[k] = sacc * pe.coef;
-            nrm2 += pv[k] * pv[k];
+    for (int k = 0; k < MAXP; k++) {
+        const int pr = lane + 64 * k;
+#pragma unroll
+        for (int l = 0; l < L1; l++) pv[k][l] = 0.0;
+        if (pr < npair) {
+            const PackEntry p0 = a.pack[pr * L1];
+            const double *cu = cl + (p0.u / N1) * NSLOT + (p0.u % N1) * LL;
+            const double *cv = cl + (p0.v / N1) * NSLOT + (p0.v % N1) * LL;
+#pragma unroll
+            for (int l = 0; l < L1; l++) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int mm = 0; mm < 2 * l + 1; mm++) sacc += cu[l * l + mm] * cv[l * l + mm];
+                pv[k][l] = sacc * a.pack[pr * L1 + l].coef;
+                nrm2 += pv[k][l] * pv[k][l];
+            }
         }
     }
     nrm2 = wave_sum(nrm2);
     const double nrm = sqrt(nrm2);
     const double inv = nn > 0 ? 1.0 / (nrm + SGPR_EPS) : 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXE; k++) {
-        const int e = lane + 64 * k;
-        if (e < a.Dpad) a.Pn[(size_t)ia * a.Dpad + e] = e < a.Dc ? pv[k] * inv : 0.0;
+    for (int k = 0; k < MAXP; k++) {
+        const int pr = lane + 64 * k;
+        if (pr < npair) {
+#pragma unroll
+            for (int l = 0; l < L1; l++) a.Pn[(size_t)ia * a.Dpad + pr * L1 + l] = pv[k][l] * inv;
+        }
     }
+    for (int e = a.Dc + lane; e < a.Dpad; e += 64) a.Pn[(size_t)ia * a.Dpad + e] = 0.0;
     if (lane == 0) {
         a.norm[ia] = nn > 0 ? nrm : 0.0;
         if (a.shear) a.shear[ia] = shear ? 1 : 0;
