@@ -194,11 +194,14 @@ __device__ __forceinline__ void load_neighbor(const DescArgs &a, int gi, int ia,
 template <int NMAX>
 __device__ __forceinline__ void radial(double d, double u, double rc, double *f, double &g, double &dg)
 {
+    // reciprocals instead of fp64 divisions (each is a ~12-instruction sequence on the VALU): the
+    // pair term had 14 of them per evaluation
     const double ud = u * d;
+    const double irc = 1.0 / rc;  // wave-uniform
     const double step = ud < rc ? 1.0 : 0.0;
-    const double qq = 1.0 - ud / rc;
+    const double qq = 1.0 - ud * irc;
     const double cut = step * qq * qq;
-    const double dcut = step * (-2.0 * qq / rc) * u;
+    const double dcut = step * (-2.0 * qq * irc) * u;
     const double ex = exp(-0.5 * d * d);
     g = cut * ex;
     dg = dcut * ex - d * g;
@@ -278,7 +281,8 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         int s = 0, j = 0;
         if (t < nn) load_neighbor<ENV>(a, gi, ia, t, pi, cell, r, s, j);
         const double u = unit_of<ST>(a, s);
-        const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
+        const double iu = 1.0 / u;
+        const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
         if (nn <= 64) {
             const double tol = SGPR_TINY_ANGLE * fabs(z);
             shear = __any(t < nn && fabs(x) < tol && fabs(y) < tol);
@@ -498,8 +502,10 @@ __device__ __forceinline__ void pair_grad(const double r[3], double u, double rc
                                           double gr[3])
 {
     constexpr int N1 = NMAX + 1, LL = (LMAX + 1) * (LMAX + 1);
-    const double x = r[0] / u, y = r[1] / u, z = r[2] / u;
+    const double iu = 1.0 / u;
+    const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
     const double d = sqrt(x * x + y * y + z * z);
+    const double id = 1.0 / d;
     double f[N1], g, dg;
     radial<NMAX>(d, u, rc, f, g, dg);
     double Y[LL], gY[LL];
@@ -524,16 +530,17 @@ __device__ __forceinline__ void pair_grad(const double r[3], double u, double rc
             gY[k] += fn * dck;
         }
         // d f_n/dd = dg rho^n + g 2n d^(2n-1)
-        const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow / d : 0.0);
+        const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow * id : 0.0);
         dEdd += dEdf * dfn;
         rpow *= rho;
     }
     double gxs, gys, gzs;
     h.backward(gY, gxs, gys, gzs);
     // inverse shear (ylm.py:203-213) + radial part, then 1/u
-    gr[0] = (gxs + dEdd * x / d) / u;
-    gr[1] = (gys + ang * gzs + dEdd * y / d) / u;
-    gr[2] = (-ang * gys + gzs + dEdd * z / d) / u;
+    const double rad = dEdd * id;
+    gr[0] = (gxs + rad * x) * iu;
+    gr[1] = (gys + ang * gzs + rad * y) * iu;
+    gr[2] = (-ang * gys + gzs + rad * z) * iu;
 }
 
 // PASS 0: own terms + atomic scatter (sharded form); 3: own then mirrored terms in one launch (the
