@@ -235,28 +235,52 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // bitonic sort of the first min(base, NL_SORT_MAX) keys in LDS, then coalesced write-out
+    // bitonic sort of the first min(base, NL_SORT_MAX) keys, then coalesced write-out.  Up to 64 keys
+    // (the usual case) sort in registers, one key per lane, partners by cross-lane shuffle: a third of
+    // the instructions of the LDS network below and no barriers.
     const int ns = min(base, NL_SORT_MAX);
-    int np2 = 1;
-    while (np2 < ns) np2 <<= 1;
-    for (int t = ns + lane; t < np2; t += 64) keys[t] = ~0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int k2 = 2; k2 <= np2; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = lane; t < np2; t += 64) {
-                const int p = t ^ j2;
-                if (p > t) {
-                    const unsigned long long a0 = keys[t], a1 = keys[p];
-                    const bool up = (t & k2) == 0;
-                    if ((a0 > a1) == up) { keys[t] = a1; keys[p] = a0; }
-                }
+    if (ns <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long key = lane < ns ? keys[lane] : ~0ull;
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1)
+#pragma unroll
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)key, j2, 64), hi = __shfl_xor((unsigned)(key >> 32), j2, 64);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                const bool lower = (lane & j2) == 0, up = (lane & k2) == 0;
+                // the lower lane of a pair keeps the smaller key in an ascending block
+                const bool take_min = lower == up;
+                key = take_min ? (other < key ? other : key) : (other > key ? other : key);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+        if (lane < ns) keys[lane] = key;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        int np2 = 1;
+        while (np2 < ns) np2 <<= 1;
+        for (int t = ns + lane; t < np2; t += 64) keys[t] = ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k2 = 2; k2 <= np2; k2 <<= 1)
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (int t = lane; t < np2; t += 64) {
+                    const int p = t ^ j2;
+                    if (p > t) {
+                        const unsigned long long a0 = keys[t], a1 = keys[p];
+                        const bool up = (t & k2) == 0;
+                        if ((a0 > a1) == up) { keys[t] = a1; keys[p] = a0; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+    }
     for (int t = lane; t < ns && t < maxnn; t += 64) {
         const unsigned long long key = keys[t];
         const unsigned code = (unsigned)key;
