@@ -205,35 +205,45 @@ class ActiveCalculator(Calculator):
         return (np.asarray(atoms.numbers, dtype=np.int32), np.asarray(atoms.positions, dtype=float), cell,
                 np.asarray(atoms.pbc, dtype=bool))
 
+    def _evaluate_engine(self, engine):
+        """One device pass of `engine` over the current atoms (sharded + all-reduced when a process
+        group is attached): dict(energy, forces, stress, beta, cov)."""
+        numbers, positions, cell, pbc = self._system(self.atoms)
+        N = len(numbers)
+        rank, world = self._dist()
+        if not (engine.m > 0 and engine.mu is not None):
+            # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
+            return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf),
+                        cov=np.zeros((N, 0)))
+        out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=True, beta=True)
+        cov = out["cov"]
+        if world > 1:
+            import torch.distributed as dist
+            v = self._tensor(pack_partial(out, N))
+            dist.all_reduce(v, group=self.process_group)  # active.py:562,601,602,777 in one collective
+            out = unpack_total(v.cpu().numpy(), N)
+            out["cov"] = cov
+        return out
+
     def update_results(self, retain_graph=False, covloss_only=False):
         """active.py:548-611 + :781-804 in one device pass: E, F, stress, covloss, cov.
         covloss_only: refresh `cov` and the covloss after the model changed but leave `results`
         alone — inside update_inducing the reference extends cov by a column and keeps the
         pre-update predictions, which update_data then offers as 'fake' labels."""
-        numbers, positions, cell, pbc = self._system(self.atoms)
-        N = len(numbers)
-        rank, world = self._dist()
-        ready = self.engine.m > 0 and self.engine.mu is not None
-        if not ready:
-            # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
-            out = dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf),
-                       cov=np.zeros((N, 0)))
-        else:
-            out = self.engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=True, beta=True)
+        out = self._evaluate_engine(self.engine)
+        if out["cov"].shape[1]:
             self.cov = out["cov"]
-            if world > 1:
-                import torch.distributed as dist
-                v = self._tensor(pack_partial(out, N))
-                dist.all_reduce(v, group=self.process_group)  # active.py:562,601,602,777 in one collective
-                out = unpack_total(v.cpu().numpy(), N)
         self._nl = None
         self._beta = out["beta"]
         if covloss_only:
             return
+        self._set_results(out)
+
+    def _set_results(self, out):
         self.results["energy"] = np.asarray(out["energy"])
         self.results["forces"] = np.asarray(out["forces"])
         self.results["stress"] = np.asarray(out["stress"])
-        self.maximum_force = float(np.abs(self.results["forces"]).max()) if N else 0.0
+        self.maximum_force = float(np.abs(self.results["forces"]).max()) if len(self.atoms) else 0.0
 
     def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
         timings = [time.time()]
@@ -242,7 +252,7 @@ class ActiveCalculator(Calculator):
         Calculator.calculate(self, atoms, properties, system_changes)
         self.maximum_force = inf
         timings.append(time.time())
-        if self.step == 0 and self.active and self.model.ndata == 0:
+        if self._needs_seed():
             self.initiate_model()
             self._update_args = dict(data=False)
         timings.append(time.time())
@@ -268,6 +278,9 @@ class ActiveCalculator(Calculator):
                 ase.io.Trajectory("active_uncertain.traj", "a").write(tmp)
         timings.append(time.time())
         self.post_calculate(timings)
+
+    def _needs_seed(self):
+        return self.step == 0 and self.active and self.model.ndata == 0  # active.py:458-461
 
     def post_calculate(self, timings):
         """active.py:504-535."""

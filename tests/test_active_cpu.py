@@ -288,3 +288,53 @@ def test_learning_loop_world2_gloo(tmp_path):
         np.testing.assert_allclose(energies, [t[1] for t in ref], rtol=0, atol=1e-8)
         np.testing.assert_allclose(forces, ref[-1][2], rtol=0, atol=1e-8)
     np.testing.assert_array_equal(got[0][4], got[1][4])
+
+
+def test_bcm_committee(tmp_path):
+    """active_bcm.py:589-633, :885-894: weights from each member's worst covloss, member-wise
+    minimum as the sampling uncertainty, initiate_bcm freezes the live model."""
+    from autoforce_amd.calculator_bcm import BCMActiveCalculator
+    (tmp_path / "a").mkdir()
+    calc_a, teacher, tr_a = ac.run(engine(), tmp_path / "a", steps=3, tape=False)
+    (tmp_path / "b").mkdir()
+    calc_b, _, tr_b = ac.run(engine(), tmp_path / "b", steps=3, seed=3, tape=False)
+    at = tr_a[-1][5]
+    probe = lambda: Atoms(at.numbers, at.positions, at.cell, True)  # noqa: E731
+    outs = []
+    for c in (calc_a, calc_b):
+        p = probe()
+        p.calc = ActiveCalculator(covariance=c.model, logfile=None)
+        outs.append((p.get_potential_energy(), p.get_forces(), p.get_stress(), p.calc.get_covloss().copy()))
+    bcm = BCMActiveCalculator(covariance=calc_b.model, kernel_model_dict={"a": calc_a.model}, logfile=None)
+    p = probe()
+    p.calc = bcm
+    e, f, s = p.get_potential_energy(), p.get_forces(), p.get_stress()
+    scale = []
+    for o in outs:
+        cm = o[3].max()
+        scale.append((-np.log(cm) if cm < 1 else 0.0) / cm)
+    w = np.array(scale) / np.sum(scale)
+    assert abs(e - (w[0] * outs[0][0] + w[1] * outs[1][0])) < 1e-12
+    np.testing.assert_allclose(f, w[0] * outs[0][1] + w[1] * outs[1][1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(s, w[0] * outs[0][2] + w[1] * outs[1][2], rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(bcm.get_covloss_total(), np.minimum(outs[0][3], outs[1][3]))
+    # model a saw this frame: it carries the larger weight
+    assert bcm.bcm_weights["a"] > bcm.bcm_weights["live"]
+    # a learning committee: freeze the live model, the next frame seeds a new member
+    (tmp_path / "c").mkdir()
+    live = BCMActiveCalculator(engine=engine(), calculator=teacher, logfile=str(tmp_path / "c" / "active.log"),
+                               pckl=str(tmp_path / "c" / "model"), tape=str(tmp_path / "c" / "model"), **ac.KW)
+    p = probe()
+    p.calc = live
+    p.get_forces()
+    assert live.size[0] == 1 and os.path.isfile(tmp_path / "c" / "model_1.npz")
+    live.initiate_bcm()
+    assert live.size == (0, 0) and len(live.model_dict) == 1
+    q = Atoms(at.numbers, at.positions + 0.05, at.cell, True)
+    q.calc = live
+    q.get_forces()
+    assert live.size[0] == 1 and os.path.isfile(tmp_path / "c" / "model_2.npz")
+    assert os.path.isfile(tmp_path / "c" / "model_2.sgpr") and set(live.bcm_weights) == {str(tmp_path / "c" / "model_1"), "live"}
+    # restart: members on disk are picked up again
+    again = BCMActiveCalculator(engine=engine(), logfile=None, pckl=str(tmp_path / "c" / "model"), member_engine=engine)
+    assert again.pckl_id == 2 and len(again.model_dict) == 1

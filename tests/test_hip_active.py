@@ -114,3 +114,27 @@ def test_saved_learner_resumes(tmp_path):
     probe = Atoms(at.numbers, at.positions, at.cell, True)
     probe.calc = c2
     np.testing.assert_allclose(probe.get_forces(), trace[-1][2], rtol=0, atol=1e-10)
+
+
+def test_bcm_committee_on_device(tmp_path):
+    """Two members trained on different trajectories, combined on the device with the weights of
+    active_bcm.py:589-633; agrees with the same committee built on the oracle engine."""
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator_bcm import BCMActiveCalculator
+    from helpers import OracleModel
+    res = {}
+    for tag, make in (("hip", hip_engine), ("cpu", lambda: OracleModel(3, 3, 4, 4.5, species=ac.SPECIES))):
+        (tmp_path / (tag + "a")).mkdir()
+        (tmp_path / (tag + "b")).mkdir()
+        ca, _, tra = ac.run(make(), tmp_path / (tag + "a"), steps=3, tape=False)
+        cb, _, _ = ac.run(make(), tmp_path / (tag + "b"), steps=3, seed=3, tape=False)
+        at = tra[-1][5]
+        bcm = BCMActiveCalculator(covariance=cb.model, kernel_model_dict={"a": ca.model}, logfile=None)
+        p = Atoms(at.numbers, at.positions, at.cell, True)
+        p.calc = bcm
+        res[tag] = (p.get_potential_energy(), p.get_forces(), bcm.get_covloss_total(), bcm.bcm_weights)
+    assert abs(res["hip"][0] - res["cpu"][0]) < 1e-6
+    assert np.abs(res["hip"][1] - res["cpu"][1]).max() < 1e-6
+    np.testing.assert_allclose(res["hip"][2], res["cpu"][2], rtol=0, atol=1e-5)
+    for k in res["hip"][3]:
+        assert abs(res["hip"][3][k] - res["cpu"][3][k]) < 1e-5
