@@ -428,6 +428,78 @@ __global__ __launch_bounds__(256) void qr_panel_update_kernel(QrPanel q, int j)
     if ((tid & 63) == 0 && nxt != 0.0) unsafeAtomicAdd(&q.nrm2[j + 1], nxt);
 }
 
+// Panel factorisation of a SHORT matrix (the 2m x m second stage of the solve) by ONE workgroup with
+// the whole panel in LDS: no launches and no global reductions between the column steps.
+// 16 waves; wave w owns panel column w for the dot product with v_j and its own rank-1 update, so a
+// column step needs two workgroup barriers (norm of the pivot column, then v_j visible to all).
+#define QNBL 16
+__global__ __launch_bounds__(1024) void qr_panel_lds_kernel(QrPanel q)
+{
+    extern __shared__ double sm[];  // [nb <= QNBL][rl]
+    __shared__ double s_red[16], s_alpha[QNBL], s_scal[QNBL];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int k0 = q.k0, nb = q.nb, rl = q.rows - k0;
+    for (int c = wave; c < nb; c += 16)
+        for (int i = lane; i < rl; i += 64) sm[c * rl + i] = q.At[(size_t)(k0 + c) * q.ldr + k0 + i];
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        // |a_j|^2 over rows >= j, by all threads
+        double s = 0.0;
+        for (int i = j + tid; i < rl; i += 1024) {
+            const double a = sm[j * rl + i];
+            s += a * a;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) s_red[wave] = s;
+        __syncthreads();
+        double s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) s2 += s_red[w];
+        const double akk = sm[j * rl + j];
+        const double nrm = sqrt(s2);
+        const double alpha = akk > 0.0 ? -nrm : nrm;
+        const double vv = s2 - akk * akk + (akk - alpha) * (akk - alpha);
+        const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
+        __syncthreads();  // everyone has read sm[j][j] and s_red
+        if (tid == 0) {
+            sm[j * rl + j] = akk - alpha;  // v_j[j]
+            s_alpha[j] = alpha;
+            s_scal[j] = sc;
+        }
+        __syncthreads();
+        // wave c: g = v_j . (column c for c > j | v_c for c < j); the later columns are updated in place
+        for (int c = wave; c < nb; c += 16) {
+            if (c == j) continue;
+            double g = 0.0;
+            for (int i = j + lane; i < rl; i += 64) g += sm[j * rl + i] * sm[c * rl + i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, 64);
+            if (lane == 0) q.G[j * QNB + c] = g;
+            if (c > j) {
+                const double f = sc * g;
+                for (int i = j + lane; i < rl; i += 64) sm[c * rl + i] -= f * sm[j * rl + i];
+            }
+        }
+        __syncthreads();
+    }
+    // write back: R entries above the diagonals and alpha on them, reflectors into Vt / Vrm
+    for (int c = wave; c < nb; c += 16) {
+        for (int i = lane; i < rl; i += 64) {
+            const double v = sm[c * rl + i];
+            if (i < c) q.At[(size_t)(k0 + c) * q.ldr + k0 + i] = v;
+            else {
+                q.Vt[(size_t)c * q.ldr + k0 + i] = v;
+                q.Vrm[(size_t)(k0 + i) * QNB + c] = v;
+            }
+        }
+        if (lane == 0) {
+            q.At[(size_t)(k0 + c) * q.ldr + k0 + c] = s_alpha[c];
+            q.scal[c] = s_scal[c];
+        }
+    }
+}
+
 // T (upper triangular, Q = I - V T V^T) from scal and the v.v products in G; then clears G.
 __global__ __launch_bounds__(64) void qr_panel_T_kernel(QrPanel q, double *T)
 {
@@ -496,8 +568,16 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
     struct Span { size_t w0, wn, u0, un; };
     std::vector<Span> span;
     const int KSPLIT = 1024;
-    for (int k0 = 0; k0 < cols; k0 += QNB) {
-        const int ntrail = cols + 1 - (k0 + std::min(QNB, cols - k0));
+    // short matrices: 16-column panels factored by one workgroup in LDS (the panel must fit 144 KB)
+    int PNB = QNB;
+    for (int w = QNBL; w >= 8; w >>= 1)
+        if ((size_t)rows * w * sizeof(double) <= 144 * 1024) { PNB = w; break; }
+    const bool lds_panels = PNB != QNB;
+    if (lds_panels)
+        (void)hipFuncSetAttribute((const void *)qr_panel_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  rows * PNB * (int)sizeof(double));
+    for (int k0 = 0; k0 < cols; k0 += PNB) {
+        const int ntrail = cols + 1 - (k0 + std::min(PNB, cols - k0));
         Span sp = {tiles.size(), 0, 0, 0};
         if (ntrail > 0) {
             const int ctl = (ntrail + 63) / 64;
@@ -518,17 +598,21 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
         (void)hipMemcpyAsync(d_tiles, tiles.data(), sizeof(int4) * tiles.size(), hipMemcpyHostToDevice, st);
     }
     int pi = 0;
-    for (int k0 = 0; k0 < cols; k0 += QNB, pi++) {
+    for (int k0 = 0; k0 < cols; k0 += PNB, pi++) {
         q.k0 = k0;
-        q.nb = std::min(QNB, cols - k0);
+        q.nb = std::min(PNB, cols - k0);
         (void)hipMemsetAsync(q.Vt, 0, sizeof(double) * 2 * (size_t)QNB * ldr, st);  // Vt and Vrm
         (void)hipMemsetAsync(q.G, 0, sizeof(double) * (2 * QNB * QNB + 2 * QNB + 8), st);  // G, T, scal, nrm2
-        const int nwg0 = (rows - k0 + QCH - 1) / QCH;
-        hipLaunchKernelGGL(qr_colnorm_kernel, dim3(nwg0), dim3(256), 0, st, q, 0);
-        for (int j = 0; j < q.nb; j++) {
-            const int nwg = (ldr - (k0 + j) + QCH - 1) / QCH;
-            hipLaunchKernelGGL(qr_panel_dots_kernel, dim3(nwg), dim3(256), 0, st, q, j);
-            hipLaunchKernelGGL(qr_panel_update_kernel, dim3(nwg), dim3(256), 0, st, q, j);
+        if (lds_panels) {
+            hipLaunchKernelGGL(qr_panel_lds_kernel, dim3(1), dim3(1024), (size_t)(rows - k0) * PNB * sizeof(double), st, q);
+        } else {
+            const int nwg0 = (rows - k0 + QCH - 1) / QCH;
+            hipLaunchKernelGGL(qr_colnorm_kernel, dim3(nwg0), dim3(256), 0, st, q, 0);
+            for (int j = 0; j < q.nb; j++) {
+                const int nwg = (ldr - (k0 + j) + QCH - 1) / QCH;
+                hipLaunchKernelGGL(qr_panel_dots_kernel, dim3(nwg), dim3(256), 0, st, q, j);
+                hipLaunchKernelGGL(qr_panel_update_kernel, dim3(nwg), dim3(256), 0, st, q, j);
+            }
         }
         const int ntrail = cols + 1 - (k0 + q.nb);
         if (ntrail <= 0) continue;
