@@ -442,29 +442,80 @@ __global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
         return;
     }
     const double sden = nrm + SGPR_EPS;
-    // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
+    constexpr int MAXE = ((UT * (UT + 1)) / 2 * L1 + 63) / 64;
     const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
-    double pw = 0.0;
-    for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
-    pw = wave_sum(pw);
-    const double corr = pw * sden / nrm;
-    for (int e = lane; e < a.Dc; e += 64) {
-        const PackEntry pe = a.pack[e];
-        const double gv = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
-        if constexpr (EXPAND) {
-            gl[(pe.u * UT + pe.v) * L1 + pe.l] = gv;
-            gl[(pe.v * UT + pe.u) * L1 + pe.l] = gv;
-        } else
-            gl[e] = gv;
-    }
-#pragma unroll
-    for (int s = 0; s < ST; s++)
-#pragma unroll
-        for (int k = 0; k < SPL; k++) {
-            const int slot = lane + 64 * k;
-            if (SPL * 64 == NSLOT || slot < NSLOT)
-                cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+    if constexpr (MAXE <= 10) {
+        // all global reads of this atom are issued up front (W, p^, pack entries, c): one memory
+        // latency instead of three dependent ones
+        double wv[MAXE], pv[MAXE];
+        PackEntry pe[MAXE];
+    #pragma unroll
+        for (int k = 0; k < MAXE; k++) {
+            const int e = lane + 64 * k;
+            const bool in = e < a.Dc;
+            wv[k] = in ? Wi[e] : 0.0;
+            pv[k] = in ? Pi[e] : 0.0;
+            pe[k] = a.pack[in ? e : 0];
         }
+        double cin[ST][SPL];
+    #pragma unroll
+        for (int s = 0; s < ST; s++)
+    #pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                cin[s][k] = (s < a.S && (SPL * 64 == NSLOT || slot < NSLOT)) ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+            }
+        // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
+        double pw = 0.0;
+    #pragma unroll
+        for (int k = 0; k < MAXE; k++) pw += wv[k] * pv[k];
+        pw = wave_sum(pw);
+        const double corr = pw * sden / nrm;
+        const double isden = 1.0 / sden;
+    #pragma unroll
+        for (int k = 0; k < MAXE; k++) {
+            const int e = lane + 64 * k;
+            if (e < a.Dc) {
+                const double gv = (wv[k] - pv[k] * corr) * isden * pe[k].coef * (pe[k].u == pe[k].v ? 2.0 : 1.0);
+                if constexpr (EXPAND) {
+                    gl[(pe[k].u * UT + pe[k].v) * L1 + pe[k].l] = gv;
+                    gl[(pe[k].v * UT + pe[k].u) * L1 + pe[k].l] = gv;
+                } else
+                    gl[e] = gv;
+            }
+        }
+    #pragma unroll
+        for (int s = 0; s < ST; s++)
+    #pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                if (SPL * 64 == NSLOT || slot < NSLOT) cl[s * NSLOT + slot] = cin[s][k];
+            }
+
+    } else {
+        // many species / high lmax: too many entries per lane to hold in registers
+        double pw = 0.0;
+        for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
+        pw = wave_sum(pw);
+        const double corr = pw * sden / nrm;
+        for (int e = lane; e < a.Dc; e += 64) {
+            const PackEntry pe = a.pack[e];
+            const double gv = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+            if constexpr (EXPAND) {
+                gl[(pe.u * UT + pe.v) * L1 + pe.l] = gv;
+                gl[(pe.v * UT + pe.u) * L1 + pe.l] = gv;
+            } else
+                gl[e] = gv;
+        }
+#pragma unroll
+        for (int s = 0; s < ST; s++)
+#pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                if (SPL * 64 == NSLOT || slot < NSLOT)
+                    cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+            }
+    }
     wave_sync();
     // dE/dc[u][lm] = sum_v G[u][v][l] c[v][lm]
 #pragma unroll
