@@ -594,6 +594,82 @@ __device__ __forceinline__ void pair_grad(const double r[3], double u, double rc
     gr[2] = (-ang * gys + gzs + rad * z) * iu;
 }
 
+// The mirrored pass of desc_pair_kernel: as pair_grad, with the coefficient rows of the 64 lanes'
+// neighbours (dC[j][slot][n][:], one row per lane) gathered cooperatively — GR lanes per row, whole
+// cache lines per group of lanes — one radial channel at a time, and SOFTWARE-PIPELINED: channel
+// n+1 is in flight in registers while channel n is contracted out of LDS.  (As a lambda capturing
+// the register array this ended in scratch; here the array is a local of the function that owns
+// the rolled loop.)
+template <int LMAX, int NMAX>
+__device__ __forceinline__ void pair_grad_gathered(const double r[3], double u, double rc, double ang,
+                                                   const double *dC, int CS, int chan_off /*slot*NSLOT*/, int j,
+                                                   double *stage, int lane, double gr[3])
+{
+    constexpr int N1 = NMAX + 1, LL = (LMAX + 1) * (LMAX + 1);
+    constexpr int SP = LL + 2, G = (LL % 2 == 0) ? 2 : 1, GR = LL / G;
+    const double iu = 1.0 / u;
+    const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
+    const double d = sqrt(x * x + y * y + z * z);
+    const double id = 1.0 / d;
+    double f[N1], g, dg;
+    radial<NMAX>(d, u, rc, f, g, dg);
+    double Y[LL], gY[LL];
+    Harm<LMAX> h;
+    h.eval(x, y - ang * z, ang * y + z, Y);
+    double dEdd = 0.0;
+#pragma unroll
+    for (int k = 0; k < LL; k++) gY[k] = 0.0;
+    const double rho = d * d;
+    double rpow = 1.0;
+    double pre[GR][G];
+#define SGPR_GATHER(N)                                                                           \
+    _Pragma("unroll") for (int q = 0; q < GR; q++) {                                            \
+        const int idx = q * 64 + lane;                                                          \
+        const int jr = __shfl(j, idx / GR, 64);                                                 \
+        const double *src = dC + (size_t)jr * CS + chan_off + (N) * LL + (idx % GR) * G;         \
+        if constexpr (G == 2) {                                                                 \
+            const double2 t2 = *(const double2 *)src;                                           \
+            pre[q][0] = t2.x; pre[q][G - 1] = t2.y;                                             \
+        } else                                                                                  \
+            pre[q][0] = *src;                                                                   \
+    }
+    SGPR_GATHER(0)
+#pragma unroll 1
+    for (int n = 0; n < N1; n++) {
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < GR; q++) {
+            const int idx = q * 64 + lane;
+            double *dst = stage + (idx / GR) * SP + (idx % GR) * G;
+            if constexpr (G == 2)
+                *(double2 *)dst = make_double2(pre[q][0], pre[q][G - 1]);
+            else
+                *dst = pre[q][0];
+        }
+        wave_sync();
+        if (n + 1 < N1) { SGPR_GATHER(n + 1) }
+        const double *dcn = stage + lane * SP;
+        const double fn = g * rpow;
+        double dEdf = 0.0;
+#pragma unroll
+        for (int k = 0; k < LL; k++) {
+            const double dck = dcn[k];
+            dEdf += dck * Y[k];
+            gY[k] += fn * dck;
+        }
+        const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow * id : 0.0);
+        dEdd += dEdf * dfn;
+        rpow *= rho;
+    }
+#undef SGPR_GATHER
+    double gxs, gys, gzs;
+    h.backward(gY, gxs, gys, gzs);
+    const double rad = dEdd * id;
+    gr[0] = (gxs + rad * x) * iu;
+    gr[1] = (gys + ang * gzs + rad * y) * iu;
+    gr[2] = (-ang * gys + gzs + rad * z) * iu;
+}
+
 // PASS 0: own terms + atomic scatter (sharded form); 3: own then mirrored terms in one launch (the
 // single-process form); 1 / 2: the two halves as separate launches (measured 17.5 + 17.5 us against
 // 29.8 us fused: both halves still need ~220 VGPRs, so splitting buys no occupancy).
@@ -670,23 +746,7 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
                     r[0] = -r[0]; r[1] = -r[1]; r[2] = -r[2];
                 }
                 const double angm = a.shear[j] ? SGPR_TINY_ANGLE : 0.0;
-                auto fetch_mirror = [&](int n) {
-                    wave_sync();
-#pragma unroll
-                    for (int q = 0; q < GR; q++) {
-                        const int idx = q * 64 + lane;
-                        const int row = idx / GR, gc = idx % GR;
-                        const int jr = __shfl(j, row, 64);
-                        const double *src = a.dC + (size_t)jr * a.CS + sc * NSLOT + n * LL + gc * G;
-                        if constexpr (G == 2)
-                            *(double2 *)(stage + row * SP + gc * 2) = *(const double2 *)src;
-                        else
-                            stage[row * SP + gc] = *src;
-                    }
-                    wave_sync();
-                    return (const double *)(stage + lane * SP);
-                };
-                pair_grad<LMAX, NMAX>(r, uc, a.rc, angm, fetch_mirror, gm);
+                pair_grad_gathered<LMAX, NMAX>(r, uc, a.rc, angm, a.dC, a.CS, sc * NSLOT, j, stage, lane, gm);
                 if (on) {
 #pragma unroll
                     for (int k = 0; k < 3; k++) fsum[k] -= gm[k];
