@@ -436,6 +436,10 @@ static int build_tiles(sgpr_model *h, int kind)
             if (t.w > t.z) bk[t.x % 8].push_back(t);
         for (const int4 &t : h->h_t_cov)
             if (t.w > t.z) bk[t.x % 8].push_back(make_int4(t.x | (1 << 16), t.y, t.z, t.w));
+        // longest reductions first (LPT): row tiles come in species order and the species with the most
+        // inducing points — the deepest reductions — would otherwise form the tail of the launch
+        for (auto &b : bk)
+            std::stable_sort(b.begin(), b.end(), [](const int4 &p, const int4 &q) { return p.w - p.z > q.w - q.z; });
         size_t dp = 0;
         for (auto &b : bk) dp = std::max(dp, b.size());
         std::vector<int4> both(dp * 8, make_int4(0, 0, 0, 0));
