@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
     __shared__ double vred[4][9];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ia = blockIdx.x * 4 + wave;
-    double *dcl = smem + (size_t)wave * (ST * NSLOT + 64 * SP + 9 * 64);  // [S][NSLOT] dE/dc of this atom
+    double *dcl = smem + (size_t)wave * (ST * NSLOT + 64 * SP + 12 * 64);  // [S][NSLOT] dE/dc of this atom
     double *stage = dcl + ST * NSLOT;                            // [64][SP] one channel of 64 mirrored rows
     double *lv = stage + 64 * SP;                                // [9][64] per-lane virial accumulators
 #pragma unroll
@@ -754,25 +754,35 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) fsum[k] = wave_sum(fsum[k]);
     if constexpr (PASS == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) fsum[k] = wave_sum(fsum[k]);
         // mirrored half: subtract from the forces the own-term launch stored (same wave owns the atom)
         if (lane == 0 && active)
 #pragma unroll
             for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] += fsum[k];
         return;
     }
-    double vir[9];
+    // 12 wave sums (force 3 + virial 9) through LDS: the per-lane virial terms already live there as
+    // [9][64]; the force terms join as rows 9..11, then 48 lanes each add a quarter of a row and two
+    // shuffles finish it (12 x 6 shuffle steps on 64-bit values were 144 ds_bpermute per wave)
 #pragma unroll
-    for (int k = 0; k < 9; k++) vir[k] = wave_sum(lv[k * 64 + lane]);
-    // one virial partial per workgroup: the 4 waves meet in LDS (all waves reach this point)
-    if (lane == 0) {
-        if (active)
+    for (int k = 0; k < 3; k++) lv[(9 + k) * 64 + lane] = fsum[k];
+    wave_sync();
+    {
+        const int k = lane >> 2, part = lane & 3;
+        double sacc = 0.0;
+        if (lane < 48) {
+            const double *src = lv + k * 64 + part * 16;
 #pragma unroll
-            for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] = fsum[k];
-#pragma unroll
-        for (int k = 0; k < 9; k++) vred[wave][k] = vir[k];
+            for (int i = 0; i < 16; i++) sacc += src[i];
+        }
+        sacc += __shfl_xor(sacc, 1, 64);
+        sacc += __shfl_xor(sacc, 2, 64);
+        if (lane < 48 && part == 0) {
+            if (k < 9) vred[wave][k] = sacc;
+            else if (active) a.Fself[3 * (size_t)gi + (k - 9)] = sacc;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 9)
@@ -841,7 +851,7 @@ static int run_bwd(const DescArgs &a, hipStream_t st)
     }
     if (a.phase != 2) hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
     if (a.phase == 1) return 0;
-    const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + 64 * (WL::LL + 2) + 9 * 64);
+    const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + 64 * (WL::LL + 2) + 12 * 64);
     if (a.stride == 1 && a.first == 0 && a.N == a.Nall) {
         hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, 3>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
     } else
