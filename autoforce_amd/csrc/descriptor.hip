@@ -671,8 +671,8 @@ __device__ __forceinline__ void pair_grad_gathered(const double r[3], double u, 
 }
 
 // PASS 0: own terms + atomic scatter (sharded form); 3: own then mirrored terms in one launch (the
-// single-process form); 1 / 2: the two halves as separate launches (measured 17.5 + 17.5 us against
-// 29.8 us fused: both halves still need ~220 VGPRs, so splitting buys no occupancy).
+// single-process form).  (The two halves as separate launches measured 17.5 + 17.5 us against 29.8 us
+// fused: both halves still need ~220 VGPRs, so splitting buys no occupancy.)
 template <int LMAX, int NMAX, int ST, int PASS>
 __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
 {
@@ -694,11 +694,9 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
     const bool active = ia < a.N;
     const int gi = a.first + (active ? ia : 0) * a.stride;
     const int nn = active ? a.nn[gi] : 0;
-    constexpr bool MIRROR = PASS == 2 || PASS == 3;
+    constexpr bool MIRROR = PASS == 3;
     if (active && nn > 0) {
-        if (PASS != 2) {
-            for (int k = lane; k < a.CS; k += 64) dcl[k] = a.dC[(size_t)ia * a.CS + k];
-        }
+        for (int k = lane; k < a.CS; k += 64) dcl[k] = a.dC[(size_t)ia * a.CS + k];
         wave_sync();
         const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
         const int sc = a.slot[gi];
@@ -709,7 +707,6 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
 #pragma unroll
         for (int k = 0; k < 9; k++) cell[k] = uniform(a.cell[k]);
         // pass 1: own terms g_t = dE_j/dr_jt (dE/dc of this atom from LDS)
-        if constexpr (PASS != 2)
         for (int t0 = 0; t0 < nn; t0 += 64) {
             const int t = t0 + lane;
             if (t < nn) {
@@ -753,15 +750,6 @@ __global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
                 }
             }
         }
-    }
-    if constexpr (PASS == 2) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) fsum[k] = wave_sum(fsum[k]);
-        // mirrored half: subtract from the forces the own-term launch stored (same wave owns the atom)
-        if (lane == 0 && active)
-#pragma unroll
-            for (int k = 0; k < 3; k++) a.Fself[3 * (size_t)gi + k] += fsum[k];
-        return;
     }
     // 12 wave sums (force 3 + virial 9) through LDS: the per-lane virial terms already live there as
     // [9][64]; the force terms join as rows 9..11, then 48 lanes each add a quarter of a row and two
