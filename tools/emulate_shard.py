@@ -25,3 +25,13 @@ for world in worlds:
             _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
         torch.cuda.synchronize()
         print(f"world={world} rank0 share, graph={graph}: {(time.perf_counter()-t0)/300*1e6:.1f} us/step")
+    if world > 1:
+        mdl.profile(True)
+        acc = {}
+        for _ in range(30):
+            _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+            torch.cuda.synchronize()
+            for k, v in mdl.stage_times().items():
+                acc[k] = acc.get(k, 0.0) + v / 30
+        mdl.profile(False)
+        print("   stages (us, incl. ~3 us marker each):", {k: round(v * 1e3, 1) for k, v in acc.items()})
