@@ -24,7 +24,7 @@ def random_frame(rng, n, box, species, dmin=1.4, pbc=True, cell=None):
     return numbers, pos, cell
 
 
-def build(lmax, nmax, eta, rc, species, numbers, pos, cell, pbc, m, seed):
+def build(lmax, nmax, eta, rc, species, numbers, pos, cell, pbc, m, seed, radii=None):
     from autoforce_amd import Local, SGPRModel
     from oracle import oracle as orc
     rng = np.random.default_rng(seed)
@@ -36,19 +36,19 @@ def build(lmax, nmax, eta, rc, species, numbers, pos, cell, pbc, m, seed):
         r = pos[j[s]] - pos[a] + off[s].astype(float) @ cell + 0.03 * rng.normal(size=(ptr[a + 1] - ptr[a], 3))
         keep = np.linalg.norm(r, axis=1) < rc - 1e-3
         X.append(Local(int(numbers[a]), numbers[j[s]][keep], r[keep]))
-    mdl = SGPRModel(lmax, nmax, eta, rc, species=species)
+    mdl = SGPRModel(lmax, nmax, eta, rc, species=species, radii=radii)
     mdl.set_inducing(X)
     return mdl, (ptr, j, off)
 
 
-def compare(mdl, lmax, nmax, eta, rc, numbers, pos, cell, pbc, nl, tol=1e-8):
+def compare(mdl, lmax, nmax, eta, rc, numbers, pos, cell, pbc, nl, tol=1e-8, radii=None):
     from oracle import oracle as orc
     X = mdl.X
     species = np.array(mdl.species, np.int32)
     ind_z = np.array([x.number for x in X], np.int32)
     ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
     Pm, nnm = orc.inducing_descriptors(lmax, nmax, rc, species, ind_z, ind_ptr,
-                                       np.concatenate([x._b for x in X]), np.concatenate([x._r for x in X]))
+                                       np.concatenate([x._b for x in X]), np.concatenate([x._r for x in X]), radii=radii)
     M = orc.kernel_matrix(ind_z, nnm, Pm, ind_z, nnm, Pm, eta)
     np.testing.assert_allclose(mdl.M, M, rtol=1e-9, atol=1e-12)
     L, ridge = orc.jitcholesky(M)
@@ -63,7 +63,7 @@ def compare(mdl, lmax, nmax, eta, rc, numbers, pos, cell, pbc, nl, tol=1e-8):
     got = set(map(tuple, np.column_stack([i, j, off]).tolist()))
     want = set(map(tuple, np.column_stack([i0, nl[1], nl[2]]).tolist()))
     assert got == want
-    ref = orc.frame(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mu, choli=choli)
+    ref = orc.frame(lmax, nmax, rc, eta, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mu, choli=choli, radii=radii)
     np.testing.assert_allclose(out["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
     assert abs(out["energy"] - ref["energy"]) <= 1e-9 * max(1.0, abs(ref["energy"]))
     assert np.abs(out["forces"] - ref["forces"]).max() <= tol * np.abs(ref["forces"]).max()
@@ -78,6 +78,19 @@ def test_five_species_uses_the_8_slot_kernels():
     numbers, pos, cell = random_frame(rng, 96, 9.5, species)
     mdl, nl = build(3, 3, 4.0, 5.0, species, numbers, pos, cell, [True] * 3, 20, 2)
     compare(mdl, 3, 3, 4.0, 5.0, numbers, pos, cell, [True] * 3, nl)
+    mdl.close()
+
+
+def test_non_integer_exponent_and_custom_radii():
+    """eta = 2.5 takes the pow() branch of the kernel epilogue (integer exponents use repeated
+    multiplication); radii other than the defaults exercise the per-species length unit
+    (descriptor/sesoap.py:84-99 allows any table) where r/u is not exact."""
+    rng = np.random.default_rng(11)
+    species = [3, 8, 15]
+    radii = np.array([0.8, 1.3, 1.0])
+    numbers, pos, cell = random_frame(rng, 80, 9.0, species)
+    mdl, nl = build(3, 3, 2.5, 5.0, species, numbers, pos, cell, [True] * 3, 18, 5, radii=radii)
+    compare(mdl, 3, 3, 2.5, 5.0, numbers, pos, cell, [True] * 3, nl, radii=radii)
     mdl.close()
 
 
