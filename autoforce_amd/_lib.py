@@ -53,6 +53,7 @@ SIGNATURES = {
     "sgpr_stress_from_virial": (C.c_int, [_vp, _vp, _vp]),
     "sgpr_get_descriptors": (C.c_int, [_vp, _vp]),
     "sgpr_get_neighbors": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "sgpr_get_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int]),
     "sgpr_get_dims": (C.c_int, [_vp, _vp]),
     "sgpr_profile": (C.c_int, [_vp, C.c_int]),
     "sgpr_get_stage_times": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),

@@ -324,6 +324,9 @@ class ActiveCalculator(Calculator):
         return self._nl
 
     def _local_here(self, k, system=None):
+        if system is None and hasattr(self.engine, "local"):
+            z, r = self.engine.local(k)  # one atom's list from the device, not the whole neighbour list
+            return Local(int(self.atoms.numbers[k]), z, r)
         numbers, positions, cell, _ = system or self._system(self.atoms)
         ptr, j, off = self._neighbors()
         a, b = int(ptr[k]), int(ptr[k + 1])

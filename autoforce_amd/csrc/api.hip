@@ -90,6 +90,7 @@ struct sgpr_model {
     double mean_energy = 0.0;
     DevBuf<int> d_perm, d_slot, d_aoff, d_lslot /*local rows*/, d_lnn;
     DevBuf<double> d_pos_in, d_cell_in, d_pos;
+    const double *last_cell = nullptr;  // device cell of the last enqueued step (sgpr_get_local)
     // neighbour list
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
@@ -788,6 +789,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
                         hipStream_t st)
 {
     const int N = h->N, cnt = h->cnt;
+    h->last_cell = cell_dev;
     if (h->profile) {
         h->stage_names.clear();
         if (h->ev.empty()) {
@@ -1019,6 +1021,52 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
 }
 
 // ---------------------------------------------------------------------------- inspection
+// one atom's LCE out of the device neighbour list: out_r[t] = x_j - x_i + shift.cell, out_slot[t]
+__global__ void local_extract_kernel(int g, int maxnn, const int *nn, const int *nbr_j, const int *nbr_shift,
+                                     const double *pos, const double *cell, double *out_r, int *out_slot)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nn[g]) return;
+    const size_t e = (size_t)g * maxnn + t;
+    const int j = nbr_j[e], code = nbr_shift[e];
+    const double s0 = (double)(int)(int8_t)(code & 0xff), s1 = (double)(int)(int8_t)((code >> 8) & 0xff),
+                 s2 = (double)(int)(int8_t)((code >> 16) & 0xff);
+    for (int k = 0; k < 3; k++)
+        out_r[3 * t + k] = pos[3 * (size_t)j + k] - pos[3 * (size_t)g + k] + (s0 * cell[k] + s1 * cell[3 + k] + s2 * cell[6 + k]);
+    out_slot[t] = (code >> 24) & 0xff;
+}
+
+extern "C" int sgpr_get_local(sgpr_model *h, int atom, int32_t *nn_out, int32_t *nbr_z, double *nbr_r, int capacity)
+{
+    if (!h || !nn_out) return fail(SGPR_E_INVALID, "sgpr_get_local: bad arguments");
+    if (h->N <= 0 || atom < 0 || atom >= h->N) return fail(SGPR_E_INVALID, "sgpr_get_local: atom %d outside the bound system", atom);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int g = -1;
+    for (int k = 0; k < h->N; k++)
+        if (h->perm[k] == atom) { g = k; break; }
+    if (g < h->rank || (g - h->rank) % h->world != 0)
+        return fail(SGPR_E_INVALID, "sgpr_get_local: atom %d belongs to another rank's share", atom);
+    int nn = 0;
+    HIPCHK(hipMemcpy(&nn, h->d_nn.p + g, sizeof(int), hipMemcpyDeviceToHost));
+    *nn_out = nn;
+    if (!nbr_z || !nbr_r) return SGPR_OK;
+    if (nn > capacity) return fail(SGPR_E_OVERFLOW, "sgpr_get_local: %d neighbours, room for %d", nn, capacity);
+    if (nn == 0) return SGPR_OK;
+    DevBuf<double> d_r;
+    DevBuf<int> d_s;
+    if (d_r.alloc(3 * (size_t)nn, false) || d_s.alloc(nn, false)) return fail(SGPR_E_NODEVICE, "hipMalloc failed");
+    hipLaunchKernelGGL(local_extract_kernel, dim3((nn + 255) / 256), dim3(256), 0, h->stream, g, h->maxnn, h->d_nn.p,
+                       h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pos.p, h->last_cell ? h->last_cell : h->d_cell_in.p, d_r.p, d_s.p);
+    std::vector<int> slots(nn);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(nbr_r, d_r.p, sizeof(double) * 3 * nn, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(slots.data(), d_s.p, sizeof(int) * nn, hipMemcpyDeviceToHost));
+    for (int t = 0; t < nn; t++) nbr_z[t] = h->species[slots[t]];
+    d_r.release(); d_s.release();
+    return SGPR_OK;
+}
+
 extern "C" int sgpr_get_descriptors(sgpr_model *h, double *P)
 {
     if (!h || !P) return fail(SGPR_E_INVALID, "sgpr_get_descriptors: bad arguments");

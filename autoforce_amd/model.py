@@ -269,6 +269,16 @@ class SGPRModel:
         check(_lib.load().sgpr_get_neighbors(self._h, ptr(p), ptr(j), ptr(off)))
         return p, j, off
 
+    def local(self, atom):
+        """The LCE of one atom of the last evaluated frame (TorchAtoms.local, descriptor/atoms.py:365-382)
+        straight from the device neighbour list."""
+        nn = C.c_int32(0)
+        lib = _lib.load()
+        check(lib.sgpr_get_local(self._h, int(atom), C.addressof(nn), None, None, 0))
+        z, r = np.zeros(nn.value, np.int32), np.zeros((nn.value, 3))
+        check(lib.sgpr_get_local(self._h, int(atom), C.addressof(nn), ptr(z), ptr(r), nn.value))
+        return z, r
+
     def profile(self, on=True):
         check(_lib.load().sgpr_profile(self._h, int(bool(on))))
 

@@ -206,6 +206,12 @@ int sgpr_stress_from_virial(const double *virial9, const double *cell, double *s
 int sgpr_get_descriptors(sgpr_model *h, double *P);
 int sgpr_get_neighbors(sgpr_model *h, int64_t *ptr, int32_t *j, int32_t *off);
 
+/* One atom's LCE (neighbour numbers and displacement vectors x_j - x_i + off.cell, descriptor/atoms.py:
+ * 365-382 `TorchAtoms.local`) out of the neighbour list of the last evaluated frame, without moving
+ * the whole list to the host (the cell is read from the device buffer that step used).
+ * nbr_z / nbr_r may be NULL to ask for the count only. */
+int sgpr_get_local(sgpr_model *h, int atom, int32_t *nn, int32_t *nbr_z, double *nbr_r, int capacity);
+
 /* Model dimensions, out[8]: out[0]=m, out[1]=S, out[2]=D (dense per block), out[3]=Dc (packed
  * row length used on the device), out[4]=neighbour capacity per atom, out[5]=N bound,
  * out[6]=largest neighbour count seen at the last checked step, out[7]=padded row stride. */

@@ -212,3 +212,23 @@ def test_baseline_config5_oxide16384_m1024():
     vs = np.sqrt([mdl._vscale[int(z)] for z in numbers])
     np.testing.assert_allclose(out["beta"], ref["beta"] * vs, rtol=0, atol=5e-6 * vs.max())
     mdl.close()
+
+
+def test_single_atom_lce_from_device():
+    """sgpr_get_local == the LCE assembled on the host from the full neighbour list
+    (descriptor/atoms.py:365-382), for periodic images and an empty environment."""
+    for name in ("g5_si32", "g5_tric24", "g5_cluster16"):
+        g = load(name)
+        mdl = model_from_fixture(g)
+        N = len(g["numbers"])
+        mdl.predict(g["numbers"], g["positions"], g["cell"], g["pbc"], beta=False)
+        ptr, j, off = mdl.neighbors(N)
+        for k in (0, N // 2, N - 1):
+            z, r = mdl.local(k)
+            a, b = int(ptr[k]), int(ptr[k + 1])
+            want_r = g["positions"][j[a:b]] - g["positions"][k] + off[a:b].astype(float) @ g["cell"]
+            np.testing.assert_array_equal(z, g["numbers"][j[a:b]])
+            np.testing.assert_allclose(r, want_r, rtol=0, atol=1e-13)
+        with pytest.raises(Exception):
+            mdl.local(N)
+        mdl.close()
