@@ -54,6 +54,7 @@ SIGNATURES = {
     "sgpr_get_descriptors": (C.c_int, [_vp, _vp]),
     "sgpr_get_neighbors": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sgpr_get_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int]),
+    "sgpr_get_cov": (C.c_int, [_vp, _vp]),
     "sgpr_get_dims": (C.c_int, [_vp, _vp]),
     "sgpr_profile": (C.c_int, [_vp, C.c_int]),
     "sgpr_get_stage_times": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),

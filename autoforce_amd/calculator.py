@@ -131,7 +131,7 @@ class ActiveCalculator(Calculator):
         self.report_timings = report_timings
         self.step0_forced_fp = step0_forced_fp
         self.nbeads = nbeads
-        self.deltas, self.covlog, self.cov = None, "", None
+        self.deltas, self.covlog, self._cov = None, "", None
         self.blind = False
         self._saved_for_tape = None
         self._beta = None
@@ -213,17 +213,29 @@ class ActiveCalculator(Calculator):
         rank, world = self._dist()
         if not (engine.m > 0 and engine.mu is not None):
             # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
-            return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf),
-                        cov=np.zeros((N, 0)))
-        out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=True, beta=True)
-        cov = out["cov"]
+            return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf), ready=False)
+        out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=False, beta=True)
         if world > 1:
             import torch.distributed as dist
             v = self._tensor(pack_partial(out, N))
             dist.all_reduce(v, group=self.process_group)  # active.py:562,601,602,777 in one collective
             out = unpack_total(v.cpu().numpy(), N)
-            out["cov"] = cov
+        out["ready"] = True
         return out
+
+    @property
+    def cov(self):
+        """K_nm of the last evaluated frame, [N, m] (this rank's rows) — active.py:464 `self.cov`.
+        It stays on the device until somebody looks: N x m doubles per step over PCIe would cost
+        more than the step itself."""
+        if self._cov is None and self.atoms is not None and self.engine.m > 0:
+            fetch = getattr(self.engine, "last_cov", None)
+            self._cov = fetch(len(self.atoms)) if fetch else None
+        return self._cov
+
+    @cov.setter
+    def cov(self, value):
+        self._cov = value
 
     def update_results(self, retain_graph=False, covloss_only=False):
         """active.py:548-611 + :781-804 in one device pass: E, F, stress, covloss, cov.
@@ -231,8 +243,7 @@ class ActiveCalculator(Calculator):
         alone — inside update_inducing the reference extends cov by a column and keeps the
         pre-update predictions, which update_data then offers as 'fake' labels."""
         out = self._evaluate_engine(self.engine)
-        if out["cov"].shape[1]:
-            self.cov = out["cov"]
+        self._cov = None  # fetched lazily
         self._nl = None
         self._beta = out["beta"]
         if covloss_only:

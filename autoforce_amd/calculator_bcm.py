@@ -85,8 +85,7 @@ class BCMActiveCalculator(ActiveCalculator):
 
     def update_results(self, retain_graph=False, covloss_only=False):
         live = self._evaluate_engine(self.engine)
-        if live["cov"].shape[1]:
-            self.cov = live["cov"]
+        self._cov = None
         self._nl = None
         self._beta = live["beta"]
         outs = {key: self._evaluate_engine(post.engine) for key, post in self.model_dict.items()}
@@ -95,7 +94,7 @@ class BCMActiveCalculator(ActiveCalculator):
             return
         members = list(outs.values()) + [live]
         scales = [self._scale(o["beta"])[0] for o in members]
-        ready = [o["cov"].shape[1] > 0 for o in members]
+        ready = [o["ready"] for o in members]
         w = np.array([s if r else 0.0 for s, r in zip(scales, ready)], float)
         if np.isinf(w).any():  # a member with zero covloss everywhere is certain: it alone decides
             w = np.isinf(w).astype(float)

@@ -950,14 +950,23 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
     if (beta) memcpy(beta, out.data() + 3 * (size_t)N, sizeof(double) * N);
     if (energy) *energy = out[4 * (size_t)N];
     if (stress) sgpr_stress_from_virial(out.data() + 4 * (size_t)N + 1, cell, stress);
-    if (cov && h->m > 0) {
-        memset(cov, 0, sizeof(double) * (size_t)N * h->m);
-        std::vector<double> kb((size_t)h->cnt_rows * h->m_pad);
-        HIPCHK(hipMemcpy(kb.data(), h->d_K.p, sizeof(double) * kb.size(), hipMemcpyDeviceToHost));
-        for (int il = 0; il < h->cnt; il++) {
-            const int c = h->perm[h->rank + il * h->world];
-            for (int q = 0; q < h->m; q++) cov[(size_t)c * h->m + h->ind_perm[q]] = kb[(size_t)il * h->m_pad + q];
-        }
+    if (cov && h->m > 0) return sgpr_get_cov(h, cov);
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_cov(sgpr_model *h, double *cov)
+{
+    if (!h || !cov) return fail(SGPR_E_INVALID, "sgpr_get_cov: bad arguments");
+    if (h->N <= 0 || h->m <= 0) return fail(SGPR_E_NOMODEL, "sgpr_get_cov: no evaluated frame / inducing set");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N = h->N;
+    memset(cov, 0, sizeof(double) * (size_t)N * h->m);
+    std::vector<double> kb((size_t)h->cnt_rows * h->m_pad);
+    HIPCHK(hipMemcpy(kb.data(), h->d_K.p, sizeof(double) * kb.size(), hipMemcpyDeviceToHost));
+    for (int il = 0; il < h->cnt; il++) {
+        const int c = h->perm[h->rank + il * h->world];
+        for (int q = 0; q < h->m; q++) cov[(size_t)c * h->m + h->ind_perm[q]] = kb[(size_t)il * h->m_pad + q];
     }
     return SGPR_OK;
 }

@@ -269,6 +269,13 @@ class SGPRModel:
         check(_lib.load().sgpr_get_neighbors(self._h, ptr(p), ptr(j), ptr(off)))
         return p, j, off
 
+    def last_cov(self, N):
+        """K_nm [N, m] of the last evaluated frame, downloaded on demand."""
+        out = np.zeros((N, self.m))
+        if self.m:
+            check(_lib.load().sgpr_get_cov(self._h, ptr(out)))
+        return out
+
     def local(self, atom):
         """The LCE of one atom of the last evaluated frame (TorchAtoms.local, descriptor/atoms.py:365-382)
         straight from the device neighbour list."""

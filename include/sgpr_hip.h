@@ -212,6 +212,10 @@ int sgpr_get_neighbors(sgpr_model *h, int64_t *ptr, int32_t *j, int32_t *off);
  * nbr_z / nbr_r may be NULL to ask for the count only. */
 int sgpr_get_local(sgpr_model *h, int atom, int32_t *nn, int32_t *nbr_z, double *nbr_r, int capacity);
 
+/* K_nm [N][m] of the last evaluated frame (caller order; rows of other ranks' atoms are zero): the
+ * `cov` output of sgpr_compute, fetched only when somebody looks at it (calc.cov, active.py:464). */
+int sgpr_get_cov(sgpr_model *h, double *cov);
+
 /* Model dimensions, out[8]: out[0]=m, out[1]=S, out[2]=D (dense per block), out[3]=Dc (packed
  * row length used on the device), out[4]=neighbour capacity per atom, out[5]=N bound,
  * out[6]=largest neighbour count seen at the last checked step, out[7]=padded row stride. */

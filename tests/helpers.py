@@ -143,6 +143,7 @@ class OracleModel:
                         self._nl_mine, self._ind_z, self._nnm, self._Pm, self.mu, choli=self.choli, radii=self.radii,
                         want_p=False)
         K = out["cov"] * mine[:, None]
+        self._last_cov = K
         e = float((K @ self.mu).sum())
         if rank == 0:
             e += sum(self.mean.get(int(z), 0.0) for z in numbers)
@@ -153,6 +154,9 @@ class OracleModel:
         elif beta:
             b = np.zeros(N)
         return dict(energy=e, forces=out["forces"], stress=out["stress"], beta=b, cov=K if cov else None)
+
+    def last_cov(self, N):
+        return self._last_cov
 
     def neighbors(self, N):
         return self._nl_mine
