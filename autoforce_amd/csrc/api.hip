@@ -145,87 +145,62 @@ __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, d
 
 // packed = [F(3N) | beta(N) | E | virial(9)] in CALLER atom order.
 // The scalar reductions (energy partials of the K_nm tiles, virial partials of the pair kernel,
-// largest neighbour count) are two-level: every workgroup reduces its slice, the last one to
-// arrive (agent-scope release / ticket / acquire, cdna_hip_programming.md Guideline 16) combines
-// the per-workgroup partials in a fixed order, so the sums are reproducible.
+// largest neighbour count) are done by one extra workgroup in a fixed order: reproducible sums.
 __global__ __launch_bounds__(256) void finalize_kernel(int N, int cnt, int first, int stride, const int *perm,
                                                        const int *slot, const double *Fnbr, const double *Fself,
                                                        const double *csq, int has_beta, const double *vs_sqrt,
                                                        const double *Epart, int nE, const double *virpart, int nV,
                                                        double mean_energy, double *packed, const int *nn_raw,
-                                                       int *stat, double *gpart /*[grid][12]*/, unsigned *ticket,
+                                                       int *stat, double *gpart /*unused*/, unsigned *ticket /*unused*/,
                                                        int *bin_count /*[4096]: cleared for the next step*/)
 {
-    __shared__ int is_last;
-    const int tid = threadIdx.x, b = blockIdx.x, nb = gridDim.x;
-    const int i = b * blockDim.x + tid;
-    for (int k = i; k < 4096; k += nb * blockDim.x) bin_count[k] = 0;
-    if (i < N) {
-        const int c = perm[i];
+    // Two kinds of workgroup, no hand-shake between them: blocks 0 .. nA-1 put the per-atom results
+    // back in caller order; the last ELEVEN blocks each reduce one scalar (E, nine virial components,
+    // largest neighbour count) in a fixed order, so the sums are reproducible.
+    // The earlier two-level form (every block reduces a slice, release fence, ticket, last arriver
+    // combines) spent most of its 8 us in that dependent chain.
+    const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
+    if (b < nA) {
+        const int i = b * blockDim.x + tid;
+        for (int k = i; k < 4096; k += nA * blockDim.x) bin_count[k] = 0;
+        if (i < N) {
+            const int c = perm[i];
 #pragma unroll
-        for (int k = 0; k < 3; k++) packed[3 * c + k] = Fnbr[3 * i + k] + Fself[3 * i + k];
-        double bt = 0.0;
-        const int il = (i - first) / stride;
-        if (has_beta && i >= first && (i - first) % stride == 0 && il < cnt) {
-            const double v = 1.0 - csq[il];
-            bt = sqrt(v > 0.0 ? v : 0.0) * vs_sqrt[slot[i]];
+            for (int k = 0; k < 3; k++) packed[3 * c + k] = Fnbr[3 * i + k] + Fself[3 * i + k];
+            double bt = 0.0;
+            const int il = (i - first) / stride;
+            if (has_beta && i >= first && (i - first) % stride == 0 && il < cnt) {
+                const double v = 1.0 - csq[il];
+                bt = sqrt(v > 0.0 ? v : 0.0) * vs_sqrt[slot[i]];
+            }
+            packed[3 * N + c] = bt;
         }
-        packed[3 * N + c] = bt;
+        return;
     }
-    // level 1: this workgroup's slice of each partial array, one wave per component
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int q = wave; q < 11; q += 4) {
-        if (q == 10) {
-            const int per = (cnt + nb - 1) / nb, lo = b * per, hi = min(cnt, lo + per);
-            int mx = 0;
-            for (int k = lo + lane; k < hi; k += 64) mx = max(mx, nn_raw[k]);
+    // reducer block q: E (0), the nine virial components (1..9), the largest neighbour count (10)
+    __shared__ double wsum[4];
+    const int q = b - nA, wave = tid >> 6, lane = tid & 63;
+    double s = 0.0;
+    if (q == 10) {
+        int mx = 0;
+        for (int k = tid; k < cnt; k += 256) mx = max(mx, nn_raw[k]);
+        s = (double)mx;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-            if (lane == 0) gpart[b * 12 + q] = (double)mx;
-        } else {
-            const double *src = q == 0 ? Epart : virpart + (size_t)(q - 1) * nV;
-            const int n = q == 0 ? nE : nV;
-            const int per = (n + nb - 1) / nb, lo = b * per, hi = min(n, lo + per);
-            double s = 0.0;
-            for (int k = lo + lane; k < hi; k += 64) s += src[k];
+        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    } else {
+        const double *src = q == 0 ? Epart : virpart + (size_t)(q - 1) * nV;
+        const int n = q == 0 ? nE : nV;
+        for (int k = tid; k < n; k += 256) s += src[k];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (lane == 0) gpart[b * 12 + q] = s;
-        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) wsum[wave] = s;
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == (unsigned)nb - 1);
-        if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (q == 10) stat[0] = max(stat[0], (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3])));  // sticky
+        else packed[4 * (size_t)N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? mean_energy : 0.0);
     }
-    __syncthreads();
-    if (!is_last) return;
-    // level 2: combine the per-workgroup partials in workgroup order
-    for (int q = wave; q < 11; q += 4) {
-        double s = 0.0, mx = 0.0;
-        for (int k = lane; k < nb; k += 64) {
-            const double v = __hip_atomic_load(&gpart[k * 12 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s += v;
-            mx = fmax(mx, v);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s += __shfl_xor(s, o, 64);
-            mx = fmax(mx, __shfl_xor(mx, o, 64));
-        }
-        if (lane == 0) {
-            if (q == 10) stat[0] = max(stat[0], (int)mx);  // sticky until the host reads and clears it
-            else packed[4 * (size_t)N + q] = s + (q == 0 ? mean_energy : 0.0);
-        }
-    }
-    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    (void)gpart; (void)ticket;
 }
 
 // ---------------------------------------------------------------------------- host tables
@@ -858,7 +833,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
             stamp(h, phase == 1 ? "descriptor_dc" : "descriptor_pair", st);
         }
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256), dim3(256), 0, st, N, cnt, h->rank,
+    hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256 + 11), dim3(256), 0, st, N, cnt, h->rank,
                        h->world, h->d_perm.p, h->d_slot.p, h->d_F.p, h->d_F.p + 3 * (size_t)N, h->d_csq.p,
                        beta ? 1 : 0, h->d_vs_sqrt.p, h->d_Epart.p, predict ? h->epart_len : 0, h->d_virpart.p,
                        predict ? h->virpart_len : 0, h->mean_energy, packed_dev, h->d_nn_raw.p, h->d_stat.p,
