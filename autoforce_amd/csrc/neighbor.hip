@@ -104,13 +104,20 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         if (wg == 0) *a.grid = g;
     }
     const int gsz = gridDim.x * 256, gid = wg * 256 + tid;
+    // this atom's position is requested before the barrier: the gather (perm -> pos_in) and the grid
+    // set-up by thread 0 are independent latency chains
+    const int i = gid;
+    double x = 0.0, y = 0.0, z = 0.0;
+    int slot_i = 0;
+    if (i < a.N) {
+        const int c = a.perm ? a.perm[i] : i;
+        x = a.pos_in[3 * c]; y = a.pos_in[3 * c + 1]; z = a.pos_in[3 * c + 2];
+        slot_i = a.slot[i];
+    }
     for (int k = gid; k < a.n_zero_a; k += gsz) a.zero_a[k] = 0.0;
     for (int k = gid; k < a.n_zero_b; k += gsz) a.zero_b[k] = 0.0;
     __syncthreads();
-    const int i = gid;
     if (i >= a.N) return;
-    const int c = a.perm ? a.perm[i] : i;
-    const double x = a.pos_in[3 * c], y = a.pos_in[3 * c + 1], z = a.pos_in[3 * c + 2];
     a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
     int bidx[3], w[3];
 #pragma unroll
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     if (k < a.cap) {
         const size_t e = (size_t)bin * a.cap + k;
         a.b_idx[e] = i;
-        a.b_slot[e] = a.slot[i];
+        a.b_slot[e] = slot_i;
         a.b_pos[3 * e] = x; a.b_pos[3 * e + 1] = y; a.b_pos[3 * e + 2] = z;
         a.b_wrap[3 * e] = w[0]; a.b_wrap[3 * e + 1] = w[1]; a.b_wrap[3 * e + 2] = w[2];
     } else
