@@ -215,7 +215,11 @@ template <int LMAX, int NMAX>
 struct WaveLds {
     static constexpr int L1 = LMAX + 1, N1 = NMAX + 1, LL = L1 * L1, LLP = LL + 1, NSLOT = N1 * LL;
     // doubles per wave for the neighbour tile
-    static constexpr int TILE_D = 64 * N1 + 64 * LLP;
+    // neighbours per tile of the forward kernel: 48, not 64 — a 64-neighbour tile costs 50 KB of LDS per
+    // workgroup (3 workgroups per CU, so 1024 workgroups run as 1.33 rounds); 48 fits four per CU and
+    // the whole grid is resident at once.  Lists longer than 48 take another tile.
+    static constexpr int CH = 48;
+    static constexpr int TILE_D = CH * N1 + CH * LLP;
 };
 
 // =========================================================================== forward
@@ -230,10 +234,11 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
     const int ia = blockIdx.x * 4 + wave;
     if (ia >= a.N) return;
     const int gi = a.first + ia * a.stride;
+    constexpr int CH = WL::CH;
     const int perwave = WL::TILE_D + ST * NSLOT + 64 / 2;  // + 64 ints
-    double *fl = smem + (size_t)wave * perwave;  // [64][N1]
-    double *Yl = fl + 64 * N1;                   // [64][LLP]
-    double *cl = Yl + 64 * LLP;                  // [ST][NSLOT]
+    double *fl = smem + (size_t)wave * perwave;  // [CH][N1]
+    double *Yl = fl + CH * N1;                   // [CH][LLP]
+    double *cl = Yl + CH * LLP;                  // [ST][NSLOT]
     int *sl = (int *)(cl + ST * NSLOT);          // [64]
 
     int nn;
@@ -249,10 +254,10 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
     }
 
     // Does any neighbour sit inside the z cone? (ylm.py:10-23: then the whole environment shears.)
-    // Environments that fit one 64-neighbour tile decide it inside the main pass; larger ones
+    // Environments that fit one tile decide it inside the main pass; larger ones
     // need a pass of their own first.
     bool shear = false;
-    if (nn > 64) {
+    if (nn > CH) {
         bool near = false;
         for (int t0 = 0; t0 < nn; t0 += 64) {
             const int t = t0 + lane;
@@ -273,9 +278,9 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
 #pragma unroll
         for (int k = 0; k < SPL; k++) acc[s][k] = 0.0;
 
-    for (int t0 = 0; t0 < nn; t0 += 64) {
-        const int t = t0 + lane;
-        const int cnt = min(64, nn - t0);
+    for (int t0 = 0; t0 < nn; t0 += CH) {
+        const int cnt = min(CH, nn - t0);
+        const int t = lane < cnt ? t0 + lane : nn;  // lanes past the tile sit the neighbour phase out
         wave_sync();
         double r[3] = {1.0, 0.0, 0.0};
         int s = 0, j = 0;
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         const double u = unit_of<ST>(a, s);
         const double iu = 1.0 / u;
         const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
-        if (nn <= 64) {
+        if (nn <= CH) {
             const double tol = SGPR_TINY_ANGLE * fabs(z);
             shear = __any(t < nn && fabs(x) < tol && fabs(y) < tol);
         }
