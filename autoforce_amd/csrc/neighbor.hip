@@ -166,9 +166,19 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     for (int k = 0; k < 9; k++) h[k] = cell[k];
     const double xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     const int wi0 = wrap[3 * i], wi1 = wrap[3 * i + 1], wi2 = wrap[3 * i + 2];
+    // index arithmetic without integer division (a ~30-instruction sequence each on this ISA): small
+    // non-negative operands, so floor((q + 1/2) * (1/w)) in fp32 is exact (the argument is never within
+    // 0.5/33 of an integer), and floor(t / nb) for the image count goes through an fp64 reciprocal
+    auto fdiv = [](int q, int w, float inv) { (void)w; return (int)(((float)q + 0.5f) * inv); };
     const int bi = bin_of[i];
-    const int b2 = bi % g.nb[2], b1 = (bi / g.nb[2]) % g.nb[1], b0 = bi / (g.nb[2] * g.nb[1]);
+    const float i_n2 = 1.0f / (float)g.nb[2], i_n1 = 1.0f / (float)g.nb[1];
+    const int bq = fdiv(bi, g.nb[2], i_n2);
+    const int b2 = bi - bq * g.nb[2];
+    const int b0 = fdiv(bq, g.nb[1], i_n1);
+    const int b1 = bq - b0 * g.nb[1];
     const int w0 = 2 * g.rng[0] + 1, w1 = 2 * g.rng[1] + 1, w2 = 2 * g.rng[2] + 1;
+    const float i_w2 = 1.0f / (float)w2, i_w1 = 1.0f / (float)w1;
+    const double r_n0 = 1.0 / g.nb[0], r_n1 = 1.0 / g.nb[1], r_n2 = 1.0 / g.nb[2];
     const int nbox = w0 * w1 * w2;
     int base = 0;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -178,10 +188,11 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
         const int q = q0 + lane;
         int cntb = 0, sb = 0, code = 0;
         if (q < nbox) {
-            const int o2 = q % w2 - g.rng[2], o1 = (q / w2) % w1 - g.rng[1], o0 = q / (w2 * w1) - g.rng[0];
+            const int qa = fdiv(q, w2, i_w2), qb = fdiv(qa, w1, i_w1);
+            const int o2 = q - qa * w2 - g.rng[2], o1 = qa - qb * w1 - g.rng[1], o0 = qb - g.rng[0];
             const int t0 = b0 + o0, t1 = b1 + o1, t2 = b2 + o2;
-            const int c0 = (int)floor((double)t0 / g.nb[0]), c1 = (int)floor((double)t1 / g.nb[1]),
-                      c2 = (int)floor((double)t2 / g.nb[2]);
+            const int c0 = (int)floor((double)t0 * r_n0 + 1e-9), c1 = (int)floor((double)t1 * r_n1 + 1e-9),
+                      c2 = (int)floor((double)t2 * r_n2 + 1e-9);
             const int nbin = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
             sb = nbin * cap;
             cntb = min(bin_count[nbin], cap);
