@@ -33,6 +33,9 @@ def test_calculator_on_hip(tmp_path):
     assert abs(atoms.get_potential_energy() - float(g["energy"])) < 1e-10
     assert np.abs(atoms.get_forces() - g["forces"]).max() <= 1e-9 * np.abs(g["forces"]).max()
     assert np.abs(atoms.get_stress() - g["stress"]).max() <= 1e-9 * np.abs(g["stress"]).max()
+    # calc.cov (active.py:464) is fetched from the device only when somebody looks at it
+    assert calc._cov is None
+    np.testing.assert_allclose(calc.cov, g["cov"], rtol=1e-10, atol=1e-13)
     ok = np.isfinite(g["covloss"])
     np.testing.assert_allclose(calc.get_covloss()[ok], g["covloss"][ok], rtol=0, atol=1e-6)
     assert calc.step == 1 and calc.size == (0, 24)
