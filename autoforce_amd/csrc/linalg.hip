@@ -199,89 +199,7 @@ void launch_tril_inverse(int m, const double *L, int ld, double *Li, hipStream_t
     hipLaunchKernelGGL(tril_inverse_kernel, dim3((m + NB - 1) / NB), dim3(256), 0, st, m, L, ld, Li);
 }
 
-// ------------------------------------------------------------------ Householder QR least squares
-// scal[0] = 2/(v.v), w[0..cols) zeroed; v stored for rows >= k; A[k][k] <- R_kk; y updated.
-__global__ __launch_bounds__(1024) void qr_house_kernel(int rows, int cols, int k, double *A, double *y, double *v,
-                                                         double *w, double *scal)
-{
-    __shared__ double red[1024];
-    const int tid = threadIdx.x;
-    double s = 0.0;
-    for (int i = k + tid; i < rows; i += 1024) {
-        const double a = A[(size_t)i * cols + k];
-        s += a * a;
-    }
-    red[tid] = s;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    const double nrm = sqrt(red[0]);
-    __syncthreads();
-    const double akk = A[(size_t)k * cols + k];
-    const double alpha = akk > 0.0 ? -nrm : nrm;
-    double vv = 0.0, vy = 0.0;
-    for (int i = k + tid; i < rows; i += 1024) {
-        const double vi = A[(size_t)i * cols + k] - (i == k ? alpha : 0.0);
-        v[i] = vi;
-        vv += vi * vi;
-        vy += vi * y[i];
-    }
-    red[tid] = vv;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    vv = red[0];
-    __syncthreads();
-    red[tid] = vy;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    vy = red[0];
-    const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
-    for (int i = k + tid; i < rows; i += 1024) y[i] -= sc * vy * v[i];
-    for (int j = tid; j < cols; j += 1024) w[j] = 0.0;
-    if (tid == 0) {
-        scal[0] = sc;
-        A[(size_t)k * cols + k] = alpha;
-    }
-}
-
-// w[j] += sum_{i in chunk} v_i A[i][j], j > k
-__global__ __launch_bounds__(256) void qr_dot_kernel(int rows, int cols, int k, const double *A, const double *v,
-                                                     double *w, int rchunk)
-{
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = k + 1 + blockIdx.x * 64 + tx;
-    const int i0 = k + blockIdx.y * rchunk;
-    const int i1 = min(rows, i0 + rchunk);
-    double s = 0.0;
-    if (j < cols)
-        for (int i = i0 + ty; i < i1; i += 4) s += v[i] * A[(size_t)i * cols + j];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && j < cols) unsafeAtomicAdd(&w[j], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
-}
-
-// A[i][j] -= scal v_i w_j for i >= k (i > k for the column k itself is left as is), j > k
-__global__ __launch_bounds__(256) void qr_update_kernel(int rows, int cols, int k, double *A, const double *v,
-                                                        const double *w, const double *scal, int rchunk)
-{
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = k + 1 + blockIdx.x * 64 + tx;
-    const int i0 = k + blockIdx.y * rchunk;
-    const int i1 = min(rows, i0 + rchunk);
-    if (j >= cols) return;
-    const double sw = scal[0] * w[j];
-    for (int i = i0 + ty; i < i1; i += 4) A[(size_t)i * cols + j] -= sw * v[i];
-}
-
+// ------------------------------------------------------------------ back substitution of the QR least squares
 __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const double *A, const double *y, double *x)
 {
     __shared__ double red[1024];
@@ -303,26 +221,6 @@ __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const doub
         __syncthreads();
     }
 }
-
-int launch_lstsq_qr(int rows, int cols, double *A, double *y, double *x, double *work, hipStream_t st)
-{
-    if (cols > 2048 || rows < cols) return -1;
-    double *v = work, *w = work + rows, *scal = w + cols;
-    for (int k = 0; k < cols; k++) {
-        hipLaunchKernelGGL(qr_house_kernel, dim3(1), dim3(1024), 0, st, rows, cols, k, A, y, v, w, scal);
-        const int ncol = cols - k - 1;
-        if (ncol > 0) {
-            const int nrow = rows - k;
-            const int rchunk = 256;
-            dim3 grid((ncol + 63) / 64, (nrow + rchunk - 1) / rchunk);
-            hipLaunchKernelGGL(qr_dot_kernel, grid, dim3(256), 0, st, rows, cols, k, A, v, w, rchunk);
-            hipLaunchKernelGGL(qr_update_kernel, grid, dim3(256), 0, st, rows, cols, k, A, v, w, scal, rchunk);
-        }
-    }
-    hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, A, y, x);
-    return 0;
-}
-
 
 // ------------------------------------------------------------------ blocked Householder QR (compact WY)
 // Storage: At[c][r] = A[r][c] (each column of the least-squares matrix is a contiguous row of

@@ -149,8 +149,5 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /
 // R (row-major [cols][cols], upper) and z = (Q^T y)[0:cols] out of a factored At
 void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st);
 
-int launch_lstsq_qr(int rows, int cols, double *A /*[rows][cols] overwritten*/, double *y /*[rows] overwritten*/,
-                    double *x /*[cols]*/, double *work, hipStream_t st);
-
 void host_build_harm_coef(HarmCoef *hc);
 void upload_harm_coef(const HarmCoef &hc);
