@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     // a plain store, covloss = K.choli^T with the row-square epilogue); the tile table says which.
     const bool second = (EPI == EPI_WCOV) && ((g.p.tiles[blockIdx.x].x >> 16) & 1);
     const GemmParams &p = second ? g.p2 : g.p;
-    __shared__ double As[2][BM * 34];
+    __shared__ double As[2][BMT * 34];  // 32-row tiles: 52 KB per workgroup, three per CU instead of two
     __shared__ double Bs[2][BN * 34];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wr = wave >> 1, wc = wave & 1;
