@@ -35,6 +35,18 @@ def lips(n_side=16, seed=0, sigma=0.15):
     return numbers, pos, cell, np.array([True, True, True])
 
 
+def si_diamond(reps=(2, 2, 1), seed=0, sigma=0.05):
+    """C1: diamond Si a=5.431, 8-atom cubic x (2,2,1) = 32 atoms; L_z = 5.431 < rc: atoms meet their own images."""
+    rng = np.random.default_rng(seed)
+    a = 5.431
+    base = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0], [.25, .25, .25], [.25, .75, .75],
+                     [.75, .25, .75], [.75, .75, .25]]) * a
+    cells = np.stack(np.meshgrid(*[np.arange(n) for n in reps], indexing="ij"), -1).reshape(-1, 3) * a
+    pos = (cells[:, None, :] + base[None]).reshape(-1, 3) + sigma * rng.normal(size=(len(cells) * 8, 3))
+    cell = np.diag([n * a for n in reps]).astype(float)
+    return np.full(len(pos), 14, np.int32), pos, cell, np.array([True, True, True])
+
+
 def li_bcc(reps=(8, 4, 4), seed=0, sigma=0.10):
     """C2: bcc Li a=3.49, 2-atom cubic x reps = 256 atoms."""
     rng = np.random.default_rng(seed)

@@ -161,11 +161,18 @@ def test_full_size_properties():
 def _workload_model(kind, m, seed=1):
     from autoforce_amd import SGPRModel
     from autoforce_amd import workloads as wl
-    make = {"li": wl.li_bcc, "oxide": wl.oxide}[kind]
+    make = {"li": wl.li_bcc, "oxide": wl.oxide, "si": wl.si_diamond}[kind]
     numbers, pos, cell, pbc = make(seed=0)
     mdl = SGPRModel(3, 3, 4, 6.0, species=sorted(set(numbers.tolist())))
     n2, p2, c2, b2 = make(seed=seed)
-    mdl.set_inducing(wl.inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=seed))
+    if m <= len(n2):
+        X = wl.inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=seed)
+    else:  # more inducing LCEs than atoms in one frame: draw from several rattled copies
+        X = []
+        for k in range(-(-m // len(n2))):
+            nk, pk, ck, bk = make(seed=seed + k)
+            X += wl.inducing_from_frame(mdl, nk, pk, ck, bk, min(len(n2), m - len(X)), seed=seed + k)
+    mdl.set_inducing(X)
     rng = np.random.default_rng(2)
     mdl.solve(rng.normal(size=(64, m)), rng.normal(size=64))
     mdl.set_weights(rng.normal(size=m), choli=mdl.choli, vscale=mdl.make_vscale())
@@ -181,6 +188,26 @@ def _oracle_frame(mdl, numbers, pos, cell, nl):
     Pm, nnm = orc.inducing_descriptors(3, 3, 6.0, species, ind_z, ind_ptr, np.concatenate([x._b for x in X]),
                                        np.concatenate([x._r for x in X]))
     return orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mdl.mu, choli=mdl.choli)
+
+
+def test_baseline_config1_si32_m64():
+    """BASELINE configs[0] shape: 32-atom diamond Si, 8-atom cubic x (2,2,1) — the z edge is shorter than
+    the cutoff, so every atom meets its own periodic images — with 64 inducing LCEs drawn from
+    rattled copies; energy / forces / stress / covloss against the oracle."""
+    from oracle import oracle as orc
+    mdl, numbers, pos, cell, pbc = _workload_model("si", 64)
+    assert len(numbers) == 32 and mdl.m == 64
+    out = mdl.predict(numbers, pos, cell, pbc, cov=True)
+    nl = orc.neighbors(pos, cell, pbc, 6.0)
+    i = np.repeat(np.arange(32), np.diff(nl[0]))
+    assert (nl[1] == i).any()  # self images are in the list
+    ref = _oracle_frame(mdl, numbers, pos, cell, nl)
+    np.testing.assert_allclose(out["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
+    assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
+    assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
+    assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
+    np.testing.assert_allclose(out["beta"], ref["beta"] * np.sqrt(mdl._vscale[14]), rtol=0, atol=2e-6)
+    mdl.close()
 
 
 def test_baseline_config2_li256_m128():
