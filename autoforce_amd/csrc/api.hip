@@ -99,6 +99,13 @@ struct sgpr_model {
     int bin_cap = 0;  // slots per bin of the binned copies
     DevBuf<double> d_b_pos;
     DevBuf<int> d_nn_raw, d_b_slot;
+    // reverse pass in gather form (single-process frames): pair records from the forward pass, pair
+    // gradients G, and the reverse index (neighbor.hip) that lets the last kernel sum them per atom
+    DevBuf<int> d_kslot, d_aux;
+    DevBuf<unsigned short> d_T;
+    int t_stride = 0;
+    bool gather_ok = true;   // false: bin capacity / list length beyond the reverse-index format -> scatter form
+    DevBuf<double> d_prec, d_G;
     DevBuf<double> d_gpart;
     DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
@@ -106,7 +113,7 @@ struct sgpr_model {
     bool chol_valid = false, r1_valid = false;
     double chol_ridge = 0.0, chol_dmean = 0.0;
     // per-step work arrays (local rows)
-    DevBuf<double> d_Pn, d_norm, d_C, d_dC, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
+    DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
@@ -144,52 +151,38 @@ __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, d
 }
 
 // packed = [F(3N) | beta(N) | E | virial(9)] in CALLER atom order.
-// The scalar reductions (energy partials of the K_nm tiles, virial partials of the pair kernel,
-// largest neighbour count) are done by one extra workgroup in a fixed order: reproducible sums.
-__global__ __launch_bounds__(256) void finalize_kernel(int N, int cnt, int first, int stride, const int *perm,
-                                                       const int *slot, const double *Fnbr, const double *Fself,
-                                                       const double *csq, int has_beta, const double *vs_sqrt,
-                                                       const double *Epart, int nE, const double *virpart, int nV,
-                                                       double mean_energy, double *packed, const int *nn_raw,
-                                                       int *stat, double *gpart /*unused*/, unsigned *ticket /*unused*/,
-                                                       int *bin_count /*[4096]: cleared for the next step*/)
+// The scalar reductions (energy partials of the K_nm tiles, virial partials of the reverse kernel,
+// largest neighbour count) are done by eleven extra workgroups, one per scalar, in a fixed order:
+// reproducible sums, no hand-shake with the packer workgroups.  (An earlier two-level form — every
+// block reduces a slice, release fence, ticket, last arriver combines — spent most of its 8 us in that
+// dependent chain.)
+struct FinArgs {
+    int N, cnt, first, stride, maxnn, t_stride, has_beta, nE, nV;
+    const int *perm, *slot, *nn, *nbr_j, *aux, *nn_raw;
+    const unsigned short *T;
+    const double *G;            // gather form: [N][maxnn][4]
+    const double *Fnbr, *Fself; // scatter form
+    const double *csq, *vs_sqrt, *Epart, *virpart;
+    double mean_energy;
+    double *packed;
+    int *stat, *bin_count;
+};
+
+// reducer workgroup q: E (0), the nine virial components (1..9), the largest neighbour count (10)
+__device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
 {
-    // Two kinds of workgroup, no hand-shake between them: blocks 0 .. nA-1 put the per-atom results
-    // back in caller order; the last ELEVEN blocks each reduce one scalar (E, nine virial components,
-    // largest neighbour count) in a fixed order, so the sums are reproducible.
-    // The earlier two-level form (every block reduces a slice, release fence, ticket, last arriver
-    // combines) spent most of its 8 us in that dependent chain.
-    const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
-    if (b < nA) {
-        const int i = b * blockDim.x + tid;
-        for (int k = i; k < 4096; k += nA * blockDim.x) bin_count[k] = 0;
-        if (i < N) {
-            const int c = perm[i];
-#pragma unroll
-            for (int k = 0; k < 3; k++) packed[3 * c + k] = Fnbr[3 * i + k] + Fself[3 * i + k];
-            double bt = 0.0;
-            const int il = (i - first) / stride;
-            if (has_beta && i >= first && (i - first) % stride == 0 && il < cnt) {
-                const double v = 1.0 - csq[il];
-                bt = sqrt(v > 0.0 ? v : 0.0) * vs_sqrt[slot[i]];
-            }
-            packed[3 * N + c] = bt;
-        }
-        return;
-    }
-    // reducer block q: E (0), the nine virial components (1..9), the largest neighbour count (10)
     __shared__ double wsum[4];
-    const int q = b - nA, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double s = 0.0;
     if (q == 10) {
         int mx = 0;
-        for (int k = tid; k < cnt; k += 256) mx = max(mx, nn_raw[k]);
+        for (int k = tid; k < f.cnt; k += 256) mx = max(mx, f.nn_raw[k]);
         s = (double)mx;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
     } else {
-        const double *src = q == 0 ? Epart : virpart + (size_t)(q - 1) * nV;
-        const int n = q == 0 ? nE : nV;
+        const double *src = q == 0 ? f.Epart : f.virpart + (size_t)(q - 1) * f.nV;
+        const int n = q == 0 ? f.nE : f.nV;
         for (int k = tid; k < n; k += 256) s += src[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -197,10 +190,75 @@ __global__ __launch_bounds__(256) void finalize_kernel(int N, int cnt, int first
     if (lane == 0) wsum[wave] = s;
     __syncthreads();
     if (tid == 0) {
-        if (q == 10) stat[0] = max(stat[0], (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3])));  // sticky
-        else packed[4 * (size_t)N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? mean_energy : 0.0);
+        if (q == 10) f.stat[0] = max(f.stat[0], (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3])));  // sticky
+        else f.packed[4 * (size_t)f.N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
     }
-    (void)gpart; (void)ticket;
+}
+
+// scatter form (sharded frames): F = atomic part + own part, one thread per atom
+__global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
+{
+    const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
+    if (b >= nA) { finalize_reduce(f, b - nA); return; }
+    const int i = b * blockDim.x + tid;
+    for (int k = i; k < 4096; k += nA * blockDim.x) f.bin_count[k] = 0;
+    if (i < f.N) {
+        const int c = f.perm[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) f.packed[3 * c + k] = f.Fnbr[3 * i + k] + f.Fself[3 * i + k];
+        double bt = 0.0;
+        const int il = (i - f.first) / f.stride;
+        if (f.has_beta && i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt) {
+            const double v = 1.0 - f.csq[il];
+            bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
+        }
+        f.packed[3 * f.N + c] = bt;
+    }
+}
+
+// gather form: one wave per atom i,  F_i = sum_t G[i][t] - sum_t G[j_t][rev_t]  with the reverse index
+// rev_t = T[i][aux[i][t]] (neighbor.hip); lanes over t, fixed shuffle tree: reproducible.
+__global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
+{
+    const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
+    if (b >= nA) { finalize_reduce(f, b - nA); return; }
+    for (int k = b * 256 + tid; k < 4096; k += nA * 256) f.bin_count[k] = 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int i = b * 4 + wave;
+    if (i >= f.N) return;
+    const int n = f.nn[i];
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < n) {
+            const size_t e = (size_t)i * f.maxnn + t;
+            const int j = f.nbr_j[e];
+            // (clamped: an attempt that overflowed a capacity leaves these words unwritten; its results are
+            // discarded by the host, its reads must still stay inside the arrays)
+            const int hs = min(max(f.aux[e], 0), f.t_stride - 1);
+            const int rv = min((int)f.T[(size_t)i * f.t_stride + hs], f.maxnn - 1);
+            const double2 *own = (const double2 *)(f.G + e * 4);
+            const double2 *oth = (const double2 *)(f.G + ((size_t)j * f.maxnn + rv) * 4);
+            const double2 a0 = own[0], a1 = own[1], b0 = oth[0], b1 = oth[1];
+            fx += a0.x - b0.x; fy += a0.y - b0.y; fz += a1.x - b1.x;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        fx += __shfl_xor(fx, o, 64);
+        fy += __shfl_xor(fy, o, 64);
+        fz += __shfl_xor(fz, o, 64);
+    }
+    if (lane == 0) {
+        const int c = f.perm[i];
+        f.packed[3 * (size_t)c] = fx; f.packed[3 * (size_t)c + 1] = fy; f.packed[3 * (size_t)c + 2] = fz;
+        double bt = 0.0;
+        if (f.has_beta) {
+            const double v = 1.0 - f.csq[i];
+            bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
+        }
+        f.packed[3 * (size_t)f.N + c] = bt;
+    }
 }
 
 // ---------------------------------------------------------------------------- host tables
@@ -335,14 +393,15 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
                          &h->d_lnn, &h->d_bin_of, &h->d_bin_count, &h->d_b_idx, &h->d_b_wrap, &h->d_b_slot, &h->d_nn_raw, &h->d_wrap, &h->d_nn,
-                         &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear};
+                         &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear, &h->d_kslot, &h->d_aux};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
-                            &h->d_vs_sqrt, &h->d_gpart, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_dC,
+                            &h->d_vs_sqrt, &h->d_gpart, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed,
                             &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1};
     for (auto b : db) b->release();
     h->d_pack.release();
+    h->d_T.release();
     h->d_grid.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -632,7 +691,6 @@ static int alloc_work(sgpr_model *h)
     bad |= h->d_Pn.alloc((size_t)cr * h->Dpad);
     bad |= h->d_norm.alloc(cr);
     bad |= h->d_C.alloc((size_t)std::max(h->cnt, 1) * h->CS);
-    bad |= h->d_dC.alloc((size_t)std::max(h->cnt, 1) * h->CS);
     bad |= h->d_shear.alloc(cr);
     bad |= h->d_W.alloc((size_t)cr * h->Dpad);
     bad |= h->d_csq.alloc(cr);
@@ -659,7 +717,21 @@ static int ensure_nl(sgpr_model *h, int maxnn)
     int bad = 0;
     bad |= h->d_nbr_j.alloc((size_t)h->N * maxnn, false);
     bad |= h->d_nbr_shift.alloc((size_t)h->N * maxnn, false);
+    bad |= h->d_aux.alloc((size_t)h->N * maxnn, false);
+    bad |= h->d_prec.alloc((size_t)h->N * maxnn * 4, false);
+    bad |= h->d_G.alloc((size_t)h->N * maxnn * 4, false);
     return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (neighbour list, maxnn=%d)", maxnn) : 0;
+}
+
+// reverse-index table: N rows of `stride` 2-byte entries (stride = neighbouring bins x bin capacity)
+static int ensure_rev(sgpr_model *h, int stride)
+{
+    if (stride <= h->t_stride && h->d_T.p) return 0;
+    h->t_stride = stride;
+    drop_graph(h);
+    if (h->d_T.alloc((size_t)std::max(h->N, 1) * stride, false))
+        return fail(SGPR_E_NODEVICE, "hipMalloc failed (reverse index, %d entries per atom)", stride);
+    return 0;
 }
 
 static int ensure_bins(sgpr_model *h, int cap)
@@ -680,6 +752,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
 {
     if (!h || N < 0 || (N > 0 && !numbers) || world < 1 || rank < 0 || rank >= world)
         return fail(SGPR_E_INVALID, "sgpr_bind_system: bad arguments");
+    if (N >= (1 << 24)) return fail(SGPR_E_UNSUPPORTED, "sgpr_bind_system: %d atoms (the neighbour keys hold 24-bit indices)", N);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graph(h);
@@ -721,6 +794,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_pos_in.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_pos.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_bin_of.alloc(std::max(N, 1));
+    bad |= h->d_kslot.alloc(std::max(N, 1));
     bad |= h->d_nn_raw.alloc(h->cnt_rows);
     bad |= h->d_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_nn.alloc(std::max(N, 1));
@@ -738,6 +812,9 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     h->maxnn = 0;
     h->d_nbr_j.release();
     h->d_nbr_shift.release();
+    h->d_T.release();
+    h->t_stride = 0;
+    h->gather_ok = true;
     h->warm = false;
     return alloc_work(h);
 }
@@ -760,6 +837,25 @@ static void stamp(sgpr_model *h, const char *name, hipStream_t st)
     (void)hipEventRecord(h->ev[k + 1], st);
 }
 
+// the step's last kernel.  gather: forces from the pair gradients G (reverse pass in gather form);
+// otherwise from the two force buffers of the scatter form (zero when no reverse pass ran).
+static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool beta, double mean_energy,
+                            double *packed_dev, hipStream_t st)
+{
+    const int N = h->N;
+    FinArgs f = {};
+    f.N = N; f.cnt = h->cnt; f.first = h->rank; f.stride = h->world; f.maxnn = h->maxnn; f.t_stride = h->t_stride;
+    f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV;
+    f.perm = h->d_perm.p; f.slot = h->d_slot.p; f.nn = h->d_nn.p; f.nbr_j = h->d_nbr_j.p; f.aux = h->d_aux.p;
+    f.nn_raw = h->d_nn_raw.p; f.T = h->d_T.p; f.G = h->d_G.p; f.Fnbr = h->d_F.p; f.Fself = h->d_F.p + 3 * (size_t)N;
+    f.csq = h->d_csq.p; f.vs_sqrt = h->d_vs_sqrt.p; f.Epart = h->d_Epart.p; f.virpart = h->d_virpart.p;
+    f.mean_energy = mean_energy; f.packed = packed_dev; f.stat = h->d_stat.p; f.bin_count = h->d_bin_count.p;
+    if (gather)
+        hipLaunchKernelGGL(finalize_gather_kernel, dim3((std::max(N, 1) + 3) / 4 + 11), dim3(256), 0, st, f);
+    else
+        hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256 + 11), dim3(256), 0, st, f);
+}
+
 static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell_dev, double *packed_dev,
                         hipStream_t st)
 {
@@ -777,8 +873,13 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     NlParams np = {};
     np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
+    // single-process frames: reverse pass in gather form (reverse index from the list build, pair
+    // gradients summed by the last kernel); sharded frames scatter with atomics (remote atoms' lists
+    // are not built here)
+    const bool gather = h->world == 1 && h->gather_ok && h->d_T.p != nullptr;
     NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_count.p, h->bin_cap, h->d_b_idx.p, h->d_b_pos.p,
-                    h->d_b_wrap.p, h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_nn_raw.p};
+                    h->d_b_wrap.p, h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_nn_raw.p,
+                    h->d_kslot.p, h->d_aux.p, gather ? h->d_T.p : nullptr, h->t_stride};
     for (int phase = 1; phase <= 2; phase++) {
         launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
                              h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, phase, st);
@@ -790,7 +891,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     for (int k = 0; k < SGPR_MAX_S; k++) dp.radii_v[k] = k < h->S ? h->radii[k] : 1.0;
     int rcd = launch_descriptor_forward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
                                         h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
-                                        h->d_C.p, h->d_shear.p, st);
+                                        h->d_C.p, h->d_shear.p, h->d_prec.p, st);
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
     stamp(h, "descriptor_fwd", st);
     const bool predict = h->m > 0 && h->has_mu && cnt > 0 && !h->rows_mu;
@@ -824,20 +925,14 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         stamp(h, "gemm_covloss", st);
     }
     if (predict) {
-        for (int phase = 1; phase <= 2; phase++) {
-            rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
-                                             h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
-                                             h->d_C.p, h->d_shear.p, h->d_W.p, h->d_dC.p, h->d_F.p, h->d_virpart.p,
-                                             phase, st);
-            if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
-            stamp(h, phase == 1 ? "descriptor_dc" : "descriptor_pair", st);
-        }
+        rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p, h->d_nbr_j.p,
+                                         h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p,
+                                         h->d_W.p, h->d_prec.p, gather ? h->d_G.p : nullptr, h->d_F.p, h->d_virpart.p, st);
+        if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
+        stamp(h, "descriptor_rev", st);
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256 + 11), dim3(256), 0, st, N, cnt, h->rank,
-                       h->world, h->d_perm.p, h->d_slot.p, h->d_F.p, h->d_F.p + 3 * (size_t)N, h->d_csq.p,
-                       beta ? 1 : 0, h->d_vs_sqrt.p, h->d_Epart.p, predict ? h->epart_len : 0, h->d_virpart.p,
-                       predict ? h->virpart_len : 0, h->mean_energy, packed_dev, h->d_nn_raw.p, h->d_stat.p,
-                       h->d_gpart.p, (unsigned *)(h->d_stat.p + 2), h->d_bin_count.p);
+    launch_finalize(h, gather && predict, predict ? h->epart_len : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
+                    packed_dev, st);
     stamp(h, "finalize", st);
     return SGPR_OK;
 }
@@ -854,25 +949,43 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         const int rc_ = ensure_bins(h, 64);
         if (rc_) return rc_;
     }
+    if (h->world == 1 && h->gather_ok && h->t_stride == 0) {
+        const int rc_ = ensure_rev(h, 27 * h->bin_cap);  // the usual 3x3x3 bins; grown below if the grid needs more
+        if (rc_) return rc_;
+    }
     for (int attempt = 0; attempt < 12; attempt++) {
-        HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 2 * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 3 * sizeof(int), st));
         HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 4096 * sizeof(int), st));
         const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st);
         if (rc_) return rc_;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         int stat[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpy(stat, h->d_stat.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(stat, h->d_stat.p, 3 * sizeof(int), hipMemcpyDeviceToHost));
         if (stat[1] > h->bin_cap) {  // a bin overflowed: grow the bins, the lists of this attempt are incomplete
             int cap = h->bin_cap;
             while (cap < stat[1] + stat[1] / 4) cap *= 2;
             const int rc2 = ensure_bins(h, cap);
             if (rc2) return rc2;
+            if (h->world == 1 && h->gather_ok) {  // the reverse-index rows scale with the bin capacity
+                const int rc3 = ensure_rev(h, std::max(h->t_stride, 27 * cap));
+                if (rc3) return rc3;
+            }
+            continue;
+        }
+        if (stat[2] > h->t_stride && h->world == 1 && h->gather_ok) {
+            // the bin grid has more neighbouring bins than the reverse-index rows hold (small cells with
+            // many images), or a capacity beyond its format: grow, or fall back to the scatter form
+            if (stat[2] == 0x7fffffff || (double)stat[2] * std::max(h->N, 1) > 2e9) h->gather_ok = false;
+            else {
+                const int rc3 = ensure_rev(h, stat[2]);
+                if (rc3) return rc3;
+            }
             continue;
         }
         if (stat[0] <= h->maxnn) {
             h->nn_max_seen = stat[0];
-            HIPCHK(hipMemset(h->d_stat.p, 0, 2 * sizeof(int)));
+            HIPCHK(hipMemset(h->d_stat.p, 0, 3 * sizeof(int)));
             return SGPR_OK;
         }
         if (stat[0] > 100000) return fail(SGPR_E_OVERFLOW, "neighbour count %d is unreasonable", stat[0]);
@@ -986,12 +1099,13 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     int stat[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(stat, h->d_stat.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->d_stat.p, 0, 2 * sizeof(int)));
-    if (stat[0] > h->maxnn || stat[1] > h->bin_cap) {
+    HIPCHK(hipMemcpy(stat, h->d_stat.p, 3 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stat.p, 0, 3 * sizeof(int)));
+    if (stat[0] > h->maxnn || stat[1] > h->bin_cap || (h->world == 1 && h->gather_ok && stat[2] > h->t_stride)) {
         h->warm = false;  // next step re-sizes eagerly
-        return fail(SGPR_E_OVERFLOW, "neighbour-list capacity exceeded (neighbours %d/%d, bin %d/%d); results of "
-                    "the steps since the last check are invalid", stat[0], h->maxnn, stat[1], h->bin_cap);
+        return fail(SGPR_E_OVERFLOW, "neighbour-list capacity exceeded (neighbours %d/%d, bin %d/%d, reverse index %d/%d); "
+                    "results of the steps since the last check are invalid", stat[0], h->maxnn, stat[1], h->bin_cap,
+                    stat[2], h->t_stride);
     }
     h->nn_max_seen = stat[0];
     return SGPR_OK;

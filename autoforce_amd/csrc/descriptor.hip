@@ -38,6 +38,14 @@ __device__ __forceinline__ double uniform(double v)
     return __hiloint2double(hi, lo);
 }
 
+// opaque copy of a wave-uniform pointer: loads through it cannot be hoisted above this point
+template <typename T>
+__device__ __forceinline__ const T *launder(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -51,8 +59,13 @@ struct Harm {
     static constexpr int L1 = LMAX + 1, LL = L1 * L1;
     double A[L1], B[L1], q[L1][L1];
     double x, y, z, rho;
+    // recurrence coefficients: constant memory, read through a pointer so that a kernel short of
+    // SGPRs can re-derive it (launder()) and have the scalar loads issued next to their use instead
+    // of hoisted across its whole tile loop
+    const HarmCoef *hc = &c_hc;
 
-    __device__ __forceinline__ void eval(double x_, double y_, double z_, double *Y)
+    // recurrence state (A, B, q) at (x, y, z); eval()/dot()/backward() build on it
+    __device__ __forceinline__ void prepare(double x_, double y_, double z_)
     {
         x = x_; y = y_; z = z_;
         rho = x * x + y * y + z * z;
@@ -62,15 +75,20 @@ struct Harm {
             A[m] = x * A[m - 1] - y * B[m - 1];
             B[m] = y * A[m - 1] + x * B[m - 1];
         }
-        q[0][0] = c_hc.y00;
+        q[0][0] = hc->y00;
 #pragma unroll
         for (int l = 1; l <= LMAX; l++) {
 #pragma unroll
             for (int m = 0; m <= l - 2; m++)
-                q[l][m] = c_hc.al[l][m] * (z * q[l - 1][m] + rho * c_hc.bl[l][m] * q[l - 2][m]);
-            q[l][l - 1] = c_hc.cl[l] * z * q[l - 1][l - 1];
-            q[l][l] = c_hc.dl[l] * q[l - 1][l - 1];
+                q[l][m] = hc->al[l][m] * (z * q[l - 1][m] + rho * hc->bl[l][m] * q[l - 2][m]);
+            q[l][l - 1] = hc->cl[l] * z * q[l - 1][l - 1];
+            q[l][l] = hc->dl[l] * q[l - 1][l - 1];
         }
+    }
+
+    __device__ __forceinline__ void eval(double x_, double y_, double z_, double *Y)
+    {
+        prepare(x_, y_, z_);
 #pragma unroll
         for (int l = 0; l <= LMAX; l++) {
             Y[l * l] = q[l][0];
@@ -80,6 +98,20 @@ struct Harm {
                 Y[l * l + 2 * m] = SQRT2 * q[l][m] * B[m];
             }
         }
+    }
+
+    // sum_k Y_k w[k] without materialising Y; prepare() must have run.
+    __device__ __forceinline__ double dot(const double *w) const
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l <= LMAX; l++) {
+            s += q[l][0] * w[l * l];
+#pragma unroll
+            for (int m = 1; m <= l; m++)
+                s += SQRT2 * q[l][m] * (A[m] * w[l * l + 2 * m - 1] + B[m] * w[l * l + 2 * m]);
+        }
+        return s;
     }
 
     // reverse pass of eval(): gY = dE/dY  ->  (gx,gy,gz) = dE/d(x,y,z); eval() must have run.
@@ -102,16 +134,16 @@ struct Harm {
         double gzz = 0.0, grho = 0.0;
 #pragma unroll
         for (int l = LMAX; l >= 1; l--) {
-            gq[l - 1][l - 1] += c_hc.dl[l] * gq[l][l];
-            gzz += c_hc.cl[l] * q[l - 1][l - 1] * gq[l][l - 1];
-            gq[l - 1][l - 1] += c_hc.cl[l] * z * gq[l][l - 1];
+            gq[l - 1][l - 1] += hc->dl[l] * gq[l][l];
+            gzz += hc->cl[l] * q[l - 1][l - 1] * gq[l][l - 1];
+            gq[l - 1][l - 1] += hc->cl[l] * z * gq[l][l - 1];
 #pragma unroll
             for (int m = 0; m <= l - 2; m++) {
-                const double g = c_hc.al[l][m] * gq[l][m];
+                const double g = hc->al[l][m] * gq[l][m];
                 gzz += q[l - 1][m] * g;
-                grho += c_hc.bl[l][m] * q[l - 2][m] * g;
+                grho += hc->bl[l][m] * q[l - 2][m] * g;
                 gq[l - 1][m] += z * g;
-                gq[l - 2][m] += rho * c_hc.bl[l][m] * g;
+                gq[l - 2][m] += rho * hc->bl[l][m] * g;
             }
         }
         double gxx = 0.0, gyy = 0.0;
@@ -131,8 +163,7 @@ struct Harm {
 // ---------------------------------------------------------------- kernel arguments
 struct DescArgs {
     int N, Nall, first, stride, maxnn, S, Dc, Dpad, CS;
-    int phase;              // reverse pass: 0 = dE/dc then pair kernel, 1 = dE/dc only, 2 = pair kernel only
-    double rc;
+    double rc, irc;         // cutoff and its reciprocal
     const double *pos;      // [Nall][3] (sorted order)
     const double *cell;     // [9]
     const int *slot;        // [Nall]
@@ -148,7 +179,9 @@ struct DescArgs {
     double *Pn;             // [N][Dpad]
     double *norm;           // [N]
     double *C;              // [N][CS]
-    double *dC;             // [N][CS] dE/dc (reverse pass)
+    double *prec;           // [Nall][maxnn][4] pair records (r_x, r_y, r_z, exp(-d^2/2)): forward -> reverse pass
+    double *G;              // reverse pass, gather form: [Nall][maxnn][4] pair gradients g_t (x, y, z, 0)
+    int rsz;                // reverse pass: doubles of the per-wave scratch region
     int *shear;             // [N]
     const double *W;        // backward: [N][Dpad]
     double *Fnbr;           // backward: [Nall][3] (atomic)
@@ -190,25 +223,30 @@ __device__ __forceinline__ void load_neighbor(const DescArgs &a, int gi, int ia,
     }
 }
 
-// radial weights f_n = g d^(2n) (and dg/dd for the reverse pass)
+// radial weights f_n = g d^(2n) (and dg/dd for the reverse pass); ex = exp(-d^2/2)
 template <int NMAX>
-__device__ __forceinline__ void radial(double d, double u, double rc, double *f, double &g, double &dg)
+__device__ __forceinline__ void radial_ex(double d, double u, double rc, double irc, double ex, double *f, double &g,
+                                          double &dg)
 {
-    // reciprocals instead of fp64 divisions (each is a ~12-instruction sequence on the VALU): the
-    // pair term had 14 of them per evaluation
+    // reciprocals instead of fp64 divisions (each is a ~12-instruction sequence on the VALU)
     const double ud = u * d;
-    const double irc = 1.0 / rc;  // wave-uniform
     const double step = ud < rc ? 1.0 : 0.0;
     const double qq = 1.0 - ud * irc;
     const double cut = step * qq * qq;
     const double dcut = step * (-2.0 * qq * irc) * u;
-    const double ex = exp(-0.5 * d * d);
     g = cut * ex;
     dg = dcut * ex - d * g;
     const double rho = d * d;
     double pw = g;
 #pragma unroll
     for (int n = 0; n <= NMAX; n++) { f[n] = pw; pw *= rho; }
+}
+
+template <int NMAX>
+__device__ __forceinline__ void radial(double d, double u, double rc, double *f, double &g, double &dg, double &ex)
+{
+    ex = exp(-0.5 * d * d);
+    radial_ex<NMAX>(d, u, rc, 1.0 / rc, ex, f, g, dg);
 }
 
 template <int LMAX, int NMAX>
@@ -295,8 +333,17 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
         const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
         if (t < nn) {
             const double d = sqrt(x * x + y * y + z * z);
-            double f[N1], g, dg;
-            radial<NMAX>(d, u, a.rc, f, g, dg);
+            double f[N1], g, dg, ex;
+            radial<NMAX>(d, u, a.rc, f, g, dg, ex);
+            if constexpr (!ENV) {
+                // pair record for the reverse pass: displacement and exp(-d^2/2), read back coalesced
+                // (no second gather of the neighbour's position, no second exp)
+                if (a.prec) {
+                    double2 *dst = (double2 *)(a.prec + ((size_t)gi * a.maxnn + t) * 4);
+                    dst[0] = make_double2(r[0], r[1]);
+                    dst[1] = make_double2(r[2], ex);
+                }
+            }
             double Y[LL];
             Harm<LMAX> h;
             h.eval(x, y - ang * z, ang * y + z, Y);
@@ -408,379 +455,327 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
 }
 
 // =========================================================================== backward
-// Reverse pass in two kernels.
-//  desc_dc_kernel    per atom: G~ = dE/dp^ (packed, from the W GEMM) -> dE/dp -> dE/dc, stored.
-//  desc_pair_kernel  per atom j (one wave), lane = neighbour t at r = x_i - x_j + off.cell:
-//      g_t  = dE_j/dr_jt            (own environment, dE/dc of j from LDS)
-//    MIRROR (single process): the same lane also evaluates the mirrored pair, i.e. atom j seen
-//      from i's environment at -r, with dE/dc of i gathered from global memory:
-//      g'_t = dE_i/dr_ij(-r)   ->   F_j = sum_t (g_t - g'_t)     no atomics, deterministic.
-//    !MIRROR (atoms sharded over ranks: dE/dc of remote atoms is not available): F_i -= g_t by
-//      fp64 atomics into the all-atom force buffer that the ranks then all-reduce.
-//    Virial: sum_t r (x) g_t from the own terms (each ordered pair once).
+// Reverse pass: ONE kernel, one wave64 per atom i (reference: the torch.autograd pass of
+// calculator/active.py:587-599 through descriptor/sesoap.py:161-260).
+//  phase A  G~ = dE/dp^ (packed, from the W GEMM) -> dE/dp -> dE/dc[s][n][lm] of this atom, kept in LDS.
+//  phase B  lane = neighbour t at r = x_j - x_i + off.cell:  g_t = dE_i/dr_it  (ONE evaluation per
+//           ordered pair).  The contraction with the coefficients,
+//               gY[t][lm] = sum_n f_n(t)  dE/dc[s_t][n][lm],   hY[t][lm] = sum_n f_n'(t) dE/dc[s_t][n][lm],
+//           is [neighbours x radial] . [radial x lm]: it runs on v_mfma_f64_16x16x4 (rows = 16
+//           neighbours, K = radial channel, columns = 16 lm; rows of other species are masked in the A
+//           operand), and the per-neighbour rows come back to their lanes through LDS.  The lane then
+//           needs only the harmonic recurrence state (q, A, B) next to the streamed row: 128 VGPRs,
+//           four waves per SIMD, the whole 4096-atom grid resident at once.
+//  output   GATHER: g_t is stored densely, G[i][t][4]; the step's last kernel forms
+//               F_i = sum_t G[i][t] - sum_t G[j_t][rev_t]
+//           with the reverse index from the neighbour-list build (neighbor.hip): 32 B per pair, no
+//           atomics, fixed summation order.
+//           !GATHER (atoms sharded over ranks): F_j -= g_t by fp64 atomics into the all-atom buffer the
+//           ranks all-reduce, F_i += sum_t g_t by the wave.
+//           Virial: sum_t r (x) g_t, one partial per workgroup.
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int LMAX, int NMAX>
+struct RevDims {
+    static constexpr int N1 = NMAX + 1, L1 = LMAX + 1, LL = L1 * L1, NSLOT = N1 * LL;
+    static constexpr int KS = (N1 + 3) / 4;      // MFMA K-steps over the radial channels
+    static constexpr int CB = (LL + 15) / 16;    // MFMA column blocks over lm
+    static constexpr int CH = 48, RB = CH / 16;  // neighbours per tile, MFMA row blocks
+    static constexpr int SP = LL | 1;            // staged row stride (odd: conflict-free ds_read_b64 by row)
+    static constexpr int FS = 8 * KS + 1;        // radial staging row [f | f'] (odd stride)
+};
+
+// doubles of the per-wave scratch region that phase A and the stages of phase B share
 template <int LMAX, int NMAX, int ST>
-__global__ __launch_bounds__(256) void desc_dc_kernel(DescArgs a)
+static int rev_region_doubles(int Dpad)
 {
-    using WL = WaveLds<LMAX, NMAX>;
-    constexpr int N1 = WL::N1, LL = WL::LL, NSLOT = WL::NSLOT;
+    using RD = RevDims<LMAX, NMAX>;
+    const int UT = ST * RD::N1;
+    const int dc = ST * RD::NSLOT + (ST <= 4 ? UT * UT * RD::L1 : Dpad);
+    int r = RD::CH * RD::SP;
+    if (RD::CH * RD::FS > r) r = RD::CH * RD::FS;
+    if (12 * RD::CH > r) r = 12 * RD::CH;
+    if (dc > r) r = dc;
+    return (r + 1) & ~1;
+}
+
+template <int LMAX, int NMAX, int ST, bool GATHER>
+__global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
+{
+    using RD = RevDims<LMAX, NMAX>;
+    constexpr int N1 = RD::N1, L1 = RD::L1, LL = RD::LL, NSLOT = RD::NSLOT;
+    constexpr int KS = RD::KS, CB = RD::CB, CH = RD::CH, RB = RD::RB, SP = RD::SP, FS = RD::FS;
     constexpr int SPL = (NSLOT + 63) / 64;
     extern __shared__ double smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ia = blockIdx.x * 4 + wave;
-    if (ia >= a.N) return;
-    const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
-    // Up to 4 species the packed gradient is expanded into the full symmetric [u][v][l] array in LDS,
-    // which turns the contraction below into stride-1 addressing; 8 slots would need 32 KB per wave
-    // and keep the packed form with computed pair indices.
-    constexpr bool EXPAND = ST <= 4;
-    constexpr int UT = ST * N1, L1 = LMAX + 1;
-    constexpr int GS = EXPAND ? UT * UT * L1 : 0;
-    const int perwave = ST * NSLOT + (EXPAND ? GS : a.Dpad);
-    double *cl = smem + (size_t)wave * perwave;  // [ST][NSLOT]  c  ( = [u][lm], u = s*N1+n )
-    double *gl = cl + ST * NSLOT;                // EXPAND: [UT][UT][L1] else [Dpad]:  dE/dp~ * coef * (1 or 2)
-    const int gi = a.first + ia * a.stride;
-    const int nn = a.nn[gi];
-    const double nrm = a.norm[ia];
-    double *dC = a.dC + (size_t)ia * a.CS;
-    if (!(nn > 0 && nrm > 0.0)) {
-        for (int k = lane; k < a.CS; k += 64) dC[k] = 0.0;
-        return;
-    }
-    const double sden = nrm + SGPR_EPS;
-    constexpr int MAXE = ((UT * (UT + 1)) / 2 * L1 + 63) / 64;
-    const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
-    if constexpr (MAXE <= 10) {
-        // all global reads of this atom are issued up front (W, p^, pack entries, c): one memory
-        // latency instead of three dependent ones
-        double wv[MAXE], pv[MAXE];
-        PackEntry pe[MAXE];
-    #pragma unroll
-        for (int k = 0; k < MAXE; k++) {
-            const int e = lane + 64 * k;
-            const bool in = e < a.Dc;
-            wv[k] = in ? Wi[e] : 0.0;
-            pv[k] = in ? Pi[e] : 0.0;
-            pe[k] = a.pack[in ? e : 0];
-        }
-        double cin[ST][SPL];
-    #pragma unroll
-        for (int s = 0; s < ST; s++)
-    #pragma unroll
-            for (int k = 0; k < SPL; k++) {
-                const int slot = lane + 64 * k;
-                cin[s][k] = (s < a.S && (SPL * 64 == NSLOT || slot < NSLOT)) ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
-            }
-        // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
-        double pw = 0.0;
-    #pragma unroll
-        for (int k = 0; k < MAXE; k++) pw += wv[k] * pv[k];
-        pw = wave_sum(pw);
-        const double corr = pw * sden / nrm;
-        const double isden = 1.0 / sden;
-    #pragma unroll
-        for (int k = 0; k < MAXE; k++) {
-            const int e = lane + 64 * k;
-            if (e < a.Dc) {
-                const double gv = (wv[k] - pv[k] * corr) * isden * pe[k].coef * (pe[k].u == pe[k].v ? 2.0 : 1.0);
-                if constexpr (EXPAND) {
-                    gl[(pe[k].u * UT + pe[k].v) * L1 + pe[k].l] = gv;
-                    gl[(pe[k].v * UT + pe[k].u) * L1 + pe[k].l] = gv;
-                } else
-                    gl[e] = gv;
-            }
-        }
-    #pragma unroll
-        for (int s = 0; s < ST; s++)
-    #pragma unroll
-            for (int k = 0; k < SPL; k++) {
-                const int slot = lane + 64 * k;
-                if (SPL * 64 == NSLOT || slot < NSLOT) cl[s * NSLOT + slot] = cin[s][k];
-            }
-
-    } else {
-        // many species / high lmax: too many entries per lane to hold in registers
-        double pw = 0.0;
-        for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
-        pw = wave_sum(pw);
-        const double corr = pw * sden / nrm;
-        for (int e = lane; e < a.Dc; e += 64) {
-            const PackEntry pe = a.pack[e];
-            const double gv = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
-            if constexpr (EXPAND) {
-                gl[(pe.u * UT + pe.v) * L1 + pe.l] = gv;
-                gl[(pe.v * UT + pe.u) * L1 + pe.l] = gv;
-            } else
-                gl[e] = gv;
-        }
-#pragma unroll
-        for (int s = 0; s < ST; s++)
-#pragma unroll
-            for (int k = 0; k < SPL; k++) {
-                const int slot = lane + 64 * k;
-                if (SPL * 64 == NSLOT || slot < NSLOT)
-                    cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
-            }
-    }
-    wave_sync();
-    // dE/dc[u][lm] = sum_v G[u][v][l] c[v][lm]
-#pragma unroll
-    for (int s = 0; s < ST; s++)
-#pragma unroll
-        for (int k = 0; k < SPL; k++) {
-            const int slot = lane + 64 * k;
-            if ((SPL * 64 == NSLOT || slot < NSLOT) && s < a.S) {
-                const int n = slot / LL, lm = slot % LL;
-                int l = 0;
-#pragma unroll
-                for (int q = 1; q <= LMAX; q++) l += (lm >= q * q) ? 1 : 0;
-                const int u = s * N1 + n;
-                double d = 0.0;
-                if constexpr (EXPAND) {
-                    const double *gu = gl + u * UT * L1 + l;
-#pragma unroll 4
-                    for (int v = 0; v < Ur; v++) d += gu[v * L1] * cl[v * LL + lm];
-                } else {
-                    for (int v = 0; v < Ur; v++) {
-                        const int lo = min(u, v), hi = max(u, v);
-                        const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
-                        d += gl[pair * L1 + l] * cl[v * LL + lm];
-                    }
-                }
-                dC[s * NSLOT + slot] = d;
-            }
-        }
-}
-
-// dE/dr of ONE pair term: neighbour at displacement r (unscaled), unit u, environment shear `ang`,
-// dc = dE/dc[species slot of that neighbour][n][lm] of the environment's centre.
-template <int LMAX, int NMAX, typename Fetch>
-__device__ __forceinline__ void pair_grad(const double r[3], double u, double rc, double ang, Fetch fetch,
-                                          double gr[3])
-{
-    constexpr int N1 = NMAX + 1, LL = (LMAX + 1) * (LMAX + 1);
-    const double iu = 1.0 / u;
-    const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
-    const double d = sqrt(x * x + y * y + z * z);
-    const double id = 1.0 / d;
-    double f[N1], g, dg;
-    radial<NMAX>(d, u, rc, f, g, dg);
-    double Y[LL], gY[LL];
-    Harm<LMAX> h;
-    h.eval(x, y - ang * z, ang * y + z, Y);
-    double dEdd = 0.0;
-#pragma unroll
-    for (int k = 0; k < LL; k++) gY[k] = 0.0;
-    const double rho = d * d;
-    double rpow = 1.0;  // rho^n
-    // rolled over the radial channels on purpose: fully unrolled, the scheduler hoisted all 64
-    // coefficient loads and the kernel needed > 256 VGPRs (1 wave per SIMD)
-#pragma unroll 1
-    for (int n = 0; n < N1; n++) {
-        const double *dcn = fetch(n);  // channel n of dE/dc (LDS)
-        const double fn = g * rpow;    // f_n = g d^(2n)
-        double dEdf = 0.0;
-#pragma unroll
-        for (int k = 0; k < LL; k++) {
-            const double dck = dcn[k];
-            dEdf += dck * Y[k];
-            gY[k] += fn * dck;
-        }
-        // d f_n/dd = dg rho^n + g 2n d^(2n-1)
-        const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow * id : 0.0);
-        dEdd += dEdf * dfn;
-        rpow *= rho;
-    }
-    double gxs, gys, gzs;
-    h.backward(gY, gxs, gys, gzs);
-    // inverse shear (ylm.py:203-213) + radial part, then 1/u
-    const double rad = dEdd * id;
-    gr[0] = (gxs + rad * x) * iu;
-    gr[1] = (gys + ang * gzs + rad * y) * iu;
-    gr[2] = (-ang * gys + gzs + rad * z) * iu;
-}
-
-// The mirrored pass of desc_pair_kernel: as pair_grad, with the coefficient rows of the 64 lanes'
-// neighbours (dC[j][slot][n][:], one row per lane) gathered cooperatively — GR lanes per row, whole
-// cache lines per group of lanes — one radial channel at a time, and SOFTWARE-PIPELINED: channel
-// n+1 is in flight in registers while channel n is contracted out of LDS.  (As a lambda capturing
-// the register array this ended in scratch; here the array is a local of the function that owns
-// the rolled loop.)
-template <int LMAX, int NMAX>
-__device__ __forceinline__ void pair_grad_gathered(const double r[3], double u, double rc, double ang,
-                                                   const double *dC, int CS, int chan_off /*slot*NSLOT*/, int j,
-                                                   double *stage, int lane, double gr[3])
-{
-    constexpr int N1 = NMAX + 1, LL = (LMAX + 1) * (LMAX + 1);
-    constexpr int SP = LL + 2, G = (LL % 2 == 0) ? 2 : 1, GR = LL / G;
-    const double iu = 1.0 / u;
-    const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
-    const double d = sqrt(x * x + y * y + z * z);
-    const double id = 1.0 / d;
-    double f[N1], g, dg;
-    radial<NMAX>(d, u, rc, f, g, dg);
-    double Y[LL], gY[LL];
-    Harm<LMAX> h;
-    h.eval(x, y - ang * z, ang * y + z, Y);
-    double dEdd = 0.0;
-#pragma unroll
-    for (int k = 0; k < LL; k++) gY[k] = 0.0;
-    const double rho = d * d;
-    double rpow = 1.0;
-    double pre[GR][G];
-#define SGPR_GATHER(N)                                                                           \
-    _Pragma("unroll") for (int q = 0; q < GR; q++) {                                            \
-        const int idx = q * 64 + lane;                                                          \
-        const int jr = __shfl(j, idx / GR, 64);                                                 \
-        const double *src = dC + (size_t)jr * CS + chan_off + (N) * LL + (idx % GR) * G;         \
-        if constexpr (G == 2) {                                                                 \
-            const double2 t2 = *(const double2 *)src;                                           \
-            pre[q][0] = t2.x; pre[q][G - 1] = t2.y;                                             \
-        } else                                                                                  \
-            pre[q][0] = *src;                                                                   \
-    }
-    SGPR_GATHER(0)
-#pragma unroll 1
-    for (int n = 0; n < N1; n++) {
-        wave_sync();
-#pragma unroll
-        for (int q = 0; q < GR; q++) {
-            const int idx = q * 64 + lane;
-            double *dst = stage + (idx / GR) * SP + (idx % GR) * G;
-            if constexpr (G == 2)
-                *(double2 *)dst = make_double2(pre[q][0], pre[q][G - 1]);
-            else
-                *dst = pre[q][0];
-        }
-        wave_sync();
-        if (n + 1 < N1) { SGPR_GATHER(n + 1) }
-        const double *dcn = stage + lane * SP;
-        const double fn = g * rpow;
-        double dEdf = 0.0;
-#pragma unroll
-        for (int k = 0; k < LL; k++) {
-            const double dck = dcn[k];
-            dEdf += dck * Y[k];
-            gY[k] += fn * dck;
-        }
-        const double dfn = dg * rpow + (n ? g * 2.0 * n * rpow * id : 0.0);
-        dEdd += dEdf * dfn;
-        rpow *= rho;
-    }
-#undef SGPR_GATHER
-    double gxs, gys, gzs;
-    h.backward(gY, gxs, gys, gzs);
-    const double rad = dEdd * id;
-    gr[0] = (gxs + rad * x) * iu;
-    gr[1] = (gys + ang * gzs + rad * y) * iu;
-    gr[2] = (-ang * gys + gzs + rad * z) * iu;
-}
-
-// PASS 0: own terms + atomic scatter (sharded form); 3: own then mirrored terms in one launch (the
-// single-process form).  (The two halves as separate launches measured 17.5 + 17.5 us against 29.8 us
-// fused: both halves still need ~220 VGPRs, so splitting buys no occupancy.)
-template <int LMAX, int NMAX, int ST, int PASS>
-__global__ __launch_bounds__(256, 2) void desc_pair_kernel(DescArgs a)
-{
-    using WL = WaveLds<LMAX, NMAX>;
-    constexpr int NSLOT = WL::NSLOT, LL = WL::LL;
-    constexpr int SP = LL + 2;                // staged row stride (doubles): 16-B aligned, conflict-free
-    constexpr int G = (LL % 2 == 0) ? 2 : 1;  // doubles per load granule
-    constexpr int GR = LL / G;                // granules per row
-    extern __shared__ double smem[];
     __shared__ double vred[4][9];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave index through readfirstlane: everything derived from it (atom index, LDS bases, row
+    // addresses) is then scalar and stays out of the VGPR budget
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ia = blockIdx.x * 4 + wave;
-    double *dcl = smem + (size_t)wave * (ST * NSLOT + 64 * SP + 12 * 64);  // [S][NSLOT] dE/dc of this atom
-    double *stage = dcl + ST * NSLOT;                            // [64][SP] one channel of 64 mirrored rows
-    double *lv = stage + 64 * SP;                                // [9][64] per-lane virial accumulators
-#pragma unroll
-    for (int k = 0; k < 9; k++) lv[k * 64 + lane] = 0.0;
-    double fsum[3] = {0, 0, 0};
     const bool active = ia < a.N;
+    const int perwave = ST * NSLOT + a.rsz + CH / 2;
+    double *dcl = smem + (size_t)wave * perwave;  // [ST][NSLOT] dE/dc of this atom
+    double *R = dcl + ST * NSLOT;                 // shared scratch region (a.rsz doubles)
+    int *sl = (int *)(R + a.rsz);                 // [CH] species slot per tile row
     const int gi = a.first + (active ? ia : 0) * a.stride;
     const int nn = active ? a.nn[gi] : 0;
-    constexpr bool MIRROR = PASS == 3;
-    if (active && nn > 0) {
-        for (int k = lane; k < a.CS; k += 64) dcl[k] = a.dC[(size_t)ia * a.CS + k];
-        wave_sync();
+    double tot = 0.0;  // lanes < 48 with (lane & 3) == 0: running sum of virial component / force component lane >> 2
+
+    if (nn > 0) {
+        // ---------------------------------------------------------------- phase A: dE/dc -> dcl
+        const double nrm = a.norm[ia];
+        if (!(nrm > 0.0)) {
+            for (int k = lane; k < ST * NSLOT; k += 64) dcl[k] = 0.0;
+        } else {
+            const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
+            // Up to 4 species the packed gradient is expanded into the full symmetric [u][v][l] array in
+            // LDS (stride-1 addressing in the contraction); 8 slots keep the packed form.
+            constexpr bool EXPAND = ST <= 4;
+            constexpr int UT = ST * N1;
+            double *cl = R;                 // [ST][NSLOT]  c  ( = [u][lm], u = s*N1+n )
+            double *gl = R + ST * NSLOT;    // EXPAND: [UT][UT][L1] else [Dpad]:  dE/dp~ * coef * (1 or 2)
+            const double sden = nrm + SGPR_EPS;
+            constexpr int MAXE = ((UT * (UT + 1)) / 2 * L1 + 63) / 64;
+            const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
+            if constexpr (MAXE <= 10) {
+                // all global reads of this atom are issued up front (W, p^, pack entries, c)
+                double wv[MAXE], pv[MAXE];
+                PackEntry pe[MAXE];
+#pragma unroll
+                for (int k = 0; k < MAXE; k++) {
+                    const int e = lane + 64 * k;
+                    const bool in = e < a.Dc;
+                    wv[k] = in ? Wi[e] : 0.0;
+                    pv[k] = in ? Pi[e] : 0.0;
+                    pe[k] = a.pack[in ? e : 0];
+                }
+#pragma unroll
+                for (int s = 0; s < ST; s++)
+#pragma unroll
+                    for (int k = 0; k < SPL; k++) {
+                        const int slot = lane + 64 * k;
+                        if (SPL * 64 == NSLOT || slot < NSLOT)
+                            cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+                    }
+                // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
+                double pw = 0.0;
+#pragma unroll
+                for (int k = 0; k < MAXE; k++) pw += wv[k] * pv[k];
+                pw = wave_sum(pw);
+                const double corr = pw * sden / nrm;
+                const double isden = 1.0 / sden;
+#pragma unroll
+                for (int k = 0; k < MAXE; k++) {
+                    const int e = lane + 64 * k;
+                    if (e < a.Dc) {
+                        const double gv = (wv[k] - pv[k] * corr) * isden * pe[k].coef * (pe[k].u == pe[k].v ? 2.0 : 1.0);
+                        if constexpr (EXPAND) {
+                            gl[(pe[k].u * UT + pe[k].v) * L1 + pe[k].l] = gv;
+                            gl[(pe[k].v * UT + pe[k].u) * L1 + pe[k].l] = gv;
+                        } else
+                            gl[e] = gv;
+                    }
+                }
+            } else {
+                // many species / high lmax: too many entries per lane to hold in registers
+                double pw = 0.0;
+                for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
+                pw = wave_sum(pw);
+                const double corr = pw * sden / nrm;
+                for (int e = lane; e < a.Dc; e += 64) {
+                    const PackEntry pe = a.pack[e];
+                    const double gv = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+                    if constexpr (EXPAND) {
+                        gl[(pe.u * UT + pe.v) * L1 + pe.l] = gv;
+                        gl[(pe.v * UT + pe.u) * L1 + pe.l] = gv;
+                    } else
+                        gl[e] = gv;
+                }
+#pragma unroll
+                for (int s = 0; s < ST; s++)
+#pragma unroll
+                    for (int k = 0; k < SPL; k++) {
+                        const int slot = lane + 64 * k;
+                        if (SPL * 64 == NSLOT || slot < NSLOT)
+                            cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+                    }
+            }
+            wave_sync();
+            // dE/dc[u][lm] = sum_v G[u][v][l] c[v][lm]
+#pragma unroll
+            for (int s = 0; s < ST; s++)
+#pragma unroll
+                for (int k = 0; k < SPL; k++) {
+                    const int slot = lane + 64 * k;
+                    if (SPL * 64 == NSLOT || slot < NSLOT) {
+                        double d = 0.0;
+                        if (s < a.S) {
+                            const int n = slot / LL, lm = slot % LL;
+                            int l = 0;
+#pragma unroll
+                            for (int q = 1; q <= LMAX; q++) l += (lm >= q * q) ? 1 : 0;
+                            const int u = s * N1 + n;
+                            if constexpr (EXPAND) {
+                                const double *gu = gl + u * UT * L1 + l;
+#pragma unroll 4
+                                for (int v = 0; v < Ur; v++) d += gu[v * L1] * cl[v * LL + lm];
+                            } else {
+                                for (int v = 0; v < Ur; v++) {
+                                    const int lo = min(u, v), hi = max(u, v);
+                                    const int pair = lo * Ur - (lo * (lo - 1)) / 2 + (hi - lo);
+                                    d += gl[pair * L1 + l] * cl[v * LL + lm];
+                                }
+                            }
+                        }
+                        dcl[s * NSLOT + slot] = d;
+                    }
+                }
+        }
+        // ---------------------------------------------------------------- phase B: pair terms
         const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
-        const int sc = a.slot[gi];
-        const double uc = unit_of<ST>(a, sc);
-        double pi[3], cell[9];
-#pragma unroll
-        for (int k = 0; k < 3; k++) pi[k] = uniform(a.pos[3 * (size_t)gi + k]);
-#pragma unroll
-        for (int k = 0; k < 9; k++) cell[k] = uniform(a.cell[k]);
-        // pass 1: own terms g_t = dE_j/dr_jt (dE/dc of this atom from LDS)
-        for (int t0 = 0; t0 < nn; t0 += 64) {
+        double *stage = R;  // [CH][SP] one staged row set (hY, then gY); earlier in a tile: [CH][FS] radial rows
+        for (int t0 = 0; t0 < nn; t0 += CH) {
+            const int cnt = min(CH, nn - t0);
+            const bool on = lane < cnt;
             const int t = t0 + lane;
-            if (t < nn) {
-                double r[3], gr[3];
-                int s, j;
-                load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
-                pair_grad<LMAX, NMAX>(r, unit_of<ST>(a, s), a.rc, ang,
-                                      [&](int n) { return (const double *)(dcl + s * NSLOT + n * LL); }, gr);
+            double r[3] = {1.0, 0.0, 0.0}, ex = 0.0;
+            int s = 0, j = 0;
+            if (on) {
+                // the forward pass left (r, exp(-d^2/2)) of every pair: one coalesced 32-B read per lane
+                const size_t e = (size_t)gi * a.maxnn + t;
+                const double2 *src = (const double2 *)(a.prec + e * 4);
+                const double2 p0 = src[0], p1 = src[1];
+                r[0] = p0.x; r[1] = p0.y; r[2] = p1.x; ex = p1.y;
+                s = (a.nbr_shift[e] >> 24) & 0xff;
+                if constexpr (!GATHER) j = a.nbr_j[e];
+            }
+            const double u = unit_of<ST>(a, s);
+            const double iu = 1.0 / u;
+            const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
+            const double d = sqrt(x * x + y * y + z * z);
+            const double id = 1.0 / d;
+            double f[N1], g, dg;
+            radial_ex<NMAX>(d, u, a.rc, a.irc, ex, f, g, dg);
+            wave_sync();  // the previous user of the region (phase A / the previous tile) is done
+            if (on) {
+                // f_n = g d^(2n);  f_n' = dg d^(2n) + 2n g d^(2n-1)
+                double rpow = 1.0;
+                const double rho = d * d;
 #pragma unroll
-                for (int p = 0; p < 3; p++)
+                for (int n = 0; n < 4 * KS; n++) {
+                    stage[lane * FS + n] = n < N1 ? f[n < N1 ? n : 0] : 0.0;
+                    stage[lane * FS + 4 * KS + n] = n < N1 ? dg * rpow + (n ? g * 2.0 * n * rpow * id : 0.0) : 0.0;
+                    rpow *= rho;
+                }
+            }
+            if (lane < CH) sl[lane] = on ? s : -1;
+            wave_sync();
+            // MFMA A operands: lane = (row i = lane & 15, k = lane >> 4) of each row block
+            double af[RB][KS], ah[RB][KS];
+            int sr[RB];
 #pragma unroll
-                    for (int q = 0; q < 3; q++) lv[(3 * p + q) * 64 + lane] += r[p] * gr[q];
+            for (int rb = 0; rb < RB; rb++) {
+                const int row = 16 * rb + (lane & 15);
+                sr[rb] = sl[row];
 #pragma unroll
-                for (int k = 0; k < 3; k++) fsum[k] += gr[k];
-                if constexpr (PASS == 0) {
+                for (int ks = 0; ks < KS; ks++) {
+                    af[rb][ks] = stage[row * FS + 4 * ks + (lane >> 4)];
+                    ah[rb][ks] = stage[row * FS + 4 * KS + 4 * ks + (lane >> 4)];
+                }
+            }
+            wave_sync();  // radial rows are in registers: the region is free for the staged outputs
+            Harm<LMAX> h;
+            h.hc = launder(&c_hc);
+            h.prepare(x, y - ang * z, ang * y + z);
+            double dEdd = 0.0, gxs = 0.0, gys = 0.0, gzs = 0.0;
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                // pass 0: hY = f'.dC (radial derivative part), pass 1: gY = f.dC (angular part)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) {
+                    // row block outermost: one accumulator tile (4 doubles) live at a time; the B
+                    // fragment is re-read from LDS for every row block (one ds_read_b64)
+                    const int n_b = lane >> 4, lm = 16 * cb + (lane & 15);
+#pragma unroll
+                    for (int rb = 0; rb < RB; rb++) {
+                        v4d D = (v4d){0.0, 0.0, 0.0, 0.0};
+                        for (int sp = 0; sp < a.S; sp++) {
+                            if (__ballot(sr[rb] == sp) == 0ull) continue;
+#pragma unroll
+                            for (int ks = 0; ks < KS; ks++) {
+                                const int n = 4 * ks + n_b;
+                                const bool ok = n < N1 && lm < LL;
+                                const double bv = dcl[sp * NSLOT + (ok ? n * LL + lm : 0)];
+                                const double av = pass == 0 ? ah[rb][ks] : af[rb][ks];
+                                D = __builtin_amdgcn_mfma_f64_16x16x4f64(sr[rb] == sp ? av : 0.0, ok ? bv : 0.0, D, 0, 0, 0);
+                            }
+                        }
+                        // C/D map of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+                        if (CB * 16 == LL || lm < LL) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) stage[(16 * rb + (lane >> 4) + 4 * q) * SP + lm] = D[q];
+                        }
+                    }
+                }
+                wave_sync();
+                if (on) {
+                    if (pass == 0) dEdd = h.dot(stage + lane * SP);
+                    else {
+                        h.hc = launder(h.hc);
+                        h.backward(stage + lane * SP, gxs, gys, gzs);
+                    }
+                }
+                wave_sync();
+            }
+            // inverse shear (ylm.py:203-213) + radial part, then 1/u
+            const double rad = dEdd * id;
+            double gr[3];
+            gr[0] = (gxs + rad * x) * iu;
+            gr[1] = (gys + ang * gzs + rad * y) * iu;
+            gr[2] = (-ang * gys + gzs + rad * z) * iu;
+            if (on) {
+                if constexpr (GATHER) {
+                    double2 *dst = (double2 *)(a.G + ((size_t)gi * a.maxnn + t) * 4);
+                    dst[0] = make_double2(gr[0], gr[1]);
+                    dst[1] = make_double2(gr[2], 0.0);
+                } else {
 #pragma unroll
                     for (int k = 0; k < 3; k++) unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
                 }
             }
-        }
-        if constexpr (MIRROR) {
-            // pass 2: mirrored terms g'_t = dE_i/dr_ij(-r): this atom as a neighbour of i, our
-            // species slot, i's shear state.  The 64 rows dC[i][our slot][n][:] are fetched
-            // cooperatively, one radial channel at a time, GR lanes per row (whole cache lines per
-            // quad of lanes), and handed to their lanes through LDS: a per-lane 512-B gather costs
-            // 4x the TA cycles.
-            for (int t0 = 0; t0 < nn; t0 += 64) {
-                const int t = t0 + lane;
-                const bool on = t < nn;
-                double r[3] = {-1.0, 0.0, 0.0}, gm[3];
-                int s = sc, j = gi;
-                if (on) {
-                    load_neighbor<false>(a, gi, ia, t, pi, cell, r, s, j);
-                    r[0] = -r[0]; r[1] = -r[1]; r[2] = -r[2];
-                }
-                const double angm = a.shear[j] ? SGPR_TINY_ANGLE : 0.0;
-                pair_grad_gathered<LMAX, NMAX>(r, uc, a.rc, angm, a.dC, a.CS, sc * NSLOT, j, stage, lane, gm);
-                if (on) {
+            // 9 virial sums (+ 3 force sums in the sharded form) through the region: [12][CH], then 48
+            // lanes each add a quarter of a row and two shuffles finish it
+            if (lane < CH) {
+                const double rv[3] = {x * u, y * u, z * u};  // = r to rounding (r itself is not kept live)
 #pragma unroll
-                    for (int k = 0; k < 3; k++) fsum[k] -= gm[k];
+                for (int p = 0; p < 3; p++)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) stage[(3 * p + q) * CH + lane] = on ? rv[p] * gr[q] : 0.0;
+                if constexpr (!GATHER) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) stage[(9 + k) * CH + lane] = on ? gr[k] : 0.0;
                 }
+            }
+            wave_sync();
+            if (lane < (GATHER ? 36 : 48)) {
+                const double *src = stage + (lane >> 2) * CH + (lane & 3) * (CH / 4);
+                double sacc = 0.0;
+#pragma unroll
+                for (int i = 0; i < CH / 4; i++) sacc += src[i];
+                tot += sacc;
             }
         }
     }
-    // 12 wave sums (force 3 + virial 9) through LDS: the per-lane virial terms already live there as
-    // [9][64]; the force terms join as rows 9..11, then 48 lanes each add a quarter of a row and two
-    // shuffles finish it (12 x 6 shuffle steps on 64-bit values were 144 ds_bpermute per wave)
-#pragma unroll
-    for (int k = 0; k < 3; k++) lv[(9 + k) * 64 + lane] = fsum[k];
-    wave_sync();
-    {
-        const int k = lane >> 2, part = lane & 3;
-        double sacc = 0.0;
-        if (lane < 48) {
-            const double *src = lv + k * 64 + part * 16;
-#pragma unroll
-            for (int i = 0; i < 16; i++) sacc += src[i];
-        }
-        sacc += __shfl_xor(sacc, 1, 64);
-        sacc += __shfl_xor(sacc, 2, 64);
-        if (lane < 48 && part == 0) {
-            if (k < 9) vred[wave][k] = sacc;
-            else if (active) a.Fself[3 * (size_t)gi + (k - 9)] = sacc;
-        }
+    tot += __shfl_xor(tot, 1, 64);
+    tot += __shfl_xor(tot, 2, 64);
+    if (lane < 48 && (lane & 3) == 0) {
+        const int k = lane >> 2;
+        if (k < 9) vred[wave][k] = tot;
+        else if (!GATHER && active) a.Fself[3 * (size_t)gi + (k - 9)] = tot;
     }
     __syncthreads();
-    if (threadIdx.x < 9)
-        a.vir_part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-            vred[0][threadIdx.x] + vred[1][threadIdx.x] + vred[2][threadIdx.x] + vred[3][threadIdx.x];
+    if (wave == 0 && lane < 9)
+        a.vir_part[(size_t)lane * gridDim.x + blockIdx.x] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
 }
 
 // =========================================================================== unpack (tests)
@@ -831,24 +826,25 @@ static int run_fwd(const DescArgs &a, hipStream_t st)
 }
 
 template <int LMAX, int NMAX, int ST>
-static int run_bwd(const DescArgs &a, hipStream_t st)
+static int run_bwd(DescArgs a, hipStream_t st)
 {
     if (a.N <= 0) return 0;
-    using WL = WaveLds<LMAX, NMAX>;
-    const size_t lds1 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + (ST <= 4 ? (ST * WL::N1) * (ST * WL::N1) * (LMAX + 1) : a.Dpad));
-    static size_t attr_set = 0;
-    if (attr_set < lds1) {
-        (void)hipFuncSetAttribute((const void *)desc_dc_kernel<LMAX, NMAX, ST>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        attr_set = lds1;
+    using RD = RevDims<LMAX, NMAX>;
+    a.rsz = rev_region_doubles<LMAX, NMAX, ST>(a.Dpad);
+    const size_t lds = sizeof(double) * 4 * (size_t)(ST * RD::NSLOT + a.rsz + RD::CH / 2);
+    static size_t attr_set[2] = {0, 0};
+    const bool gather = a.G != nullptr;
+    if (attr_set[gather] < lds) {
+        if (gather)
+            (void)hipFuncSetAttribute((const void *)desc_rev_kernel<LMAX, NMAX, ST, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else
+            (void)hipFuncSetAttribute((const void *)desc_rev_kernel<LMAX, NMAX, ST, false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[gather] = lds;
     }
-    if (a.phase != 2) hipLaunchKernelGGL((desc_dc_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds1, st, a);
-    if (a.phase == 1) return 0;
-    const size_t lds2 = sizeof(double) * 4 * (size_t)(ST * WL::NSLOT + 64 * (WL::LL + 2) + 12 * 64);
-    if (a.stride == 1 && a.first == 0 && a.N == a.Nall) {
-        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, 3>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
-    } else
-        hipLaunchKernelGGL((desc_pair_kernel<LMAX, NMAX, ST, 0>), dim3((a.N + 3) / 4), dim3(256), lds2, st, a);
+    if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
     return 0;
 }
 
@@ -881,6 +877,7 @@ static DescArgs make_args(const DescParams &p)
     DescArgs a = {};
     a.N = p.N; a.Nall = p.Nall; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
     a.rc = p.rc;
+    a.irc = 1.0 / p.rc;
     for (int k = 0; k < SGPR_MAX_S; k++) a.radii_v[k] = p.radii_v[k];
     return a;
 }
@@ -892,11 +889,11 @@ static DescArgs make_args(const DescParams &p)
 int launch_descriptor_forward(const DescParams &p, const double *pos, const double *cell, const int *slot,
                               const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
                               const PackEntry *pack, double *Pn, double *norm, double *C, int *shear,
-                              hipStream_t st)
+                              double *prec, hipStream_t st)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
-    a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = Pn; a.norm = norm; a.C = C; a.shear = shear;
+    a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = Pn; a.norm = norm; a.C = C; a.shear = shear; a.prec = prec;
     DISPATCH_LNS(FWD_NL, a, st);
 }
 
@@ -913,16 +910,18 @@ int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, c
 int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell, const int *slot,
                                const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
-                               const int *shear, const double *W, double *dC, double *F, double *virial,
-                               int phase, hipStream_t st)
+                               const int *shear, const double *W, const double *prec, double *G, double *F,
+                               double *virial, hipStream_t st)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
     a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = (double *)Pn; a.norm = (double *)norm; a.C = (double *)C;
-    a.shear = (int *)shear; a.W = W; a.dC = dC; a.phase = phase;
-    // F points at [Fnbr | Fself], virial at the per-wave partial array (see api.hip)
+    a.shear = (int *)shear; a.W = W; a.prec = (double *)prec;
+    // gather form (G != null): pair gradients go to G[Nall][maxnn][4], the step's last kernel sums them.
+    // scatter form: F points at [Fnbr | Fself] (fp64 atomics into Fnbr; sharded frames).
+    a.G = G;
     a.Fnbr = F;
-    a.Fself = F + 3 * (size_t)p.Nall;
+    a.Fself = F ? F + 3 * (size_t)p.Nall : nullptr;
     a.vir_part = virial;
     DISPATCH_LNS(BWD, a, st);
 }

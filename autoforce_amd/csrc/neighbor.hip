@@ -17,6 +17,14 @@
 //                   SORTED by (j, image) with an in-wave bitonic network — the atomic placement
 //                   order inside a bin is not reproducible, the sorted list is — and written out.
 // The bin counters are re-zeroed by the step's last kernel (finalize).
+//
+// Reverse index.  The reverse pass stores one gradient per ordered pair, G[i][t], and atom j needs the
+// entry of every pair (i -> j): the position of j in i's SORTED list.  Both ends can name the pair
+// without knowing each other's list: i found j as candidate (q, k) = (bin offset index, slot in that
+// bin) of its sweep, and j finds i under the mirrored offset nbox-1-q at i's own slot.  So wave i
+// writes its list position t into T[j][(nbox-1-q)*cap + k_i] and remembers aux[i][t] = q*cap + k_j;
+// later atom j reads rev = T[j][aux[j][t']] from its OWN row: one scattered 2-byte store per pair
+// here, one local 2-byte load per pair there, no search.
 #include "sgpr_internal.h"
 
 #define NL_MAX_BINS 4096
@@ -51,6 +59,7 @@ struct BinArgs {
     int *b_slot;            // [nbins][cap] its species slot
     const int *slot;        // [N] species slot by sorted index
     int *bin_of;            // [N]
+    int *kslot;             // [N] slot of the atom inside its bin
     int *wrap;              // [N][3]
     int *stat;              // [4]: [1] = largest bin population seen beyond cap (overflow)
     double *zero_a; int n_zero_a;   // accumulators to clear for this step
@@ -137,6 +146,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     const int bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
     a.bin_of[i] = bin;
     const int k = atomicAdd(&a.bin_count[bin], 1);
+    a.kslot[i] = k;
     if (k < a.cap) {
         const size_t e = (size_t)bin * a.cap + k;
         a.b_idx[e] = i;
@@ -152,10 +162,13 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
                                                        const int *bin_of, const int *bin_count, int cap,
                                                        const int *b_idx, const double *b_pos, const int *b_wrap,
                                                        const int *b_slot, const int *wrap, int maxnn, int *nn,
-                                                       int *nn_local, int *nbr_j, int *nbr_shift, int *nn_raw)
+                                                       int *nn_local, int *nbr_j, int *nbr_shift, int *nn_raw,
+                                                       const int *kslot, int *aux, unsigned short *T, int t_stride,
+                                                       int *stat)
 {
     __shared__ int s_start[4][64], s_pref[4][65], s_code[4][64];
     __shared__ unsigned long long s_key[4][NL_SORT_MAX];
+    __shared__ int s_hq[4][NL_SORT_MAX];  // candidate id (q << 12 | k) of the hit with sweep ordinal o
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int il = blockIdx.x * 4 + wave;
     if (il >= count) return;
@@ -180,6 +193,12 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     const float i_w2 = 1.0f / (float)w2, i_w1 = 1.0f / (float)w1;
     const double r_n0 = 1.0 / g.nb[0], r_n1 = 1.0 / g.nb[1], r_n2 = 1.0 / g.nb[2];
     const int nbox = w0 * w1 * w2;
+    // reverse-index table: row stride nbox*cap entries; a smaller allocation is reported (sticky) and
+    // the host grows it and reruns, like the other capacities
+    const int ki = kslot[i];
+    const bool t_ok = T != nullptr && (long long)nbox * cap <= (long long)t_stride && cap <= 4096 && maxnn <= 65535 &&
+                      ki < cap;  // (ki >= cap: the bin overflowed, the host grows it and reruns the step)
+    if (T != nullptr && !t_ok && ki < cap && lane == 0 && il == 0) atomicMax(&stat[2], cap <= 4096 ? nbox * cap : 0x7fffffff);
     int base = 0;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     unsigned long long *keys = s_key[wave];
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
         for (int c0 = 0; c0 < total; c0 += 64) {
             const int c = c0 + lane;
             bool hit = false;
-            int j = 0, f0 = 0, f1 = 0, f2 = 0, sj = 0;
+            int j = 0, f0 = 0, f1 = 0, f2 = 0, sj = 0, lo_hit = 0, k_hit = 0;
             if (c < total) {
                 // largest b with pref[b] <= c  (empty bins share a prefix value: take the last)
                 int lo = 0, hi = 63;
@@ -225,6 +244,8 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
                 }
                 const int k = s_start[wave][lo] + (c - s_pref[wave][lo]);
                 const int cd = s_code[wave][lo];
+                lo_hit = lo;
+                k_hit = c - s_pref[wave][lo];
                 j = b_idx[k];
                 sj = b_slot[k];
                 f0 = (int)(int8_t)(cd & 0xff) - b_wrap[3 * k] + wi0;
@@ -239,14 +260,24 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int slot = base + __popcll(m & lt);
-                // key: neighbour index, then the image triple (biased to sort as unsigned), then slot
-                const unsigned code = (unsigned)((f0 + 128) & 0xff) << 16 | (unsigned)((f1 + 128) & 0xff) << 8 |
-                                      (unsigned)((f2 + 128) & 0xff) | (unsigned)sj << 24;
-                const unsigned long long key = ((unsigned long long)(unsigned)j << 32) | code;
-                if (slot < NL_SORT_MAX) keys[slot] = key;
-                else if (slot < maxnn) {  // very long lists: keep sweep order beyond the sortable part
-                    nbr_j[(size_t)i * maxnn + slot] = j;
-                    nbr_shift[(size_t)i * maxnn + slot] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+                // key: neighbour index (24 bits), the image triple biased to sort as unsigned (24), species
+                // slot (4), sweep ordinal (12: finds the candidate id again after the sort)
+                const unsigned img = (unsigned)((f0 + 128) & 0xff) << 16 | (unsigned)((f1 + 128) & 0xff) << 8 |
+                                     (unsigned)((f2 + 128) & 0xff);
+                const unsigned long long key = ((unsigned long long)(unsigned)j << 40) | ((unsigned long long)img << 16) |
+                                               ((unsigned long long)(unsigned)sj << 12) | (unsigned)(slot & 0xfff);
+                const int qq = q0 + lo_hit, kk = k_hit;
+                if (slot < NL_SORT_MAX) {
+                    keys[slot] = key;
+                    s_hq[wave][slot] = (qq << 12) | kk;
+                } else if (slot < maxnn) {  // very long lists: keep sweep order beyond the sortable part
+                    const size_t e = (size_t)i * maxnn + slot;
+                    nbr_j[e] = j;
+                    nbr_shift[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+                    if (t_ok) {
+                        aux[e] = qq * cap + kk;
+                        T[(size_t)j * t_stride + (size_t)(nbox - 1 - qq) * cap + ki] = (unsigned short)slot;
+                    }
                 }
             }
             base += __popcll(m);
@@ -301,11 +332,19 @@ __global__ __launch_bounds__(256) void nl_build_kernel(int N, int first, int str
     }
     for (int t = lane; t < ns && t < maxnn; t += 64) {
         const unsigned long long key = keys[t];
-        const unsigned code = (unsigned)key;
-        const int f0 = (int)((code >> 16) & 0xff) - 128, f1 = (int)((code >> 8) & 0xff) - 128,
-                  f2 = (int)(code & 0xff) - 128, sj = (int)(code >> 24);
-        nbr_j[(size_t)i * maxnn + t] = (int)(key >> 32);
-        nbr_shift[(size_t)i * maxnn + t] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+        const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
+        const int f0 = (int)((img >> 16) & 0xff) - 128, f1 = (int)((img >> 8) & 0xff) - 128, f2 = (int)(img & 0xff) - 128,
+                  sj = (int)(key >> 12) & 0xf, j = (int)(key >> 40);
+        const size_t e = (size_t)i * maxnn + t;
+        nbr_j[e] = j;
+        nbr_shift[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+        aux[e] = 0;
+        if (t_ok) {
+            const int hq = s_hq[wave][(int)key & 0xfff];
+            const int qq = hq >> 12, kk = hq & 0xfff;
+            aux[e] = qq * cap + kk;
+            T[(size_t)j * t_stride + (size_t)(nbox - 1 - qq) * cap + ki] = (unsigned short)t;
+        }
     }
     if (lane == 0) {
         nn[i] = base < maxnn ? base : maxnn;
@@ -323,12 +362,12 @@ void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_
     a.N = p.N; a.cap = s.cap; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
     for (int k = 0; k < 3; k++) a.pbc[k] = p.pbc[k];
     a.grid = (NlGrid *)s.grid; a.pos = pos; a.bin_count = s.bin_count; a.b_idx = s.b_idx; a.b_pos = s.b_pos;
-    a.b_wrap = s.b_wrap; a.b_slot = s.b_slot; a.slot = s.slot; a.bin_of = s.bin_of; a.wrap = s.wrap; a.stat = s.stat;
+    a.b_wrap = s.b_wrap; a.b_slot = s.b_slot; a.slot = s.slot; a.bin_of = s.bin_of; a.kslot = s.kslot; a.wrap = s.wrap; a.stat = s.stat;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
     if (phase != 2) hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
     if (phase != 1 && p.count > 0)
         hipLaunchKernelGGL(nl_build_kernel, dim3((p.count + 3) / 4), dim3(256), 0, st, p.N, p.first,
                            p.stride > 0 ? p.stride : 1, p.count, pos, cell, rc, (const NlGrid *)s.grid, s.bin_of,
                            s.bin_count, s.cap, s.b_idx, s.b_pos, s.b_wrap, s.b_slot, s.wrap, p.maxnn, nn, nn_local, nbr_j,
-                           nbr_shift, s.nn_raw);
+                           nbr_shift, s.nn_raw, s.kslot, s.aux, s.T, s.t_stride, s.stat);
 }

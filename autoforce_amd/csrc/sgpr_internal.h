@@ -54,8 +54,14 @@ struct NlScratch {
     int *b_slot;       // [4096][cap]
     const int *slot;   // [N] species slot by sorted index (input)
     int *wrap;         // [N][3]
-    int *stat;         // [4]: [0] max neighbour count, [1] max bin population beyond cap (both sticky)
+    int *stat;         // [4]: [0] max neighbour count, [1] max bin population beyond cap, [2] reverse-index
+                       //      row stride needed beyond t_stride (all sticky)
     int *nn_raw;       // [count] unclamped neighbour counts (overflow check)
+    // reverse index (neighbor.hip): null T = not built (sharded frames use the scatter form)
+    int *kslot;        // [N] slot of the atom in its bin
+    int *aux;          // [N][maxnn] candidate id q*cap + k of each list entry
+    unsigned short *T; // [N][t_stride] list position of the pair as seen from the other end
+    int t_stride;
 };
 
 // Bins ALL N atoms (also: gathers pos_in[perm] -> pos in species-sorted order and clears the
@@ -81,21 +87,25 @@ int launch_descriptor_forward(const DescParams &p, const double *pos, const doub
                               const int *slot /*[Nall]*/, const double *radii, const int *nn,
                               const int *nbr_j, const int *nbr_shift, const PackEntry *pack,
                               double *Pn /*[N][Dpad]*/, double *norm /*[N]*/, double *C /*[N][CS]*/,
-                              int *shear /*[N]*/, hipStream_t st);
+                              int *shear /*[N]*/, double *prec /*[Nall][maxnn][4] pair records (r, exp(-d^2/2))*/,
+                              hipStream_t st);
 
 // explicit-environment form for the inducing set: CSR of neighbour vectors instead of a NL
 int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, const int *env_slot,
                                   const double *env_r, const double *radii, const PackEntry *pack,
                                   double *Pn, double *norm, hipStream_t st);
 
+// Reverse pass (one launch).  G != null: gather form, pair gradients stored to G[Nall][maxnn][4] and
+// summed by the finalize kernel through the reverse index of the neighbour list.  G == null: scatter
+// form (sharded frames), fp64 atomics into F[0:3*Nall], own sums into F[3*Nall:6*Nall].
 int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell,
                                const int *slot, const double *radii, const int *nn, const int *nbr_j,
                                const int *nbr_shift, const PackEntry *pack, const double *Pn,
                                const double *norm, const double *C, const int *shear,
-                               const double *W /*[N][Dpad] dE/dp-hat*/, double *dC /*[N][CS] scratch*/,
+                               const double *W /*[N][Dpad] dE/dp-hat*/, const double *prec /*from the forward pass*/,
+                               double *G /*[Nall][maxnn][4] or null*/,
                                double *F /*[2][Nall][3]: atomic part | own part*/,
-                               double *virial /*[9][workgroups]*/, int phase /*0 both, 1 dE/dc, 2 pair*/,
-                               hipStream_t st);
+                               double *virial /*[9][workgroups]*/, hipStream_t st);
 
 // Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
 void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,
