@@ -95,10 +95,11 @@ struct sgpr_model {
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
     DevBuf<char> d_grid;
-    DevBuf<int> d_bin_of, d_bin_count, d_b_idx, d_b_wrap, d_wrap, d_nn, d_nbr_j, d_nbr_shift, d_stat;
+    DevBuf<int> d_bin_of, d_bin_count, d_nn, d_nbr_j, d_nbr_shift, d_stat;
     int bin_cap = 0;  // slots per bin of the binned copies
-    DevBuf<double> d_b_pos;
-    DevBuf<int> d_nn_raw, d_b_slot;
+    DevBuf<BinRec> d_b_rec;
+    DevBuf<BinAux> d_b_aux;
+    DevBuf<int> d_nn_raw;
     // reverse pass in gather form (single-process frames): pair records from the forward pass, pair
     // gradients G, and the reverse index (neighbor.hip) that lets the last kernel sum them per atom
     DevBuf<int> d_kslot, d_aux;
@@ -117,6 +118,7 @@ struct sgpr_model {
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
+    DevBuf<long long> d_pstamps; // SGPR_STAMPS=1 + a -DSGPR_PHASE_STAMPS build: [2][N][8] phase stamps (forward | reverse)
     DevBuf<int4> t_knm, t_w, t_cov, t_kmm, t_wcov;  // working-tile tables of the GEMMs
     int gemm_bm_k = 64, gemm_bm_w = 64;  // rows per tile of t_knm  /  t_w, t_cov, t_wcov
     std::vector<int4> h_t_w, h_t_cov;
@@ -216,8 +218,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
     }
 }
 
-// gather form: one wave per atom i,  F_i = sum_t G[i][t] - sum_t G[j_t][rev_t]  with the reverse index
-// rev_t = T[i][aux[i][t]] (neighbor.hip); lanes over t, fixed shuffle tree: reproducible.
+// gather form: one wave per atom i,  F_i = (sum_t g_it, kept by the reverse kernel) - sum_t' G[i][t']
+// where G[i][t'] is the gradient of the pair (j_t' -> i), stored at i's own list position by the
+// reverse kernel: one coalesced row per wave, fixed shuffle tree: reproducible.
 __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
 {
     const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
@@ -227,20 +230,17 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     const int i = b * 4 + wave;
     if (i >= f.N) return;
     const int n = f.nn[i];
+    double fs = lane < 3 ? f.Fself[3 * (size_t)i + lane] : 0.0;
+    const int c = f.perm[i];
+    const double cs = f.has_beta ? f.csq[i] : 1.0;
+    const double vs = f.has_beta ? f.vs_sqrt[f.slot[i]] : 0.0;
     double fx = 0.0, fy = 0.0, fz = 0.0;
     for (int t0 = 0; t0 < n; t0 += 64) {
         const int t = t0 + lane;
         if (t < n) {
-            const size_t e = (size_t)i * f.maxnn + t;
-            const int j = f.nbr_j[e];
-            // (clamped: an attempt that overflowed a capacity leaves these words unwritten; its results are
-            // discarded by the host, its reads must still stay inside the arrays)
-            const int hs = min(max(f.aux[e], 0), f.t_stride - 1);
-            const int rv = min((int)f.T[(size_t)i * f.t_stride + hs], f.maxnn - 1);
-            const double2 *own = (const double2 *)(f.G + e * 4);
-            const double2 *oth = (const double2 *)(f.G + ((size_t)j * f.maxnn + rv) * 4);
-            const double2 a0 = own[0], a1 = own[1], b0 = oth[0], b1 = oth[1];
-            fx += a0.x - b0.x; fy += a0.y - b0.y; fz += a1.x - b1.x;
+            const double2 *row = (const double2 *)(f.G + ((size_t)i * f.maxnn + t) * 4);
+            const double2 b0 = row[0], b1 = row[1];
+            fx += b0.x; fy += b0.y; fz += b1.x;
         }
     }
 #pragma unroll
@@ -249,15 +249,10 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
         fy += __shfl_xor(fy, o, 64);
         fz += __shfl_xor(fz, o, 64);
     }
-    if (lane == 0) {
-        const int c = f.perm[i];
-        f.packed[3 * (size_t)c] = fx; f.packed[3 * (size_t)c + 1] = fy; f.packed[3 * (size_t)c + 2] = fz;
-        double bt = 0.0;
-        if (f.has_beta) {
-            const double v = 1.0 - f.csq[i];
-            bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
-        }
-        f.packed[3 * (size_t)f.N + c] = bt;
+    if (lane < 3) f.packed[3 * (size_t)c + lane] = fs - (lane == 0 ? fx : lane == 1 ? fy : fz);
+    if (lane == 3) {
+        const double v = 1.0 - cs;
+        f.packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
     }
 }
 
@@ -389,19 +384,43 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                 n, loop / std::max(n, 1), epi / std::max(n, 1), t1 - t0);
         (void)pro;
     }
+    if (h->d_pstamps.p && h->N > 0) {
+        const int N = h->N;
+        std::vector<long long> st((size_t)16 * N);
+        (void)hipMemcpy(st.data(), h->d_pstamps.p, sizeof(long long) * st.size(), hipMemcpyDeviceToHost);
+        for (int pass = 0; pass < 2; pass++) {
+            double d[7] = {0, 0, 0, 0, 0, 0, 0};
+            long long t0 = 1LL << 62, t1 = 0;
+            int cntw = 0;
+            const int np = pass == 0 ? 6 : 3;
+            for (int i = 0; i < h->cnt; i++) {
+                const long long *w = st.data() + ((size_t)pass * N + i) * 8;
+                if (w[0] <= 0 || w[np - 1] <= 0) continue;
+                for (int k = 0; k + 1 < np; k++) d[k] += (double)(w[k + 1] - w[k]);
+                t0 = std::min(t0, w[0]); t1 = std::max(t1, w[np - 1]);
+                cntw++;
+            }
+            fprintf(stderr, "[sgpr stamps] %s: %d waves, cycles per phase:", pass == 0 ? "list+forward (sweep, sort, list out, tiles, c+spectrum)" : "reverse (dE/dc, pairs)", cntw);
+            for (int k = 0; k + 1 < np; k++) fprintf(stderr, " %.0f", d[k] / std::max(cntw, 1));
+            fprintf(stderr, "; first start -> last end %lld\n", t1 - t0);
+        }
+    }
+    h->d_pstamps.release();
     drop_graph(h);
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
-                         &h->d_lnn, &h->d_bin_of, &h->d_bin_count, &h->d_b_idx, &h->d_b_wrap, &h->d_b_slot, &h->d_nn_raw, &h->d_wrap, &h->d_nn,
+                         &h->d_lnn, &h->d_bin_of, &h->d_bin_count, &h->d_nn_raw, &h->d_nn,
                          &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear, &h->d_kslot, &h->d_aux};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
-                            &h->d_vs_sqrt, &h->d_gpart, &h->d_b_pos, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
+                            &h->d_vs_sqrt, &h->d_gpart, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed,
                             &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1};
     for (auto b : db) b->release();
     h->d_pack.release();
     h->d_T.release();
+    h->d_b_rec.release();
+    h->d_b_aux.release();
     h->d_grid.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
@@ -736,15 +755,13 @@ static int ensure_rev(sgpr_model *h, int stride)
 
 static int ensure_bins(sgpr_model *h, int cap)
 {
-    if (cap <= h->bin_cap && h->d_b_idx.p) return 0;
+    if (cap <= h->bin_cap && h->d_b_rec.p) return 0;
     h->bin_cap = cap;
     drop_graph(h);
     const size_t slots = (size_t)4096 * cap;
     int bad = 0;
-    bad |= h->d_b_idx.alloc(slots, false);
-    bad |= h->d_b_slot.alloc(slots, false);
-    bad |= h->d_b_wrap.alloc(3 * slots, false);
-    bad |= h->d_b_pos.alloc(3 * slots, false);
+    bad |= h->d_b_rec.alloc(slots);  // zero-filled: the sweep may read (and discard) slot 0 of an empty bin
+    bad |= h->d_b_aux.alloc(slots);
     return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (bins, cap=%d)", cap) : 0;
 }
 
@@ -796,7 +813,6 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_bin_of.alloc(std::max(N, 1));
     bad |= h->d_kslot.alloc(std::max(N, 1));
     bad |= h->d_nn_raw.alloc(h->cnt_rows);
-    bad |= h->d_wrap.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_nn.alloc(std::max(N, 1));
     bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
     if (bad) return fail(SGPR_E_NODEVICE, "hipMalloc failed (system arrays)");
@@ -871,29 +887,27 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         (void)hipEventRecord(h->ev[0], st);
     }
     NlParams np = {};
-    np.N = N; np.first = h->rank; np.stride = h->world; np.count = cnt; np.maxnn = h->maxnn;
+    np.N = N;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
     // single-process frames: reverse pass in gather form (reverse index from the list build, pair
     // gradients summed by the last kernel); sharded frames scatter with atomics (remote atoms' lists
     // are not built here)
     const bool gather = h->world == 1 && h->gather_ok && h->d_T.p != nullptr;
-    NlScratch sc = {h->d_grid.p, h->d_bin_of.p, h->d_bin_count.p, h->bin_cap, h->d_b_idx.p, h->d_b_pos.p,
-                    h->d_b_wrap.p, h->d_b_slot.p, h->d_slot.p, h->d_wrap.p, h->d_stat.p, h->d_nn_raw.p,
-                    h->d_kslot.p, h->d_aux.p, gather ? h->d_T.p : nullptr, h->t_stride};
-    for (int phase = 1; phase <= 2; phase++) {
-        launch_neighbor_list(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_nn.p, h->d_lnn.p,
-                             h->d_nbr_j.p, h->d_nbr_shift.p, h->d_F.p, 3 * N, h->d_csq.p, cnt, phase, st);
-        stamp(h, phase == 1 ? "neighbor_bin" : "neighbor_build", st);
-    }
+    NlScratch sc = {(NlGrid *)h->d_grid.p, h->d_bin_of.p, h->d_kslot.p, h->d_bin_count.p, h->bin_cap, h->d_b_rec.p,
+                    h->d_b_aux.p, h->d_slot.p, h->d_stat.p, h->d_nn_raw.p, h->d_aux.p, gather ? h->d_T.p : nullptr,
+                    h->t_stride};
+    launch_neighbor_bin(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_F.p, 3 * N, h->d_csq.p, cnt, st);
+    stamp(h, "neighbor_bin", st);
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
     dp.stride = h->world; dp.maxnn = h->maxnn; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
     for (int k = 0; k < SGPR_MAX_S; k++) dp.radii_v[k] = k < h->S ? h->radii[k] : 1.0;
-    int rcd = launch_descriptor_forward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p,
-                                        h->d_nbr_j.p, h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p,
-                                        h->d_C.p, h->d_shear.p, h->d_prec.p, st);
+    if (h->d_stamps.p && h->d_pstamps.n < (size_t)16 * N) h->d_pstamps.alloc((size_t)16 * N);
+    dp.stamps = h->d_stamps.p ? h->d_pstamps.p : nullptr;
+    int rcd = launch_list_forward(dp, sc, h->d_pos.p, cell_dev, h->d_pack.p, h->d_nn.p, h->d_lnn.p, h->d_nbr_j.p,
+                                  h->d_nbr_shift.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p, h->d_prec.p, st);
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
-    stamp(h, "descriptor_fwd", st);
+    stamp(h, "list_forward", st);
     const bool predict = h->m > 0 && h->has_mu && cnt > 0 && !h->rows_mu;
     const bool beta = h->m > 0 && h->has_choli && cnt > 0 && !h->rows_mu;
     if (h->m > 0 && cnt > 0) {
@@ -914,7 +928,17 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     gc.A = h->d_K.p; gc.B = h->d_choli.p; gc.C = nullptr;
     gc.tiles = h->t_cov.p; gc.ntiles = (int)h->t_cov.n; gc.bm = h->gemm_bm_w;
     gc.rowsq = h->d_csq.p;
-    if (predict && beta) {
+    // "overlap" option: the covloss product (MFMA-bound) runs on a side stream next to the reverse pass
+    // (VALU/latency-bound) instead of being grouped with the W product
+    bool forked = false;
+    if (predict && beta && h->use_fork && h->side && !h->profile) {
+        (void)hipEventRecord(h->ev_fork, st);
+        (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
+        launch_gemm_nt(gc, EPI_ROWSQ, h->side);
+        (void)hipEventRecord(h->ev_join, h->side);
+        launch_gemm_nt(gw, EPI_STORE, st);
+        forked = true;
+    } else if (predict && beta) {
         launch_gemm_wcov(gw, gc, h->t_wcov.p, (int)h->t_wcov.n, st);
         stamp(h, "gemm_w_covloss", st);
     } else if (predict) {
@@ -927,10 +951,12 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     if (predict) {
         rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p, h->d_nbr_j.p,
                                          h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p,
-                                         h->d_W.p, h->d_prec.p, gather ? h->d_G.p : nullptr, h->d_F.p, h->d_virpart.p, st);
+                                         h->d_W.p, h->d_prec.p, gather ? h->d_G.p : nullptr, h->d_aux.p,
+                                         h->d_T.p, h->t_stride, h->d_F.p, h->d_virpart.p, st);
         if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
         stamp(h, "descriptor_rev", st);
     }
+    if (forked) (void)hipStreamWaitEvent(st, h->ev_join, 0);
     launch_finalize(h, gather && predict, predict ? h->epart_len : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
                     packed_dev, st);
     stamp(h, "finalize", st);
@@ -954,14 +980,17 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         if (rc_) return rc_;
     }
     for (int attempt = 0; attempt < 12; attempt++) {
-        HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 3 * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 4 * sizeof(int), st));
         HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 4096 * sizeof(int), st));
         const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st);
         if (rc_) return rc_;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         int stat[4] = {0, 0, 0, 0};
-        HIPCHK(hipMemcpy(stat, h->d_stat.p, 3 * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+        if (stat[3])
+            return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 "
+                        "cells from the origin): wrap the positions into the cell");
         if (stat[1] > h->bin_cap) {  // a bin overflowed: grow the bins, the lists of this attempt are incomplete
             int cap = h->bin_cap;
             while (cap < stat[1] + stat[1] / 4) cap *= 2;
@@ -985,7 +1014,7 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         }
         if (stat[0] <= h->maxnn) {
             h->nn_max_seen = stat[0];
-            HIPCHK(hipMemset(h->d_stat.p, 0, 3 * sizeof(int)));
+            HIPCHK(hipMemset(h->d_stat.p, 0, 4 * sizeof(int)));
             return SGPR_OK;
         }
         if (stat[0] > 100000) return fail(SGPR_E_OVERFLOW, "neighbour count %d is unreasonable", stat[0]);
@@ -1099,8 +1128,13 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     int stat[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(stat, h->d_stat.p, 3 * sizeof(int), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->d_stat.p, 0, 3 * sizeof(int)));
+    HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->d_stat.p, 0, 4 * sizeof(int)));
+    if (stat[3]) {
+        h->warm = false;
+        return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 cells "
+                    "from the origin): wrap the positions into the cell; results since the last check are invalid");
+    }
     if (stat[0] > h->maxnn || stat[1] > h->bin_cap || (h->world == 1 && h->gather_ok && stat[2] > h->t_stride)) {
         h->warm = false;  // next step re-sizes eagerly
         return fail(SGPR_E_OVERFLOW, "neighbour-list capacity exceeded (neighbours %d/%d, bin %d/%d, reverse index %d/%d); "
@@ -1115,6 +1149,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
 {
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
+    if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     return fail(SGPR_E_INVALID, "sgpr_set_option: unknown option %s", name);
 }
 

@@ -22,6 +22,7 @@ __constant__ HarmCoef c_hc;
 void upload_harm_coef(const HarmCoef &hc) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_hc), &hc, sizeof(HarmCoef)); }
 
 #define SQRT2 1.4142135623730951
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -169,6 +170,7 @@ struct DescArgs {
     const int *slot;        // [Nall]
     const double *radii;    // [S] (device; ENV path)
     double radii_v[SGPR_MAX_S];  // the same by value: unit lookup is a select chain, no load
+    double radii_iv[SGPR_MAX_S]; // reciprocals
     const int *nn;          // [Nall]
     const int *nbr_j;       // [Nall][maxnn]
     const int *nbr_shift;   // [Nall][maxnn]
@@ -179,8 +181,12 @@ struct DescArgs {
     double *Pn;             // [N][Dpad]
     double *norm;           // [N]
     double *C;              // [N][CS]
+    long long *stamps;      // diagnostic build (-DSGPR_PHASE_STAMPS) only: [N][8] s_memtime per phase
     double *prec;           // [Nall][maxnn][4] pair records (r_x, r_y, r_z, exp(-d^2/2)): forward -> reverse pass
-    double *G;              // reverse pass, gather form: [Nall][maxnn][4] pair gradients g_t (x, y, z, 0)
+    double *G;              // reverse pass, gather form: [Nall][maxnn][4]: G[j][rev] = gradient of the pair (i -> j)
+    const int *aux;         // [Nall][maxnn] candidate id of each list entry   } reverse index of the list build:
+    const unsigned short *T; // [Nall][t_stride]                               } rev = T[i][aux[i][t]]
+    int t_stride;
     int rsz;                // reverse pass: doubles of the per-wave scratch region
     int *shear;             // [N]
     const double *W;        // backward: [N][Dpad]
@@ -196,6 +202,15 @@ __device__ __forceinline__ double unit_of(const DescArgs &a, int s)
     double u = a.radii_v[0];
 #pragma unroll
     for (int q = 1; q < ST; q++) u = (s == q) ? a.radii_v[q] : u;
+    return u;
+}
+
+template <int ST>
+__device__ __forceinline__ double inv_unit_of(const DescArgs &a, int s)
+{
+    double u = a.radii_iv[0];
+#pragma unroll
+    for (int q = 1; q < ST; q++) u = (s == q) ? a.radii_iv[q] : u;
     return u;
 }
 
@@ -454,6 +469,442 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
     }
 }
 
+// =========================================================================== list build + forward
+// One wave64 per atom i (reference: ase NeighborList as driven by descriptor/atoms.py:348-363,:402, then
+// descriptor/sesoap.py:161-260).
+//  sweep   the (2R+1)^3 neighbouring bins, FOUR bins x 16 slots per step (lane = bin of the group, slot):
+//          bin index and population need no search, and the eight steps of a 32-bin chunk issue their
+//          loads back to back (one 32-B + one 8-B record per candidate).  Hits are compacted into LDS
+//          by ballot/popcount and SORTED by (j, image): the placement order inside a bin comes from
+//          atomics and is not reproducible, the sorted list is.  Up to 64 keys sort in registers.
+//  list    neighbour index, image/species code, and the reverse index for the reverse pass: atom i found
+//          j as candidate (q, k) = (bin offset index, slot in that bin); j finds i under the mirrored
+//          offset nbox-1-q at i's own slot.  So i writes its list position t into T[j][(nbox-1-q)*cap+k_i]
+//          and keeps aux[i][t] = q*cap + k_j: later rev = T[i][aux[i][t]] is the position of i in the
+//          list of its t-th neighbour — one scattered 2-byte store per pair, no search.
+//  forward lane = neighbour (tiles of 48): radial weights, solid harmonics, staged in LDS;
+//          c[lm][(s,n)] += sum_t Y[t][lm] f[t][n] [s_t = s] on v_mfma_f64_16x16x4 (K = four neighbours);
+//          power spectrum with one lane per (u,v) pair; norm in-wave.  The displacement and exp(-d^2/2)
+//          of every pair are left in `prec` for the reverse pass.
+#define NL_SORT_MAX 256  // lists up to this length are sorted (longer ones keep sweep order beyond it)
+#ifndef NL_STEPS
+#define NL_STEPS 4
+#endif
+
+struct NlArgs {
+    const NlGrid *grid;
+    const int *bin_of, *kslot, *bin_count;
+    int cap;
+    const BinRec *b_rec;
+    const BinAux *b_aux;
+    int *nn, *nn_local, *nn_raw, *nbr_j, *nbr_shift, *aux;
+    unsigned short *T;
+    int t_stride;
+    int *stat;
+};
+
+#ifdef SGPR_PHASE_STAMPS
+#define PHASE_STAMP(K) if (a.stamps && lane == 0) a.stamps[(size_t)ia * 8 + (K)] = (long long)__builtin_amdgcn_s_memtime()
+#else
+#define PHASE_STAMP(K)
+#endif
+
+template <int LMAX, int NMAX, int ST>
+struct FwdLds {
+    using WL = WaveLds<LMAX, NMAX>;
+    static constexpr int CH = WL::CH;
+    static constexpr int NLV = NL_SORT_MAX + NL_SORT_MAX / 2 + 3 * 64;           // keys | candidate ids | first 64 displacements
+    static constexpr int FWV = CH * WL::N1 + CH * WL::LLP + CH / 2;              // radial rows | harmonic rows | species
+    static constexpr int P4V = ST * WL::NSLOT;                                   // c for the power spectrum
+    static constexpr int RA = (NLV > FWV ? (NLV > P4V ? NLV : P4V) : (FWV > P4V ? FWV : P4V));
+    static constexpr int PW = CH + RA;  // + the keys of the second tile
+};
+
+template <int LMAX, int NMAX, int ST>
+__global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
+{
+    using WL = WaveLds<LMAX, NMAX>;
+    using FL = FwdLds<LMAX, NMAX, ST>;
+    constexpr int N1 = WL::N1, LL = WL::LL, LLP = WL::LLP, NSLOT = WL::NSLOT, CH = WL::CH;
+    constexpr int UC = ST * N1, CBS = (UC + 15) / 16, RBL = (LL + 15) / 16;
+    extern __shared__ double smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ia = blockIdx.x * 4 + wave;
+    if (ia >= a.N) return;  // (no workgroup barrier in this kernel)
+    const int i = a.first + ia * a.stride;
+    double *wbase = smem + (size_t)wave * FL::PW;
+    unsigned long long *k2 = (unsigned long long *)wbase;          // [CH] sorted keys of the second tile
+    double *RA = wbase + CH;
+    unsigned long long *keys = (unsigned long long *)RA;           // [NL_SORT_MAX]   } list build view
+    int *hq = (int *)(RA + NL_SORT_MAX);                           // [NL_SORT_MAX]   }
+    double *rl = RA + NL_SORT_MAX + NL_SORT_MAX / 2;               // [64][3]         }
+    double *fl = RA;                                               // [CH][N1]        } forward view
+    double *Yl = fl + CH * N1;                                     // [CH][LLP]       }
+    int *sl = (int *)(Yl + CH * LLP);                              // [CH]            }
+    double *cl = RA;                                               // [ST][NSLOT]       power-spectrum view
+
+    PHASE_STAMP(0);
+    // ------------------------------------------------------------------ sweep
+    const NlGrid g = *n.grid;
+    const int cap = n.cap, maxnn = a.maxnn;
+    double h[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) h[k] = a.cell[k];
+    const double xi = uniform(a.pos[3 * (size_t)i]), yi = uniform(a.pos[3 * (size_t)i + 1]), zi = uniform(a.pos[3 * (size_t)i + 2]);
+    const int bi = __builtin_amdgcn_readfirstlane(n.bin_of[i]), ki = __builtin_amdgcn_readfirstlane(n.kslot[i]);
+    int wi0 = 0, wi1 = 0, wi2 = 0;
+    if (ki < cap) {  // (ki >= cap: the bin overflowed, the host grows it and reruns the step)
+        const BinAux own = n.b_aux[(size_t)bi * cap + ki];
+        wi0 = own.w0; wi1 = own.w1; wi2 = own.w2;
+    }
+    // index arithmetic without integer division (a ~30-instruction sequence each on this ISA): small
+    // non-negative operands, so floor((q + 1/2) * (1/w)) in fp32 is exact
+    auto fdiv = [](int q, float inv) { return (int)(((float)q + 0.5f) * inv); };
+    const float i_n2 = 1.0f / (float)g.nb[2], i_n1 = 1.0f / (float)g.nb[1];
+    const int bq = fdiv(bi, i_n2);
+    const int b2 = bi - bq * g.nb[2];
+    const int b0 = fdiv(bq, i_n1);
+    const int b1 = bq - b0 * g.nb[1];
+    const int w0 = 2 * g.rng[0] + 1, w1 = 2 * g.rng[1] + 1, w2 = 2 * g.rng[2] + 1;
+    const float i_w2 = 1.0f / (float)w2, i_w1 = 1.0f / (float)w1;
+    const double r_n0 = 1.0 / g.nb[0], r_n1 = 1.0 / g.nb[1], r_n2 = 1.0 / g.nb[2];
+    const int nbox = w0 * w1 * w2;
+    // reverse-index table: row stride nbox*cap entries; a smaller allocation is reported (sticky) and
+    // the host grows it and reruns, like the other capacities
+    const bool t_ok = n.T != nullptr && (long long)nbox * cap <= (long long)n.t_stride && cap <= 4096 && maxnn <= 65535 &&
+                      ki < cap;
+    if (n.T != nullptr && !t_ok && ki < cap && lane == 0 && ia == 0)
+        atomicMax(&n.stat[2], cap <= 4096 && maxnn <= 65535 ? nbox * cap : 0x7fffffff);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int grp = lane >> 4, s16 = lane & 15;
+    const double rc2_lo = a.rc * a.rc * (1.0 - 1e-14), rc2_hi = a.rc * a.rc * (1.0 + 1e-14);
+    int base = 0;
+    bool near = false;
+    // one candidate per lane: distance test, compaction, key
+    auto consume = [&](bool valid, const BinRec &rec, const BinAux &ax, int code, int q, int k) {
+        bool hit = false;
+        int f0 = 0, f1 = 0, f2 = 0;
+        double dx = 0.0, dy = 0.0, dz = 0.0;
+        if (valid) {
+            f0 = (int)(int8_t)(code & 0xff) - ax.w0 + wi0;
+            f1 = (int)(int8_t)((code >> 8) & 0xff) - ax.w1 + wi1;
+            f2 = (int)(int8_t)((code >> 16) & 0xff) - ax.w2 + wi2;
+            dx = rec.x - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
+            dy = rec.y - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
+            dz = rec.z - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
+            // |r| < rc on the squared distance; only within a few ulp of the cutoff the square root decides
+            // (the pair rule of the reference list is on |r| itself)
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            bool in = d2 < rc2_lo;
+            if (!in && d2 < rc2_hi) in = sqrt(d2) < a.rc;
+            hit = in && !(rec.idx == i && f0 == 0 && f1 == 0 && f2 == 0);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int slot = base + __popcll(m & lt);
+            const int j = rec.idx, sj = ax.slot;
+            // key: neighbour index (24 bits), the image triple biased to sort as unsigned (24), species
+            // slot (4), sweep ordinal (12: finds candidate id and displacement again after the sort)
+            const unsigned img = (unsigned)((f0 + 128) & 0xff) << 16 | (unsigned)((f1 + 128) & 0xff) << 8 |
+                                 (unsigned)((f2 + 128) & 0xff);
+            const unsigned long long key = ((unsigned long long)(unsigned)j << 40) | ((unsigned long long)img << 16) |
+                                           ((unsigned long long)(unsigned)sj << 12) | (unsigned)(slot & 0xfff);
+            if (max(max(abs(f0), abs(f1)), abs(f2)) > 127) atomicMax(&n.stat[3], 1);  // image shift beyond the packed code
+            if (slot < NL_SORT_MAX) {
+                keys[slot] = key;
+                hq[slot] = (q << 12) | k;
+                if (slot < 64) { rl[3 * slot] = dx; rl[3 * slot + 1] = dy; rl[3 * slot + 2] = dz; }
+            } else if (slot < maxnn) {  // very long lists: keep sweep order beyond the sortable part
+                const size_t e = (size_t)i * maxnn + slot;
+                n.nbr_j[e] = j;
+                n.nbr_shift[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+                n.aux[e] = 0;
+                if (t_ok) {
+                    n.aux[e] = q * cap + k;
+                    n.T[(size_t)j * n.t_stride + (size_t)(nbox - 1 - q) * cap + ki] = (unsigned short)slot;
+                }
+            }
+            // does the neighbour sit inside the z cone? (ylm.py:10-23: then the whole environment shears)
+            // (the length unit scales all three components alike)
+            const double tol = SGPR_TINY_ANGLE * fabs(dz);
+            near |= (fabs(dx) < tol) && (fabs(dy) < tol);
+        }
+        base += __popcll(m);
+    };
+    constexpr int STEPS = NL_STEPS;  // steps (of four bins) whose loads are requested together
+    for (int q0 = 0; q0 < nbox; q0 += 64) {
+        // lane = neighbouring bin: index, image code and population of up to 64 bins with one load
+        int nbin_l = 0, code_l = 0, cnt_l = 0;
+        {
+            const int q = q0 + lane;
+            if (q < nbox) {
+                const int qa = fdiv(q, i_w2), qb = fdiv(qa, i_w1);
+                const int o2 = q - qa * w2 - g.rng[2], o1 = qa - qb * w1 - g.rng[1], o0 = qb - g.rng[0];
+                const int t0 = b0 + o0, t1 = b1 + o1, t2 = b2 + o2;
+                const int c0 = (int)floor((double)t0 * r_n0 + 1e-9), c1 = (int)floor((double)t1 * r_n1 + 1e-9),
+                          c2 = (int)floor((double)t2 * r_n2 + 1e-9);
+                nbin_l = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
+                code_l = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16);
+                cnt_l = min(n.bin_count[nbin_l], cap);
+            }
+        }
+        const int nsteps = (min(64, nbox - q0) + 3) >> 2;
+        for (int u0 = 0; u0 < nsteps; u0 += STEPS) {
+            // step u of the chunk: the 16 lanes of group grp take bin 4*(u0+u) + grp
+            int nbin[STEPS], code[STEPS], cnt[STEPS], cmax = 0;
+#pragma unroll
+            for (int u = 0; u < STEPS; u++) {
+                const int src = 4 * (u0 + u) + grp;  // (>= 64 only beyond nsteps: masked below)
+                nbin[u] = __shfl(nbin_l, src & 63, 64);
+                code[u] = __shfl(code_l, src & 63, 64);
+                cnt[u] = u0 + u < nsteps ? __shfl(cnt_l, src & 63, 64) : 0;
+                cmax = max(cmax, cnt[u]);
+            }
+            // 16 slots of every bin per pass: one pass unless a bin holds more than 16 atoms
+            for (int s0 = 0; __any(s0 < cmax); s0 += 16) {
+                BinRec rec[STEPS];
+                BinAux ax[STEPS];
+#pragma unroll
+                for (int u = 0; u < STEPS; u++) {
+                    const size_t e = (size_t)nbin[u] * cap + (s0 + s16 < cnt[u] ? s0 + s16 : 0);
+                    rec[u] = n.b_rec[e];
+                    ax[u] = n.b_aux[e];
+                }
+#pragma unroll
+                for (int u = 0; u < STEPS; u++)
+                    if (__any(s0 + s16 < cnt[u]))
+                        consume(s0 + s16 < cnt[u], rec[u], ax[u], code[u], q0 + 4 * (u0 + u) + grp, s0 + s16);
+            }
+        }
+    }
+    const bool shear = __any(near);
+    PHASE_STAMP(1);
+    // ------------------------------------------------------------------ sort
+    // bitonic sort of the first min(base, NL_SORT_MAX) keys.  Up to 64 keys (the usual case) sort in
+    // registers, one key per lane, partners by cross-lane shuffle: a third of the instructions of the
+    // LDS network below and no barriers.
+    const int ns = min(base, NL_SORT_MAX);
+    wave_sync();
+    if (ns <= 64) {
+        unsigned long long key = lane < ns ? keys[lane] : ~0ull;
+#pragma unroll
+        for (int k2s = 2; k2s <= 64; k2s <<= 1)
+#pragma unroll
+            for (int j2 = k2s >> 1; j2 > 0; j2 >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)key, j2, 64), hi = __shfl_xor((unsigned)(key >> 32), j2, 64);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                const bool lower = (lane & j2) == 0, up = (lane & k2s) == 0;
+                const bool take_min = lower == up;  // the lower lane of a pair keeps the smaller key in an ascending block
+                key = take_min ? (other < key ? other : key) : (other > key ? other : key);
+            }
+        wave_sync();  // all lanes have read their unsorted key
+        if (lane < ns) keys[lane] = key;
+    } else {
+        int np2 = 1;
+        while (np2 < ns) np2 <<= 1;
+        for (int t = ns + lane; t < np2; t += 64) keys[t] = ~0ull;
+        wave_sync();
+        for (int k2s = 2; k2s <= np2; k2s <<= 1)
+            for (int j2 = k2s >> 1; j2 > 0; j2 >>= 1) {
+                for (int t = lane; t < np2; t += 64) {
+                    const int p = t ^ j2;
+                    if (p > t) {
+                        const unsigned long long a0 = keys[t], a1 = keys[p];
+                        const bool up = (t & k2s) == 0;
+                        if ((a0 > a1) == up) { keys[t] = a1; keys[p] = a0; }
+                    }
+                }
+                wave_sync();
+            }
+    }
+    wave_sync();
+    PHASE_STAMP(2);
+    // ------------------------------------------------------------------ list out
+    const int nn = base < maxnn ? base : maxnn;
+    for (int t = lane; t < ns && t < maxnn; t += 64) {
+        const unsigned long long key = keys[t];
+        const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
+        const int f0 = (int)((img >> 16) & 0xff) - 128, f1 = (int)((img >> 8) & 0xff) - 128, f2 = (int)(img & 0xff) - 128,
+                  sj = (int)(key >> 12) & 0xf, j = (int)(key >> 40);
+        const size_t e = (size_t)i * maxnn + t;
+        n.nbr_j[e] = j;
+        n.nbr_shift[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+        int hs = 0;
+        if (t_ok) {
+            const int hv = hq[(int)key & 0xfff];
+            const int qq = hv >> 12, kk = hv & 0xfff;
+            hs = qq * cap + kk;
+            n.T[(size_t)j * n.t_stride + (size_t)(nbox - 1 - qq) * cap + ki] = (unsigned short)t;
+        }
+        n.aux[e] = hs;
+    }
+    if (lane == 0) {
+        n.nn[i] = nn;
+        n.nn_local[ia] = nn;
+        n.nn_raw[ia] = base;  // unclamped: finalize reduces the max for the overflow check
+    }
+    // what the forward tiles need from the list-build view of the region before it is reused: tile 0
+    // keeps key and displacement in registers, tile 1 its keys in k2; further tiles (> 96 neighbours)
+    // read the list back from memory
+    unsigned long long key0 = 0ull;
+    double r0[3] = {1.0, 0.0, 0.0};
+    bool have_r0 = false;
+    if (lane < min(nn, CH)) {
+        key0 = keys[lane];
+        const int ord = (int)key0 & 0xfff;
+        if (ord < 64) { r0[0] = rl[3 * ord]; r0[1] = rl[3 * ord + 1]; r0[2] = rl[3 * ord + 2]; have_r0 = true; }
+    }
+    if (lane < CH && CH + lane < min(nn, NL_SORT_MAX)) k2[lane] = keys[CH + lane];
+    if (nn > 2 * CH) __threadfence();  // rare: the list entries written above are read back below
+    PHASE_STAMP(3);
+    // ------------------------------------------------------------------ forward
+    v4d D[RBL][CBS];
+#pragma unroll
+    for (int rb = 0; rb < RBL; rb++)
+#pragma unroll
+        for (int cb = 0; cb < CBS; cb++) D[rb][cb] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double ang = shear ? SGPR_TINY_ANGLE : 0.0;
+    for (int t0 = 0; t0 < nn; t0 += CH) {
+        const int cnt = min(CH, nn - t0);
+        const bool on = lane < cnt;
+        const int t = t0 + lane;
+        double r[3] = {1.0, 0.0, 0.0};
+        int s = 0;
+        if (on) {
+            int j, f0, f1, f2;
+            bool have_r = false;
+            if (t0 < 2 * CH) {
+                const unsigned long long key = t0 == 0 ? key0 : k2[lane];
+                const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
+                f0 = (int)((img >> 16) & 0xff) - 128; f1 = (int)((img >> 8) & 0xff) - 128; f2 = (int)(img & 0xff) - 128;
+                s = (int)(key >> 12) & 0xf; j = (int)(key >> 40);
+                have_r = t0 == 0 && have_r0;
+            } else {
+                const size_t e = (size_t)i * maxnn + t;
+                j = n.nbr_j[e];
+                const int cd = n.nbr_shift[e];
+                f0 = (int)(int8_t)(cd & 0xff); f1 = (int)(int8_t)((cd >> 8) & 0xff); f2 = (int)(int8_t)((cd >> 16) & 0xff);
+                s = (cd >> 24) & 0xff;
+            }
+            if (have_r) { r[0] = r0[0]; r[1] = r0[1]; r[2] = r0[2]; }
+            else {
+                r[0] = a.pos[3 * (size_t)j] - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
+                r[1] = a.pos[3 * (size_t)j + 1] - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
+                r[2] = a.pos[3 * (size_t)j + 2] - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
+            }
+        }
+        const double u = unit_of<ST>(a, s);
+        const double iu = inv_unit_of<ST>(a, s);
+        const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
+        const double d = sqrt(x * x + y * y + z * z);
+        double f[N1], gg, dg;
+        const double ex = exp(-0.5 * d * d);
+        radial_ex<NMAX>(d, u, a.rc, a.irc, ex, f, gg, dg);
+        double Y[LL];
+        Harm<LMAX> hm;
+        hm.eval(x, y - ang * z, ang * y + z, Y);
+        if (on && a.prec) {
+            // pair record for the reverse pass: displacement and exp(-d^2/2), read back coalesced
+            double2 *dst = (double2 *)(a.prec + ((size_t)i * maxnn + t) * 4);
+            dst[0] = make_double2(r[0], r[1]);
+            dst[1] = make_double2(r[2], ex);
+        }
+        wave_sync();  // the region's previous user (list build / previous tile) is done
+        if (lane < CH) {
+#pragma unroll
+            for (int q = 0; q < N1; q++) fl[lane * N1 + q] = on ? f[q] : 0.0;
+#pragma unroll
+            for (int k = 0; k < LL; k++) Yl[lane * LLP + k] = on ? Y[k] : 0.0;
+            sl[lane] = on ? s : -1;
+        }
+        wave_sync();
+        // c[lm][(s,n)] += sum over the tile's neighbours, four per MFMA: A = Y[t][lm], B = f[t][n] [s_t = s]
+        for (int g4 = 0; g4 < cnt; g4 += 4) {
+            const int tr = g4 + (lane >> 4);
+            const int st = sl[tr];
+            double av[RBL], bv[CBS];
+#pragma unroll
+            for (int rb = 0; rb < RBL; rb++) {
+                const int lm = 16 * rb + (lane & 15);
+                av[rb] = (RBL * 16 == LL || lm < LL) ? Yl[tr * LLP + (lm < LL ? lm : 0)] : 0.0;
+            }
+#pragma unroll
+            for (int cb = 0; cb < CBS; cb++) {
+                const int c = 16 * cb + (lane & 15);
+                const double fv = fl[tr * N1 + (c < UC ? c % N1 : 0)];
+                bv[cb] = (c < UC && st == c / N1) ? fv : 0.0;
+            }
+#pragma unroll
+            for (int rb = 0; rb < RBL; rb++)
+#pragma unroll
+                for (int cb = 0; cb < CBS; cb++)
+                    D[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rb], bv[cb], D[rb][cb], 0, 0, 0);
+        }
+    }
+    wave_sync();
+    PHASE_STAMP(4);
+    // c out of the accumulators (C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg): LDS for the power
+    // spectrum, memory for the reverse pass
+#pragma unroll
+    for (int rb = 0; rb < RBL; rb++)
+#pragma unroll
+        for (int cb = 0; cb < CBS; cb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int lm = 16 * rb + (lane >> 4) + 4 * q, c = 16 * cb + (lane & 15);
+                if ((RBL * 16 == LL || lm < LL) && (CBS * 16 == UC || c < UC)) {
+                    const int idx = (c / N1) * NSLOT + (c % N1) * LL + lm;
+                    cl[idx] = D[rb][cb][q];
+                    if (a.C && c / N1 < a.S) a.C[(size_t)ia * a.CS + idx] = D[rb][cb][q];
+                }
+            }
+    wave_sync();
+    // packed power spectrum: entry e = pair(u<=v)*L1 + l : coef * sum_{lm in l} c[u][lm] c[v][lm].
+    // One lane per (u,v) pair, the l shells and their m sums statically unrolled.
+    double nrm2 = 0.0;
+    constexpr int L1 = LMAX + 1;
+    constexpr int UMAX = ST * N1;
+    constexpr int MAXP = ((UMAX * (UMAX + 1)) / 2 + 63) / 64;
+    const int npair = a.Dc / L1;
+    double pv[MAXP][L1];
+#pragma unroll
+    for (int k = 0; k < MAXP; k++) {
+        const int pr = lane + 64 * k;
+#pragma unroll
+        for (int l = 0; l < L1; l++) pv[k][l] = 0.0;
+        if (pr < npair) {
+            const PackEntry p0 = a.pack[pr * L1];
+            const double *cu = cl + (p0.u / N1) * NSLOT + (p0.u % N1) * LL;
+            const double *cv = cl + (p0.v / N1) * NSLOT + (p0.v % N1) * LL;
+#pragma unroll
+            for (int l = 0; l < L1; l++) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int mm = 0; mm < 2 * l + 1; mm++) sacc += cu[l * l + mm] * cv[l * l + mm];
+                pv[k][l] = sacc * a.pack[pr * L1 + l].coef;
+                nrm2 += pv[k][l] * pv[k][l];
+            }
+        }
+    }
+    nrm2 = wave_sum(nrm2);
+    const double nrm = sqrt(nrm2);
+    const double inv = nn > 0 ? 1.0 / (nrm + SGPR_EPS) : 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXP; k++) {
+        const int pr = lane + 64 * k;
+        if (pr < npair) {
+#pragma unroll
+            for (int l = 0; l < L1; l++) a.Pn[(size_t)ia * a.Dpad + pr * L1 + l] = pv[k][l] * inv;
+        }
+    }
+    for (int e = a.Dc + lane; e < a.Dpad; e += 64) a.Pn[(size_t)ia * a.Dpad + e] = 0.0;
+    if (lane == 0) {
+        a.norm[ia] = nn > 0 ? nrm : 0.0;
+        if (a.shear) a.shear[ia] = shear ? 1 : 0;
+    }
+    PHASE_STAMP(5);
+}
+
 // =========================================================================== backward
 // Reverse pass: ONE kernel, one wave64 per atom i (reference: the torch.autograd pass of
 // calculator/active.py:587-599 through descriptor/sesoap.py:161-260).
@@ -466,15 +917,13 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
 //           operand), and the per-neighbour rows come back to their lanes through LDS.  The lane then
 //           needs only the harmonic recurrence state (q, A, B) next to the streamed row: 128 VGPRs,
 //           four waves per SIMD, the whole 4096-atom grid resident at once.
-//  output   GATHER: g_t is stored densely, G[i][t][4]; the step's last kernel forms
-//               F_i = sum_t G[i][t] - sum_t G[j_t][rev_t]
-//           with the reverse index from the neighbour-list build (neighbor.hip): 32 B per pair, no
-//           atomics, fixed summation order.
+//  output   GATHER: g_t is handed to the neighbour at ITS list position, G[j_t][rev_t] = g_t, with the
+//           reverse index from the neighbour-list build (neighbor.hip); the wave keeps sum_t g_t.  The
+//           step's last kernel forms  F_i = sum_t g_it - sum_t' G[i][t']  from one coalesced row: 32 B
+//           per pair, no atomics, fixed summation order.
 //           !GATHER (atoms sharded over ranks): F_j -= g_t by fp64 atomics into the all-atom buffer the
 //           ranks all-reduce, F_i += sum_t g_t by the wave.
 //           Virial: sum_t r (x) g_t, one partial per workgroup.
-typedef double v4d __attribute__((ext_vector_type(4)));
-
 template <int LMAX, int NMAX>
 struct RevDims {
     static constexpr int N1 = NMAX + 1, L1 = LMAX + 1, LL = L1 * L1, NSLOT = N1 * LL;
@@ -521,6 +970,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
     const int nn = active ? a.nn[gi] : 0;
     double tot = 0.0;  // lanes < 48 with (lane & 3) == 0: running sum of virial component / force component lane >> 2
 
+    PHASE_STAMP(0);
     if (nn > 0) {
         // ---------------------------------------------------------------- phase A: dE/dc -> dcl
         const double nrm = a.norm[ia];
@@ -631,6 +1081,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                     }
                 }
         }
+        PHASE_STAMP(1);
         // ---------------------------------------------------------------- phase B: pair terms
         const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
         double *stage = R;  // [CH][SP] one staged row set (hY, then gY); earlier in a tile: [CH][FS] radial rows
@@ -639,7 +1090,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             const bool on = lane < cnt;
             const int t = t0 + lane;
             double r[3] = {1.0, 0.0, 0.0}, ex = 0.0;
-            int s = 0, j = 0;
+            int s = 0, j = 0, rvp = 0;
             if (on) {
                 // the forward pass left (r, exp(-d^2/2)) of every pair: one coalesced 32-B read per lane
                 const size_t e = (size_t)gi * a.maxnn + t;
@@ -647,10 +1098,16 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                 const double2 p0 = src[0], p1 = src[1];
                 r[0] = p0.x; r[1] = p0.y; r[2] = p1.x; ex = p1.y;
                 s = (a.nbr_shift[e] >> 24) & 0xff;
-                if constexpr (!GATHER) j = a.nbr_j[e];
+                j = a.nbr_j[e];
+                if constexpr (GATHER) {
+                    // where atom j keeps this pair: position of i in j's list.  (Clamped: an attempt that
+                    // overflowed a capacity leaves these words unwritten; the host discards its results.)
+                    const int hs = min(max(a.aux[e], 0), a.t_stride - 1);
+                    rvp = min((int)a.T[(size_t)gi * a.t_stride + hs], a.maxnn - 1);
+                }
             }
             const double u = unit_of<ST>(a, s);
-            const double iu = 1.0 / u;
+            const double iu = inv_unit_of<ST>(a, s);
             const double x = r[0] * iu, y = r[1] * iu, z = r[2] * iu;
             const double d = sqrt(x * x + y * y + z * z);
             const double id = 1.0 / d;
@@ -735,7 +1192,8 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             gr[2] = (-ang * gys + gzs + rad * z) * iu;
             if (on) {
                 if constexpr (GATHER) {
-                    double2 *dst = (double2 *)(a.G + ((size_t)gi * a.maxnn + t) * 4);
+                    // handed to atom j at ITS list position: the last kernel reads whole rows, coalesced
+                    double2 *dst = (double2 *)(a.G + ((size_t)j * a.maxnn + rvp) * 4);
                     dst[0] = make_double2(gr[0], gr[1]);
                     dst[1] = make_double2(gr[2], 0.0);
                 } else {
@@ -751,13 +1209,11 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                 for (int p = 0; p < 3; p++)
 #pragma unroll
                     for (int q = 0; q < 3; q++) stage[(3 * p + q) * CH + lane] = on ? rv[p] * gr[q] : 0.0;
-                if constexpr (!GATHER) {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) stage[(9 + k) * CH + lane] = on ? gr[k] : 0.0;
-                }
+                for (int k = 0; k < 3; k++) stage[(9 + k) * CH + lane] = on ? gr[k] : 0.0;
             }
             wave_sync();
-            if (lane < (GATHER ? 36 : 48)) {
+            if (lane < 48) {
                 const double *src = stage + (lane >> 2) * CH + (lane & 3) * (CH / 4);
                 double sacc = 0.0;
 #pragma unroll
@@ -766,12 +1222,13 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             }
         }
     }
+    PHASE_STAMP(2);
     tot += __shfl_xor(tot, 1, 64);
     tot += __shfl_xor(tot, 2, 64);
     if (lane < 48 && (lane & 3) == 0) {
         const int k = lane >> 2;
         if (k < 9) vred[wave][k] = tot;
-        else if (!GATHER && active) a.Fself[3 * (size_t)gi + (k - 9)] = tot;
+        else if (active) a.Fself[3 * (size_t)gi + (k - 9)] = tot;
     }
     __syncthreads();
     if (wave == 0 && lane < 9)
@@ -878,23 +1335,41 @@ static DescArgs make_args(const DescParams &p)
     a.N = p.N; a.Nall = p.Nall; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
     a.rc = p.rc;
     a.irc = 1.0 / p.rc;
-    for (int k = 0; k < SGPR_MAX_S; k++) a.radii_v[k] = p.radii_v[k];
+    for (int k = 0; k < SGPR_MAX_S; k++) { a.radii_v[k] = p.radii_v[k]; a.radii_iv[k] = 1.0 / p.radii_v[k]; }
     return a;
 }
 
-#define FWD_NL(L, N, S, a, st) run_fwd<L, N, S, false>(a, st)
 #define FWD_ENV(L, N, S, a, st) run_fwd<L, N, S, true>(a, st)
 #define BWD(L, N, S, a, st) run_bwd<L, N, S>(a, st)
 
-int launch_descriptor_forward(const DescParams &p, const double *pos, const double *cell, const int *slot,
-                              const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
-                              const PackEntry *pack, double *Pn, double *norm, double *C, int *shear,
-                              double *prec, hipStream_t st)
+template <int LMAX, int NMAX, int ST>
+static int run_list_fwd(const DescArgs &a, const NlArgs &n, hipStream_t st)
+{
+    if (a.N <= 0) return 0;
+    const size_t lds = sizeof(double) * 4 * (size_t)FwdLds<LMAX, NMAX, ST>::PW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)nl_fwd_kernel<LMAX, NMAX, ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((nl_fwd_kernel<LMAX, NMAX, ST>), dim3((a.N + 3) / 4), dim3(256), lds, st, a, n);
+    return 0;
+}
+#define LISTFWD(L, N, S, a, n, st) run_list_fwd<L, N, S>(a, n, st)
+
+int launch_list_forward(const DescParams &p, const NlScratch &nl, const double *pos, const double *cell,
+                        const PackEntry *pack, int *nn, int *nn_local, int *nbr_j, int *nbr_shift, double *Pn,
+                        double *norm, double *C, int *shear, double *prec, hipStream_t st)
 {
     DescArgs a = make_args(p);
-    a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
-    a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = Pn; a.norm = norm; a.C = C; a.shear = shear; a.prec = prec;
-    DISPATCH_LNS(FWD_NL, a, st);
+    a.stamps = p.stamps;
+    a.pos = pos; a.cell = cell; a.pack = pack; a.Pn = Pn; a.norm = norm; a.C = C; a.shear = shear; a.prec = prec;
+    NlArgs n = {};
+    n.grid = nl.grid; n.bin_of = nl.bin_of; n.kslot = nl.kslot; n.bin_count = nl.bin_count; n.cap = nl.cap;
+    n.b_rec = nl.b_rec; n.b_aux = nl.b_aux; n.nn = nn; n.nn_local = nn_local; n.nn_raw = nl.nn_raw; n.nbr_j = nbr_j;
+    n.nbr_shift = nbr_shift; n.aux = nl.aux; n.T = nl.T; n.t_stride = nl.t_stride; n.stat = nl.stat;
+    DISPATCH_LNS(LISTFWD, a, n, st);
 }
 
 int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, const int *env_slot,
@@ -910,16 +1385,17 @@ int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, c
 int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell, const int *slot,
                                const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
-                               const int *shear, const double *W, const double *prec, double *G, double *F,
-                               double *virial, hipStream_t st)
+                               const int *shear, const double *W, const double *prec, double *G, const int *aux,
+                               const unsigned short *T, int t_stride, double *F, double *virial, hipStream_t st)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
     a.nbr_shift = nbr_shift; a.pack = pack; a.Pn = (double *)Pn; a.norm = (double *)norm; a.C = (double *)C;
     a.shear = (int *)shear; a.W = W; a.prec = (double *)prec;
+    a.stamps = p.stamps ? p.stamps + 8 * (size_t)p.Nall : nullptr;
     // gather form (G != null): pair gradients go to G[Nall][maxnn][4], the step's last kernel sums them.
     // scatter form: F points at [Fnbr | Fself] (fp64 atomics into Fnbr; sharded frames).
-    a.G = G;
+    a.G = G; a.aux = aux; a.T = T; a.t_stride = t_stride;
     a.Fnbr = F;
     a.Fself = F ? F + 3 * (size_t)p.Nall : nullptr;
     a.vir_part = virial;

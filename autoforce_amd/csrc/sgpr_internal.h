@@ -38,38 +38,46 @@ struct DevModel;  // defined in api.hip
 // ---- launchers (each enqueues on `st`, never synchronises) -------------------------------
 struct NlParams {
     int N;            // all atoms (binned)
-    int first, stride, count; // lists are built for sorted atoms first + k*stride, k < count
     int pbc[3];
-    int maxnn;        // capacity per atom
 };
 
+// bin grid of a step, built on the device from the device-resident cell (neighbor.hip)
+struct NlGrid {
+    double inv[9];   // inverse cell (columns = reciprocal vectors): frac = pos . inv
+    int nb[3];       // bins per cell vector
+    int rng[3];      // neighbouring bins searched on either side
+    int nbins;
+    int pad;
+};
+
+// binned copy of an atom: one 32-B record + one 8-B record per candidate of the list sweep
+struct BinRec { double x, y, z; int idx; int pad; };   // position, sorted atom index
+struct BinAux { short w0, w1, w2, slot; };             // wrap (floor of the fractional coordinates), species slot
+
 struct NlScratch {
-    void *grid;        // >= 128 B
+    NlGrid *grid;
     int *bin_of;       // [N]
+    int *kslot;        // [N] slot of the atom in its bin
     int *bin_count;    // [4096] atoms per bin; zero on entry (finalize re-zeroes it)
     int cap;           // slots per bin of the binned copies below
-    int *b_idx;        // [4096][cap]    binned copies
-    double *b_pos;     // [4096][cap][3]
-    int *b_wrap;       // [4096][cap][3]
-    int *b_slot;       // [4096][cap]
+    BinRec *b_rec;     // [4096][cap]
+    BinAux *b_aux;     // [4096][cap]
     const int *slot;   // [N] species slot by sorted index (input)
-    int *wrap;         // [N][3]
     int *stat;         // [4]: [0] max neighbour count, [1] max bin population beyond cap, [2] reverse-index
-                       //      row stride needed beyond t_stride (all sticky)
+                       //      row stride needed beyond t_stride, [3] image shift / wrap beyond the packed formats
+                       //      (all sticky)
     int *nn_raw;       // [count] unclamped neighbour counts (overflow check)
-    // reverse index (neighbor.hip): null T = not built (sharded frames use the scatter form)
-    int *kslot;        // [N] slot of the atom in its bin
+    // reverse index (descriptor.hip, list build): null T = not built (sharded frames use the scatter form)
     int *aux;          // [N][maxnn] candidate id q*cap + k of each list entry
     unsigned short *T; // [N][t_stride] list position of the pair as seen from the other end
     int t_stride;
 };
 
 // Bins ALL N atoms (also: gathers pos_in[perm] -> pos in species-sorted order and clears the
-// step's accumulators zero_a/zero_b), then builds the lists of this rank's atoms.
-void launch_neighbor_list(const NlParams &p, const int *perm, const double *pos_in, double *pos, const double *cell,
-                          double rc, NlScratch s, int *nn /*[N] by sorted index*/, int *nn_local /*[count]*/,
-                          int *nbr_j, int *nbr_shift, double *zero_a, int n_zero_a, double *zero_b, int n_zero_b,
-                          int phase /*0 both, 1 binning, 2 list build*/, hipStream_t st);
+// step's accumulators zero_a/zero_b).  The lists are built by the forward kernel (descriptor.hip).
+void launch_neighbor_bin(const NlParams &p, const int *perm, const double *pos_in, double *pos, const double *cell,
+                         double rc, NlScratch s, double *zero_a, int n_zero_a, double *zero_b, int n_zero_b,
+                         hipStream_t st);
 
 struct DescParams {
     int lmax, nmax, S;
@@ -81,29 +89,33 @@ struct DescParams {
     int CS;           // c stride per atom = S*(nmax+1)*(lmax+1)^2
     double radii_v[SGPR_MAX_S];  // length unit per species slot
     double rc;
+    long long *stamps;  // diagnostic build only (SGPR_STAMPS=1 + -DSGPR_PHASE_STAMPS): [2][Nall][8]
 };
 
-int launch_descriptor_forward(const DescParams &p, const double *pos, const double *cell,
-                              const int *slot /*[Nall]*/, const double *radii, const int *nn,
-                              const int *nbr_j, const int *nbr_shift, const PackEntry *pack,
-                              double *Pn /*[N][Dpad]*/, double *norm /*[N]*/, double *C /*[N][CS]*/,
-                              int *shear /*[N]*/, double *prec /*[Nall][maxnn][4] pair records (r, exp(-d^2/2))*/,
-                              hipStream_t st);
+// Neighbour lists + forward descriptors of this rank's atoms, one launch (one wave per atom): sweep of
+// the neighbouring bins, sorted list (+ reverse index) written for the reverse pass, p^, c, pair records.
+int launch_list_forward(const DescParams &p, const NlScratch &nl, const double *pos, const double *cell,
+                        const PackEntry *pack, int *nn /*[Nall] by sorted index*/, int *nn_local /*[N]*/,
+                        int *nbr_j, int *nbr_shift, double *Pn /*[N][Dpad]*/, double *norm /*[N]*/,
+                        double *C /*[N][CS]*/, int *shear /*[N]*/,
+                        double *prec /*[Nall][maxnn][4] pair records (r, exp(-d^2/2))*/, hipStream_t st);
 
 // explicit-environment form for the inducing set: CSR of neighbour vectors instead of a NL
 int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, const int *env_slot,
                                   const double *env_r, const double *radii, const PackEntry *pack,
                                   double *Pn, double *norm, hipStream_t st);
 
-// Reverse pass (one launch).  G != null: gather form, pair gradients stored to G[Nall][maxnn][4] and
-// summed by the finalize kernel through the reverse index of the neighbour list.  G == null: scatter
-// form (sharded frames), fp64 atomics into F[0:3*Nall], own sums into F[3*Nall:6*Nall].
+// Reverse pass (one launch).  Own sums go to F[3*Nall:6*Nall].  G != null: gather form, the gradient of
+// pair (i -> j) is stored to G[j][rev] (rev = T[i][aux[i][t]], the reverse index of the neighbour list)
+// and the finalize kernel subtracts each atom's row.  G == null: scatter form (sharded frames), fp64
+// atomics into F[0:3*Nall].
 int launch_descriptor_backward(const DescParams &p, const double *pos, const double *cell,
                                const int *slot, const double *radii, const int *nn, const int *nbr_j,
                                const int *nbr_shift, const PackEntry *pack, const double *Pn,
                                const double *norm, const double *C, const int *shear,
                                const double *W /*[N][Dpad] dE/dp-hat*/, const double *prec /*from the forward pass*/,
-                               double *G /*[Nall][maxnn][4] or null*/,
+                               double *G /*[Nall][maxnn][4] or null*/, const int *aux, const unsigned short *T,
+                               int t_stride,
                                double *F /*[2][Nall][3]: atomic part | own part*/,
                                double *virial /*[9][workgroups]*/, hipStream_t st);
 

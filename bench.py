@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--atoms-side", type=int, default=16, help="simple-cubic sites per edge (16 -> 4096 atoms)")
     ap.add_argument("--inducing", type=int, default=512)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--overlap", type=int, default=0, help="1: covloss GEMM on a side stream next to the reverse pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
@@ -143,6 +144,7 @@ def main():
     lib = _lib.load()
     h = mdl.handle
     _lib.check(lib.sgpr_set_option(h, b"graph", 1 if args.graph else 0))
+    _lib.check(lib.sgpr_set_option(h, b"overlap", args.overlap))
 
     dev = torch.device("cuda", local_rank)
     pos_d = torch.from_numpy(pos).to(dev)
