@@ -49,12 +49,16 @@ SIGNATURES = {
     "sgpr_packed_len": (_i64, [C.c_int]),
     "sgpr_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sgpr_sync_check": (C.c_int, [_vp, _vp]),
+    "sgpr_comm_unique_id": (C.c_int, [_vp]),
+    "sgpr_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "sgpr_comm_destroy": (C.c_int, [_vp]),
+    "sgpr_comm_allreduce": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "sgpr_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "sgpr_stress_from_virial": (C.c_int, [_vp, _vp, _vp]),
     "sgpr_get_descriptors": (C.c_int, [_vp, _vp]),
     "sgpr_get_neighbors": (C.c_int, [_vp, _vp, _vp, _vp]),
     "sgpr_get_local": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int]),
-    "sgpr_get_cov": (C.c_int, [_vp, _vp]),
+    "sgpr_get_cov": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "sgpr_get_dims": (C.c_int, [_vp, _vp]),
     "sgpr_profile": (C.c_int, [_vp, C.c_int]),
     "sgpr_get_stage_times": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int]),
@@ -74,12 +78,16 @@ def _preload_host_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    # (librccl.so, which the library links for its all-reduce, is NOT preloaded: torch's copy mapped ahead
+    # of torch's own load order ends the process with a double free at exit; whichever librccl.so.1 is
+    # mapped first — torch's if torch was imported before, else /opt/rocm's — serves both)
+    for name in ("libamdhip64.so",):
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def load():

@@ -132,6 +132,7 @@ class ActiveCalculator(Calculator):
         self.step0_forced_fp = step0_forced_fp
         self.nbeads = nbeads
         self.deltas, self.covlog, self._cov = None, "", None
+        self._cov_gen = None
         self.blind = False
         self._saved_for_tape = None
         self._beta = None
@@ -158,6 +159,23 @@ class ActiveCalculator(Calculator):
             model = PosteriorPotential(model)
         model._sync = self._broadcast if self.process_group is not None else None
         self.model = model
+        self._attach_native_comm()
+
+    def _attach_native_comm(self):
+        """Sharded frames on the HIP engine: the ranks' partial sums are combined inside the library
+        by ONE RCCL all-reduce on the step's stream (sgpr_comm_init); the process group only carries
+        the 128-byte id during set-up.  Engines without that entry point (the CPU oracle engine of the
+        tests) keep the host-side all-reduce of `_evaluate_engine`."""
+        eng = self.model.engine
+        if self.process_group is None or not hasattr(eng, "comm_init"):
+            return
+        import torch.distributed as dist
+        rank, world = self._dist()
+        if world < 2:
+            return
+        box = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.process_group, 0), group=self.process_group)
+        eng.comm_init(box[0], rank, world)
 
     @property
     def engine(self):
@@ -215,7 +233,9 @@ class ActiveCalculator(Calculator):
             # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
             return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf), ready=False)
         out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=False, beta=True)
-        if world > 1:
+        if world > 1 and getattr(engine, "comm_world", 1) == world:
+            pass  # the library's own RCCL all-reduce already combined the ranks (totals on every rank)
+        elif world > 1:
             import torch.distributed as dist
             v = self._tensor(pack_partial(out, N))
             dist.all_reduce(v, group=self.process_group)  # active.py:562,601,602,777 in one collective
@@ -229,7 +249,17 @@ class ActiveCalculator(Calculator):
         It stays on the device until somebody looks: N x m doubles per step over PCIe would cost
         more than the step itself."""
         if self._cov is None and self.atoms is not None and self.engine.m > 0:
-            fetch = getattr(self.engine, "last_cov", None)
+            eng = self.engine
+            gen = getattr(eng, "generation", None)
+            if gen is not None and gen != self._cov_gen:
+                # the device moved on to other frames since this one was evaluated (training rows, trial
+                # models, rattled copies): evaluate the current atoms again rather than hand out the
+                # K_nm of whatever frame came last
+                numbers, positions, cell, pbc = self._system(self.atoms)
+                rank, world = self._dist()
+                eng.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=False, beta=False)
+                self._cov_gen = eng.generation
+            fetch = getattr(eng, "last_cov", None)
             self._cov = fetch(len(self.atoms)) if fetch else None
         return self._cov
 
@@ -244,6 +274,7 @@ class ActiveCalculator(Calculator):
         pre-update predictions, which update_data then offers as 'fake' labels."""
         out = self._evaluate_engine(self.engine)
         self._cov = None  # fetched lazily
+        self._cov_gen = getattr(self.engine, "generation", None)  # the frame `cov` would be fetched from
         self._nl = None
         self._beta = out["beta"]
         if covloss_only:

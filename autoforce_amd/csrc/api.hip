@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <numeric>
 
+#include <rccl/rccl.h>
+
 #include "../../include/sgpr_hip.h"
 #include "sgpr_internal.h"
 
@@ -63,6 +65,10 @@ struct sgpr_model {
     std::vector<int> species;
     std::vector<double> radii;
     hipStream_t stream = nullptr, side = nullptr;
+    // multi-GPU: one process per GPU, the packed partial sums of a step are combined by ONE RCCL
+    // all-reduce enqueued on the step's stream (sgpr_comm_init)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // packed layout
     int D, Dc, Dpad, CS;
@@ -159,7 +165,7 @@ __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, d
 // block reduces a slice, release fence, ticket, last arriver combines — spent most of its 8 us in that
 // dependent chain.)
 struct FinArgs {
-    int N, cnt, first, stride, maxnn, t_stride, has_beta, nE, nV;
+    int N, cnt, first, stride, maxnn, t_stride, has_beta, nE, nV, bin_cap, t_check;
     const int *perm, *slot, *nn, *nbr_j, *aux, *nn_raw;
     const unsigned short *T;
     const double *G;            // gather form: [N][maxnn][4]
@@ -192,8 +198,14 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
     if (lane == 0) wsum[wave] = s;
     __syncthreads();
     if (tid == 0) {
-        if (q == 10) f.stat[0] = max(f.stat[0], (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3])));  // sticky
-        else f.packed[4 * (size_t)f.N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
+        if (q == 10) {
+            const int mx = (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3]));
+            f.stat[0] = max(f.stat[0], mx);  // sticky
+            // packed[4N+10]: 1 when this rank's step overflowed a capacity (its results are invalid); summed
+            // over ranks by the all-reduce, so every rank learns that the step must be repeated
+            const bool ov = mx > f.maxnn || f.stat[1] > f.bin_cap || (f.t_check && f.stat[2] > f.t_stride) || f.stat[3] != 0;
+            f.packed[4 * (size_t)f.N + 10] = ov ? 1.0 : 0.0;
+        } else f.packed[4 * (size_t)f.N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
     }
 }
 
@@ -422,6 +434,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     h->d_b_rec.release();
     h->d_b_aux.release();
     h->d_grid.release();
+    if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -716,7 +729,7 @@ static int alloc_work(sgpr_model *h)
     bad |= h->d_F.alloc((size_t)6 * h->N);
     h->virpart_len = (h->cnt + 3) / 4;  // one partial per desc_bwd workgroup
     bad |= h->d_virpart.alloc((size_t)std::max(h->virpart_len, 1) * 9);
-    bad |= h->d_packed.alloc((size_t)4 * h->N + 10);
+    bad |= h->d_packed.alloc((size_t)4 * h->N + 11);
     if (h->m > 0) {
         bad |= h->d_K.alloc((size_t)cr * h->m_pad);   // zero-filled: off-species entries are never written
         bad |= h->d_Aw.alloc((size_t)cr * h->m_pad);
@@ -835,7 +848,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     return alloc_work(h);
 }
 
-extern "C" int64_t sgpr_packed_len(int N) { return 4 * (int64_t)N + 10; }
+extern "C" int64_t sgpr_packed_len(int N) { return 4 * (int64_t)N + 11; }
 
 // ---------------------------------------------------------------------------- one step
 static void stamp(sgpr_model *h, const char *name, hipStream_t st)
@@ -861,7 +874,8 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
     const int N = h->N;
     FinArgs f = {};
     f.N = N; f.cnt = h->cnt; f.first = h->rank; f.stride = h->world; f.maxnn = h->maxnn; f.t_stride = h->t_stride;
-    f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV;
+    f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV; f.bin_cap = h->bin_cap;
+    f.t_check = (h->world == 1 && h->gather_ok) ? 1 : 0;
     f.perm = h->d_perm.p; f.slot = h->d_slot.p; f.nn = h->d_nn.p; f.nbr_j = h->d_nbr_j.p; f.aux = h->d_aux.p;
     f.nn_raw = h->d_nn_raw.p; f.T = h->d_T.p; f.G = h->d_G.p; f.Fnbr = h->d_F.p; f.Fself = h->d_F.p + 3 * (size_t)N;
     f.csq = h->d_csq.p; f.vs_sqrt = h->d_vs_sqrt.p; f.Epart = h->d_Epart.p; f.virpart = h->d_virpart.p;
@@ -1024,6 +1038,71 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
     return fail(SGPR_E_OVERFLOW, "neighbour capacity kept overflowing");
 }
 
+// combine the ranks' partial sums: ONE all-reduce of the packed buffer on the step's stream
+// (replaces the reference's four MPI collectives, calculator/active.py:562,601,602,777)
+static int reduce_packed(sgpr_model *h, double *packed_dev, hipStream_t st)
+{
+    if (!h->comm) return SGPR_OK;  // no communicator attached: the caller combines the partial sums
+    if (h->comm_world != h->world || h->comm_rank != h->rank)
+        return fail(SGPR_E_INVALID, "the bound sharding (rank %d of %d) differs from the communicator's (rank %d of %d)",
+                    h->rank, h->world, h->comm_rank, h->comm_world);
+    const ncclResult_t r = ncclAllReduce(packed_dev, packed_dev, (size_t)sgpr_packed_len(h->N), ncclDouble, ncclSum, h->comm, st);
+    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(SGPR_E_INVALID, "sgpr_comm_unique_id: bad arguments");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    static_assert(sizeof(id) == SGPR_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_comm_init(sgpr_model *h, const void *id_in, int rank, int world)
+{
+    if (!h || !id_in || world < 1 || rank < 0 || rank >= world) return fail(SGPR_E_INVALID, "sgpr_comm_init: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return fail(SGPR_E_NODEVICE, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
+    h->comm_rank = rank; h->comm_world = world;
+    drop_graph(h);
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_comm_destroy(sgpr_model *h)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_comm_destroy: bad arguments");
+    if (h->comm) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        (void)ncclCommDestroy(h->comm);
+        h->comm = nullptr;
+        drop_graph(h);
+    }
+    h->comm_rank = 0; h->comm_world = 1;
+    return SGPR_OK;
+}
+
+// device buffer of `count` doubles, all-reduced (SUM or MAX) in place over the communicator: what a host
+// needs besides the step (barriers, the max-over-ranks of a timing) without a second communication library
+extern "C" int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_max, void *stream)
+{
+    if (!h || !buf_dev || count < 0) return fail(SGPR_E_INVALID, "sgpr_comm_allreduce: bad arguments");
+    if (!h->comm) return fail(SGPR_E_INVALID, "sgpr_comm_allreduce: no communicator (sgpr_comm_init)");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    const ncclResult_t r = ncclAllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, op_max ? ncclMax : ncclSum, h->comm, st);
+    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    return SGPR_OK;
+}
+
 extern "C" int sgpr_stress_from_virial(const double *v, const double *cell, double *stress6)
 {
     if (!v || !cell || !stress6) return fail(SGPR_E_INVALID, "sgpr_stress_from_virial: bad arguments");
@@ -1061,20 +1140,28 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
     const int rc_ = run_checked(h, h->d_pos_in.p, h->d_cell_in.p, h->d_packed.p, h->stream);
     if (rc_) return rc_;
     h->warm = true;
-    std::vector<double> out((size_t)4 * N + 10);
+    {   // (after the capacity-checked local pass: every rank issues exactly one collective per call)
+        const int rr = reduce_packed(h, h->d_packed.p, h->stream);
+        if (rr) return rr;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    std::vector<double> out((size_t)4 * N + 11);
     HIPCHK(hipMemcpy(out.data(), h->d_packed.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
     if (forces) memcpy(forces, out.data(), sizeof(double) * 3 * N);
     if (beta) memcpy(beta, out.data() + 3 * (size_t)N, sizeof(double) * N);
     if (energy) *energy = out[4 * (size_t)N];
     if (stress) sgpr_stress_from_virial(out.data() + 4 * (size_t)N + 1, cell, stress);
-    if (cov && h->m > 0) return sgpr_get_cov(h, cov);
+    if (cov && h->m > 0) return sgpr_get_cov(h, N, h->m, cov);
     return SGPR_OK;
 }
 
-extern "C" int sgpr_get_cov(sgpr_model *h, double *cov)
+extern "C" int sgpr_get_cov(sgpr_model *h, int N_expected, int m_expected, double *cov)
 {
     if (!h || !cov) return fail(SGPR_E_INVALID, "sgpr_get_cov: bad arguments");
     if (h->N <= 0 || h->m <= 0) return fail(SGPR_E_NOMODEL, "sgpr_get_cov: no evaluated frame / inducing set");
+    if (N_expected != h->N || m_expected != h->m)
+        return fail(SGPR_E_INVALID, "sgpr_get_cov: the caller expects a %d x %d matrix, the last evaluated frame has %d x %d",
+                    N_expected, m_expected, h->N, h->m);
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N = h->N;
@@ -1100,14 +1187,18 @@ extern "C" int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const d
         const int rc_ = run_checked(h, positions_dev, cell_dev, packed_dev, st);
         if (rc_) return rc_;
         h->warm = true;
-        return SGPR_OK;
+        return reduce_packed(h, packed_dev, st);
     }
-    if (!h->use_graph || h->profile) return enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+    if (!h->use_graph || h->profile) {
+        const int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+        return rc_ ? rc_ : reduce_packed(h, packed_dev, st);
+    }
     if (!h->gexec || h->g_pos != positions_dev || h->g_cell != cell_dev || h->g_out != packed_dev || h->g_stream != st) {
         drop_graph(h);
         hipGraph_t graph = nullptr;
         HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        const int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+        int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+        if (!rc_) rc_ = reduce_packed(h, packed_dev, st);
         const hipError_t e = hipStreamEndCapture(st, &graph);
         if (rc_) { if (graph) (void)hipGraphDestroy(graph); return rc_; }
         if (e != hipSuccess) return fail(SGPR_E_NODEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));

@@ -14,5 +14,5 @@ for f in api descriptor neighbor gemm linalg; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/api.o build/descriptor.o build/neighbor.o build/gemm.o build/linalg.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/api.o build/descriptor.o build/neighbor.o build/gemm.o build/linalg.o -L/opt/rocm/lib -lrccl
 echo "built $(realpath $OUT)"

@@ -54,6 +54,9 @@ class SGPRModel:
         self.sigma = None
         self.mean = {z: 0.0 for z in self.species}  # AutoMean weights (gppotential.py:200-231)
         self._vscale = {}
+        self.generation = 0   # counts the frames the device evaluated (predict, training rows): whoever caches
+                              # something about "the last frame" (calc.cov) can tell when it moved on
+        self.comm_world = 1   # > 1 once an RCCL communicator is attached (comm_init)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -71,6 +74,26 @@ class SGPRModel:
     def handle(self):
         return self._h
 
+    # ------------------------------------------------------------------ multi-GPU (one process per GPU)
+    @staticmethod
+    def comm_unique_id():
+        """ncclUniqueId bytes (rank 0 creates them; the host passes them to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        check(_lib.load().sgpr_comm_unique_id(C.addressof(buf)))
+        return buf.raw
+
+    def comm_init(self, uid, rank, world):
+        """Attach an RCCL communicator (collective over all ranks): from now on a sharded predict() /
+        sgpr_step_dev ends with ONE all-reduce of the packed buffer on the step's stream and returns
+        totals (the reference's four MPI collectives, calculator/active.py:562,601,602,777)."""
+        buf = C.create_string_buffer(bytes(uid), 128)
+        check(_lib.load().sgpr_comm_init(self._h, C.addressof(buf), int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def comm_destroy(self):
+        check(_lib.load().sgpr_comm_destroy(self._h))
+        self.comm_world = 1
+
     def scratch(self):
         """A second, empty model with the same kernel on the same device (used for one-off
         K(atoms, atoms) evaluations that must not disturb this model's inducing set)."""
@@ -81,13 +104,14 @@ class SGPRModel:
     def set_inducing(self, X):
         """model.X = inducing LCEs; builds descriptors and K_mm on the device
         (gppotential.py:484-509 set_data: self.M = kern(X, X))."""
-        self.X = list(X)
-        m = len(self.X)
-        zc = i32([x.number for x in self.X])
-        nptr = i64(np.concatenate([[0], np.cumsum([len(x._b) for x in self.X])]))
-        nz = i32(np.concatenate([x._b for x in self.X] + [np.zeros(0, np.int32)]))
-        nr = f64(np.concatenate([x._r for x in self.X] + [np.zeros((0, 3))]))
+        X = list(X)
+        m = len(X)
+        zc = i32([x.number for x in X])
+        nptr = i64(np.concatenate([[0], np.cumsum([len(x._b) for x in X])]))
+        nz = i32(np.concatenate([x._b for x in X] + [np.zeros(0, np.int32)]))
+        nr = f64(np.concatenate([x._r for x in X] + [np.zeros((0, 3))]))
         check(_lib.load().sgpr_set_inducing(self._h, m, ptr(zc), ptr(nptr), ptr(nz), ptr(nr)))
+        self.X = X  # (after the device accepted it: on an error host and device lists still agree)
         self.mu = None
         self.choli = None
 
@@ -196,6 +220,7 @@ class SGPRModel:
         cell = f64(np.asarray(cell, float).reshape(3, 3))
         pbc = i32(np.asarray(pbc, bool).astype(np.int32))
         Ke, Kf, Kv = np.zeros(self.m), np.zeros((3 * N, self.m)), np.zeros((6, self.m))
+        self.generation += 1
         check(_lib.load().sgpr_kernel_rows(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), ptr(Ke),
                                            ptr(Kf), ptr(Kv)))
         return Ke, Kf, Kv
@@ -209,6 +234,7 @@ class SGPRModel:
         cell = f64(np.asarray(cell, float).reshape(3, 3))
         pbc = i32(np.asarray(pbc, bool).astype(np.int32))
         Ke, Kf, Kv = np.zeros(q_count), np.zeros((3 * N, q_count)), np.zeros((6, q_count))
+        self.generation += 1
         check(_lib.load().sgpr_kernel_columns(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc),
                                               int(q_first), int(q_count), ptr(Ke), ptr(Kf), ptr(Kv)))
         return Ke, Kf, Kv
@@ -251,6 +277,7 @@ class SGPRModel:
         stress = np.zeros(6)
         b = np.zeros(N) if beta else None
         K = np.zeros((N, self.m)) if cov else None
+        self.generation += 1
         check(_lib.load().sgpr_compute(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), rank, world,
                                        C.addressof(E), ptr(F), ptr(stress), ptr(b), ptr(K)))
         return dict(energy=E.value, forces=F, stress=stress, beta=b, cov=K)
@@ -273,7 +300,7 @@ class SGPRModel:
         """K_nm [N, m] of the last evaluated frame, downloaded on demand."""
         out = np.zeros((N, self.m))
         if self.m:
-            check(_lib.load().sgpr_get_cov(self._h, ptr(out)))
+            check(_lib.load().sgpr_get_cov(self._h, int(N), int(self.m), ptr(out)))
         return out
 
     def local(self, atom):

@@ -10,11 +10,18 @@ with positions already resident in HBM.  Workload at N=1: BASELINE configs[2] â€
 "LiPS" (3 species), 512 inducing points, lmax=nmax=3, eta=4, rc=6 A, fp64.
 N > 1: atoms are dealt to ranks (per-species round robin, the reference's Distributer); every
 rank evaluates its share and ONE RCCL all-reduce of the packed [F | beta | E | virial] buffer
-combines them (the reference's four MPI all-reduces, calculator/active.py:562,601,602,777).
-The frame is the same for every N, so scaling is "strong".
+combines them (the reference's four MPI all-reduces, calculator/active.py:562,601,602,777).  The
+all-reduce is issued by libsgpr_hip itself on the step's stream (sgpr_comm_init): no PyTorch op on
+the step.  torch.distributed (gloo, CPU) only carries the 128-byte communicator id at start-up and
+the barrier / max-over-ranks around the timed region.  The frame is the same for every N, so scaling
+is "strong".
 
-torch is used for device memory, streams and torch.distributed only; the numerics are
-libsgpr_hip.so (hand-written HIP) called through its C ABI.
+torch is used for device memory and that bootstrap only; the numerics are libsgpr_hip.so
+(hand-written HIP) called through its C ABI.
+
+Reported besides `value` (device-resident pipeline, K steps enqueued back to back):
+`calculate_wall`: median wall time of one ActiveCalculator.calculate() on the same frame â€” numpy
+positions in, numpy results out, synchronised every call â€” SURVEY.md section 8(d)'s definition.
 """
 import argparse
 import ctypes as C
@@ -48,18 +55,24 @@ def build_model(device, numbers, pos, cell, pbc, m, workload_seed=1):
     return mdl
 
 
-def algorithmic_bytes(N, nn, D, m):
-    """Per-kernel algorithmic HBM bytes of one step: the SURVEY.md Â§8d step formula
-    N nn 44 x2 + N nn 24 + 4 (8 N D) + 8 m D + 2 (8 N m) + 24 N, split by the kernel that moves each term
-    (+ the list the build kernel writes and the triangular factor the covloss product reads)."""
+def survey_step_bytes(N, nn, D, m):
+    """SURVEY.md section 8(d), literally: neighbour gather forward + backward (44 B per pair each), force
+    scatter (24 B per pair), p^ write + read and W write + read (4 x 8ND), P^m read, K_nm write + read,
+    force write."""
+    return N * nn * 44 * 2 + N * nn * 24 + 4 * (8 * N * D) + 8 * m * D + 2 * (8 * N * m) + 24 * N
+
+
+def algorithmic_bytes(N, nn, D, m, cs):
+    """The same terms split by the kernel of THIS formulation that moves them (D = packed row length,
+    cs = doubles of c per atom), plus what the formulation adds: the 40-B bin record per atom, the list
+    (8 B), pair record (32 B) and pair gradient (32 B) per pair, c per atom."""
     return {
-        "neighbor_bin": N * (24 + 24 + 16),
-        "neighbor_build": N * nn * 8 + N * 24,
-        "descriptor_fwd": N * nn * 44 + 8 * N * D,
+        "neighbor_bin": N * (24 + 24 + 40),
+        "list_forward": N * nn * 44 + 8 * N * D + N * nn * (8 + 32) + 8 * N * cs,
         "gemm_knm": 8 * N * D + 8 * m * D + 8 * N * m,
         "gemm_w_covloss": 8 * N * m + 8 * m * D + 8 * N * D + 8 * N * m + 8 * m * m,
-        "descriptor_dc": 8 * N * D,
-        "descriptor_pair": N * nn * 44 + N * nn * 24 + 24 * N,
+        "descriptor_rev": 2 * 8 * N * D + 8 * N * cs + N * nn * 32 + N * nn * 32 + 24 * N,
+        "finalize": N * nn * 32 + 24 * N + 32 * N,
     }
 
 
@@ -88,13 +101,14 @@ def cpu_baseline(numbers, pos, cell, pbc, mdl, mu, sample_atoms, min_seconds=12.
     ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
     Pm, nnm = orc.inducing_descriptors(3, 3, 6.0, species, ind_z, ind_ptr, np.concatenate([x._b for x in X]),
                                        np.concatenate([x._r for x in X]))
-    ptr, j, off = mdl.neighbors(len(numbers))  # device neighbour list of the benchmark frame
-    # restrict to the first `sample_atoms` atoms' environments
-    ptr_s = ptr.copy()
-    ptr_s[sample_atoms + 1:] = ptr_s[sample_atoms]
     reps, dt = 0, 0.0
     t0 = time.perf_counter()
     while dt < min_seconds:
+        # the whole path on the CPU: linked-cell neighbour list of the frame, then descriptors + K_nm +
+        # reverse pass + covloss of the first `sample_atoms` atoms' environments
+        ptr, j, off = orc.neighbors_cells(pos, cell, pbc, 6.0)
+        ptr_s = ptr.copy()
+        ptr_s[sample_atoms + 1:] = ptr_s[sample_atoms]
         orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, (ptr_s, j, off), ind_z, nnm, Pm, mu, choli=mdl.choli,
                   want_p=False)
         reps += 1
@@ -112,7 +126,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
     ap.add_argument("--overlap", type=int, default=0, help="1: covloss GEMM on a side stream next to the reverse pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for single-GPU dry runs)")
+    ap.add_argument("--collective", default="native", choices=["native", "torch"],
+                    help="native: the library's own RCCL all-reduce on the step's stream (default); torch: "
+                         "torch.distributed all_reduce of the packed buffer (dry runs of several ranks on one GPU)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -133,10 +149,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # CPU-side group: carries the communicator id at start-up and the barriers / max around the timed
+        # region; the step's collective is the library's own (RCCL over xGMI)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     numbers, pos, cell, pbc = lips(args.atoms_side, seed=0)
     N, m = len(numbers), args.inducing
@@ -154,11 +169,19 @@ def main():
                                     rank, world))
     stream = torch.cuda.current_stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
+    native = world > 1 and args.collective == "native"
+    if native:
+        box = [mdl.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        mdl.comm_init(box[0], rank, world)  # collective: ncclCommInitRank on every rank
 
     def step():
+        # with a communicator attached the step ends with the all-reduce of `packed`, same stream
         _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
-        if world > 1:
-            dist.all_reduce(packed)
+        if world > 1 and not native:
+            t = packed.cpu()
+            dist.all_reduce(t)
+            packed.copy_(t)
 
     for _ in range(max(args.warmup, 2)):
         step()
@@ -178,7 +201,7 @@ def main():
     dt = time.perf_counter() - t0
     _lib.check(lib.sgpr_sync_check(h, sp))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
@@ -210,6 +233,7 @@ def main():
     dims = mdl.dims
     # PCIe-inclusive rate of the host-array entry point (never `value`): numpy in, numpy out
     host_rate = None
+    calc_wall = None
     if world == 1:
         mdl.predict(numbers, pos, cell, pbc, beta=True)
         th = time.perf_counter()
@@ -217,6 +241,24 @@ def main():
         for _ in range(nh):
             mdl.predict(numbers, pos, cell, pbc, beta=True)
         host_rate = N * nh / (time.perf_counter() - th)
+        # wall time of one calculate() (NL + descriptors + K_nm + E/F/stress + covloss) through
+        # the drop-in surface, median of >= 50 calls after 5 warm-ups; the atoms move a little every call,
+        # as in MD, so nothing is served from ASE's result cache
+        from autoforce_amd.ase_shim import Atoms
+        from autoforce_amd.calculator import ActiveCalculator
+        calc = ActiveCalculator(covariance=mdl, logfile=None)
+        atoms = Atoms(numbers, pos.copy(), cell, pbc)
+        atoms.calc = calc
+        rng = np.random.default_rng(5)
+        walls = []
+        for it in range(55):
+            atoms.positions = atoms.positions + 1e-3 * rng.normal(size=pos.shape)
+            tc = time.perf_counter()
+            atoms.get_forces()
+            walls.append(time.perf_counter() - tc)
+        w = float(np.median(walls[5:]))
+        calc_wall = {"median_ms": w * 1e3, "atom_steps_per_s": N / w, "calls": len(walls) - 5,
+                     "what": "ActiveCalculator.calculate() wall, numpy in / numpy out, one synchronised call per step"}
 
     result = None
     if rank == 0:
@@ -225,15 +267,19 @@ def main():
         nn_mean = float(ptr[-1]) / max(cnt, 1)
         Dc = dims["Dc"]
         # algorithmic bytes of THIS formulation: packed rows (Dc) and only this rank's atoms
-        ab = algorithmic_bytes(cnt, nn_mean, Dc, m)
-        ab_survey = algorithmic_bytes(cnt, nn_mean, dims["D"] * dims["S"] ** 2, m)
+        cs = dims["S"] * 64
+        ab = algorithmic_bytes(cnt, nn_mean, Dc, m, cs)
         dom = max((k for k in stage_ms if k in ab), key=lambda k: stage_ms[k])
         dom_s = stage_ms[dom] * 1e-3
-        # dense flops actually required by the block-diagonal packed formulation
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_lips{N}_m{m}.json")
-        if world == 1 and os.path.exists(tpath):  # PMC counters come from separate rocprofv3 --pmc passes
-            traffic = json.load(open(tpath))["kernels"].get(dom, {}).get("fetch_x2_plus_write")
+        # HBM traffic of the dominant kernel: PMC counters cannot be read inside this run (rocprofv3 --pmc
+        # is a separate pass); the committed summary of the builder's own pass over this command is quoted
+        # with its source, or null
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_lips{N}_m{m}.json")
+        if world == 1 and os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj["kernels"].get(dom, {}).get("fetch_x2_plus_write")
+            traffic_source = f"profiles/{os.path.basename(tpath)} ({tj.get('source', 'builder run')})"
         af = algorithmic_flops(numbers, [x.number for x in mdl.X], dims["Dpad"], world)
         if dom in af:  # a GEMM leads: price it against the dense fp64 MFMA peak
             head = {"bound": "mfma", "achieved": af[dom] / dom_s / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -245,6 +291,7 @@ def main():
             "kernel": dom,
             **head,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes": ab[dom],
             "avg_launch_us": stage_ms[dom] * 1e3,
             "timing": f"hip events on the launch stream, {nprof} eager steps after the timed region, minus the "
@@ -252,8 +299,9 @@ def main():
             "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
             "gemm_TFLOPs": {k: round(af[k] / (stage_ms[k] * 1e-3) / 1e12, 2) for k in af if stage_ms.get(k)},
             "hbm_GBs": {k: round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) for k in ab if stage_ms.get(k)},
-            "step_bytes_packed_layout": sum(ab.values()),
-            "step_bytes_survey_formula": sum(ab_survey.values()),
+            "step_bytes_this_formulation": sum(ab.values()),
+            "step_bytes_survey_formula": survey_step_bytes(cnt, nn_mean, dims["D"] * dims["S"] ** 2, m),
+            "step_GBs_survey_formula": survey_step_bytes(cnt, nn_mean, dims["D"] * dims["S"] ** 2, m) / (ms_per_step * 1e-3) / 1e9,
             "pass_GBs_packed": sum(ab.values()) / (sum(stage_ms[k] for k in ab if k in stage_ms) * 1e-3) / 1e9,
         }
         result = {
@@ -274,9 +322,11 @@ def main():
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
                 "packed_row": Dc, "graph": bool(args.graph),
                 "host_array_path_atom_steps_per_s": host_rate,
-                "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step",
+                "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step "
+                               f"({'issued by libsgpr_hip on the step stream' if native else 'torch.distributed, host staged' if world > 1 else 'single rank: none'})",
             },
             "roofline": roof,
+            "calculate_wall": calc_wall,
             "energy": float(out_host[4 * N]),
             "max_force": float(np.abs(out_host[:3 * N]).max()),
         }
@@ -285,8 +335,8 @@ def main():
             v, cdt, reps, cores = cpu_baseline(numbers, pos, cell, pbc, mdl, mdl.mu, sample)
             result["cpu_baseline"] = {
                 "value": v, "unit": "atom*steps/s", "cores": cores, "kind": "port",
-                "sample": f"{reps} passes over {sample} of {N} atoms of the same frame (descriptors + K_nm + reverse "
-                          f"pass + covloss; neighbour list taken from the device), {cdt:.1f} s, "
+                "sample": f"{reps} passes over {sample} of {N} atoms of the same frame (linked-cell neighbour list + "
+                          f"descriptors + K_nm + reverse pass + covloss), {cdt:.1f} s, "
                           f"oracle/sgpr_oracle.c with OpenMP on {cores} threads",
             }
         print(json.dumps(result))

@@ -179,8 +179,12 @@ int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *pos
  *   packed[3N..4N)     beta   (this rank's share, 0 elsewhere)
  *   packed[4N]         energy (partial; mean term added on rank 0 only)
  *   packed[4N+1..+9)   virial sum_pairs r (x) dE/dr (partial), row-major 3x3
+ *   packed[4N+10]      1 if this rank's step overflowed a capacity (results invalid), else 0
  * i.e. exactly what one all-reduce(SUM) over ranks must combine (the reference's four
- * collectives calculator/active.py:562,601,602,777 fused into one buffer).
+ * collectives calculator/active.py:562,601,602,777 fused into one buffer).  With a communicator
+ * attached (sgpr_comm_init) the step ends with that all-reduce, enqueued on the same stream: the
+ * buffer then holds the TOTALS on every rank, and packed[4N+10] > 0 tells every rank alike that some
+ * rank must repeat the step (sgpr_sync_check on each rank, then the step again).
  * `stream` is a hipStream_t passed as void*.  With option "graph" the step is captured into a HIP graph on first
  * use and replayed afterwards.
  */
@@ -189,6 +193,22 @@ int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, const int32_t
 int64_t sgpr_packed_len(int N);
 int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell_dev,
                   double *packed_dev, void *stream);
+/*
+ * Multi-GPU (one process per GPU, atoms sharded as in sgpr_bind_system): the reference combines the
+ * ranks' partial sums with four MPI all-reduces per step (calculator/active.py:562,601,602,777,
+ * util/parallel.py); here ONE RCCL all-reduce of the packed buffer over xGMI, issued by the library
+ * on the step's stream.  Rank 0 creates the id (SGPR_COMM_ID_BYTES bytes), the host passes it to the
+ * other ranks by any means (MPI, a TCP store, a file), and every rank calls sgpr_comm_init
+ * (collective).  Without a communicator the caller combines the partial sums itself.
+ * sgpr_comm_allreduce: in-place SUM (op_max = 0) or MAX (1) of a device buffer of doubles over the
+ * same communicator (barriers, max-over-ranks timings).
+ */
+#define SGPR_COMM_ID_BYTES 128
+int sgpr_comm_unique_id(void *id_out);
+int sgpr_comm_init(sgpr_model *h, const void *id, int rank, int world);
+int sgpr_comm_destroy(sgpr_model *h);
+int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_max, void *stream);
+
 /* Synchronise `stream` (NULL = the handle's own) and verify that no step since the last
  * check overflowed the neighbour-list capacity.  Returns SGPR_E_OVERFLOW if one did (those
  * steps' results are invalid; capacity has been grown, the next step re-sizes eagerly). */
@@ -213,8 +233,10 @@ int sgpr_get_neighbors(sgpr_model *h, int64_t *ptr, int32_t *j, int32_t *off);
 int sgpr_get_local(sgpr_model *h, int atom, int32_t *nn, int32_t *nbr_z, double *nbr_r, int capacity);
 
 /* K_nm [N][m] of the last evaluated frame (caller order; rows of other ranks' atoms are zero): the
- * `cov` output of sgpr_compute, fetched only when somebody looks at it (calc.cov, active.py:464). */
-int sgpr_get_cov(sgpr_model *h, double *cov);
+ * `cov` output of sgpr_compute, fetched only when somebody looks at it (calc.cov, active.py:464).
+ * N and m are the dimensions the caller's buffer was sized for: SGPR_E_INVALID if the last frame the
+ * device evaluated (training rows and trial models rebind it) has other dimensions. */
+int sgpr_get_cov(sgpr_model *h, int N, int m, double *cov);
 
 /* Model dimensions, out[8]: out[0]=m, out[1]=S, out[2]=D (dense per block), out[3]=Dc (packed
  * row length used on the device), out[4]=neighbour capacity per atom, out[5]=N bound,

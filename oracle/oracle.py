@@ -31,6 +31,7 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.orc_neighbors.restype = C.c_int64
+        _LIB.orc_neighbors_cells.restype = C.c_int64
     return _LIB
 
 
@@ -75,6 +76,21 @@ def neighbors(pos, cell, pbc, rc):
     j = np.zeros(tot, np.int32)
     off = np.zeros((tot, 3), np.int32)
     lib().orc_neighbors(C.c_int(N), _opt(pos), _opt(cell), _opt(pbc), C.c_double(rc), _opt(ptr), _opt(j), _opt(off))
+    return ptr, j, off
+
+
+def neighbors_cells(pos, cell, pbc, rc):
+    """The same list by the linked-cell method (orc_neighbors_cells): for the 4096- and 16384-atom frames."""
+    pos = np.ascontiguousarray(pos, np.float64)
+    cell = np.ascontiguousarray(cell, np.float64).reshape(3, 3)
+    pbc = np.ascontiguousarray(np.asarray(pbc, bool).astype(np.int32))
+    N = len(pos)
+    ptr = np.zeros(N + 1, np.int64)
+    fn = lib().orc_neighbors_cells
+    tot = fn(C.c_int(N), _opt(pos), _opt(cell), _opt(pbc), C.c_double(rc), _opt(ptr), None, None)
+    j = np.zeros(tot, np.int32)
+    off = np.zeros((tot, 3), np.int32)
+    fn(C.c_int(N), _opt(pos), _opt(cell), _opt(pbc), C.c_double(rc), _opt(ptr), _opt(j), _opt(off))
     return ptr, j, off
 
 

@@ -382,6 +382,129 @@ int64_t orc_neighbors(int N, const double *pos, const double *cell, const int *p
 }
 
 /* --------------------------------------------------------------------------------------
+ * The same list by the linked-cell method, for frames where the brute-force double loop above is too
+ * slow (4096 and 16384 atoms): positions are wrapped into the cell along the periodic directions,
+ * sorted into cells at least rc wide (perpendicular heights), and every atom visits the cells within
+ * range of its own, each under the periodic image it is reached by.  Same pair rule, same output
+ * order (j ascending, then off lexicographic, off relative to the UNWRAPPED positions as ASE reports
+ * them).  tests/test_oracle_golden.py holds it equal to orc_neighbors on every golden frame and on
+ * random cells; OpenMP over atoms.
+ * ------------------------------------------------------------------------------------ */
+typedef struct { int32_t j, o0, o1, o2; } nbr_t;
+
+static int nbr_cmp(const void *pa, const void *pb)
+{
+    const nbr_t *a = (const nbr_t *)pa, *b = (const nbr_t *)pb;
+    if (a->j != b->j) return a->j < b->j ? -1 : 1;
+    if (a->o0 != b->o0) return a->o0 < b->o0 ? -1 : 1;
+    if (a->o1 != b->o1) return a->o1 < b->o1 ? -1 : 1;
+    if (a->o2 != b->o2) return a->o2 < b->o2 ? -1 : 1;
+    return 0;
+}
+
+static int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+int64_t orc_neighbors_cells(int N, const double *pos, const double *cell, const int *pbc, double rc,
+                            int64_t *ptr, int32_t *j_out, int32_t *off_out)
+{
+    if (N <= 0) { ptr[0] = 0; return 0; }
+    const double V = fabs(det3(cell));
+    double inv[9] = {0};
+    double hgt[3] = {0, 0, 0};
+    const int usable = V > 1e-12;
+    if (usable) {
+        const double *a = cell, *b = cell + 3, *c = cell + 6;
+        double bc[3], ca[3], ab[3];
+        cross3(b, c, bc); cross3(c, a, ca); cross3(a, b, ab);
+        const double dt = det3(cell);
+        for (int k = 0; k < 3; k++) { inv[3 * k + 0] = bc[k] / dt; inv[3 * k + 1] = ca[k] / dt; inv[3 * k + 2] = ab[k] / dt; }
+        hgt[0] = V / sqrt(bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2]);
+        hgt[1] = V / sqrt(ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2]);
+        hgt[2] = V / sqrt(ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2]);
+    }
+    int nc[3] = {1, 1, 1}, rg[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++)
+        if (usable && pbc[k]) {
+            nc[k] = (int)floor(hgt[k] / rc);
+            if (nc[k] < 1) nc[k] = 1;
+            if (nc[k] > 64) nc[k] = 64;
+            rg[k] = (int)ceil(rc * nc[k] / hgt[k]);
+        }
+    const int ncell = nc[0] * nc[1] * nc[2];
+    int *wrap = (int *)calloc((size_t)3 * N, sizeof(int));
+    int *cof = (int *)malloc(sizeof(int) * (size_t)N);
+    int *head = (int *)malloc(sizeof(int) * (size_t)ncell);
+    int *next = (int *)malloc(sizeof(int) * (size_t)N);
+    for (int c = 0; c < ncell; c++) head[c] = -1;
+    for (int i = 0; i < N; i++) {
+        int ci[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++)
+            if (usable && pbc[k]) {
+                double f = pos[3 * i] * inv[k] + pos[3 * i + 1] * inv[3 + k] + pos[3 * i + 2] * inv[6 + k];
+                const double fl = floor(f);
+                wrap[3 * i + k] = (int)fl;
+                f -= fl;
+                int b = (int)(f * nc[k]);
+                if (b >= nc[k]) b = nc[k] - 1;
+                if (b < 0) b = 0;
+                ci[k] = b;
+            }
+        cof[i] = (ci[0] * nc[1] + ci[1]) * nc[2] + ci[2];
+    }
+    for (int i = N - 1; i >= 0; i--) { next[i] = head[cof[i]]; head[cof[i]] = i; }
+    /* pass 1: counts; pass 2: sorted entries */
+    for (int pass = 0; pass < (j_out ? 2 : 1); pass++) {
+#pragma omp parallel
+        {
+            int cap = 256, n = 0;
+            nbr_t *buf = (nbr_t *)malloc(sizeof(nbr_t) * (size_t)cap);
+#pragma omp for schedule(dynamic, 16)
+            for (int i = 0; i < N; i++) {
+                n = 0;
+                const int c2 = cof[i] % nc[2], c1 = (cof[i] / nc[2]) % nc[1], c0 = cof[i] / (nc[1] * nc[2]);
+                for (int o0 = -rg[0]; o0 <= rg[0]; o0++)
+                    for (int o1 = -rg[1]; o1 <= rg[1]; o1++)
+                        for (int o2 = -rg[2]; o2 <= rg[2]; o2++) {
+                            const int t0 = c0 + o0, t1 = c1 + o1, t2 = c2 + o2;
+                            const int m0 = floor_div(t0, nc[0]), m1 = floor_div(t1, nc[1]), m2 = floor_div(t2, nc[2]);
+                            const int cc = ((t0 - m0 * nc[0]) * nc[1] + (t1 - m1 * nc[1])) * nc[2] + (t2 - m2 * nc[2]);
+                            for (int j = head[cc]; j >= 0; j = next[j]) {
+                                const int s0 = m0 - wrap[3 * j] + wrap[3 * i], s1 = m1 - wrap[3 * j + 1] + wrap[3 * i + 1],
+                                          s2 = m2 - wrap[3 * j + 2] + wrap[3 * i + 2];
+                                if (j == i && !s0 && !s1 && !s2) continue;
+                                double d[3];
+                                for (int a = 0; a < 3; a++)
+                                    d[a] = pos[3 * j + a] + (s0 * cell[a] + s1 * cell[3 + a] + s2 * cell[6 + a]) - pos[3 * i + a];
+                                const double rr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                                if (rr < rc) {
+                                    if (n == cap) { cap *= 2; buf = (nbr_t *)realloc(buf, sizeof(nbr_t) * (size_t)cap); }
+                                    buf[n].j = j; buf[n].o0 = s0; buf[n].o1 = s1; buf[n].o2 = s2;
+                                    n++;
+                                }
+                            }
+                        }
+                if (pass == 0) ptr[i + 1] = n;
+                else {
+                    qsort(buf, (size_t)n, sizeof(nbr_t), nbr_cmp);
+                    for (int t = 0; t < n; t++) {
+                        const int64_t e = ptr[i] + t;
+                        j_out[e] = buf[t].j;
+                        off_out[3 * e] = buf[t].o0; off_out[3 * e + 1] = buf[t].o1; off_out[3 * e + 2] = buf[t].o2;
+                    }
+                }
+            }
+            free(buf);
+        }
+        if (pass == 0) {
+            ptr[0] = 0;
+            for (int i = 0; i < N; i++) ptr[i + 1] += ptr[i];
+        }
+    }
+    free(wrap); free(cof); free(head); free(next);
+    return ptr[N];
+}
+
+/* --------------------------------------------------------------------------------------
  * Kernel entry — similarity/universal.py:109-122 + similarity/similarity.py:41-43,94-103:
  *   k(i,q) = [Z_i == Z_q] (p_i . p_q)^eta  (0 if either has no neighbours)
  *          + 1 if both have no neighbours and Z_i == Z_q.

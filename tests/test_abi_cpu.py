@@ -30,7 +30,7 @@ def test_version_and_packed_len():
     from autoforce_amd import _lib
     lib = _lib.load()
     assert lib.sgpr_version() >= 1000
-    assert lib.sgpr_packed_len(4096) == 4 * 4096 + 10
+    assert lib.sgpr_packed_len(4096) == 4 * 4096 + 11
 
 
 def test_stress_from_virial_host_helper():

@@ -9,6 +9,11 @@ import pytest
 
 from helpers import load
 
+
+def pair_set(ptr, j, off):
+    i = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    return set(zip(i.tolist(), np.asarray(j).tolist(), map(tuple, np.asarray(off).tolist())))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -118,7 +123,10 @@ def test_full_size_lips4096_against_oracle():
                                        np.concatenate([x._r for x in X]))
     M = orc.kernel_matrix(ind_z, nnm, Pm, ind_z, nnm, Pm, 4.0)
     np.testing.assert_allclose(mdl.M, M, rtol=1e-10, atol=1e-13)
-    nl = orc.neighbors(pos, cell, pbc, 6.0) if False else mdl.neighbors(len(numbers))  # O(N^2 images) on CPU is slow
+    # the oracle's own (linked-cell) neighbour list, pinned to the brute-force one by the CPU tests; the
+    # device list must hold exactly the same pairs at this size too (7 bins per cell edge here)
+    nl = orc.neighbors_cells(pos, cell, pbc, 6.0)
+    assert pair_set(*mdl.neighbors(len(numbers))) == pair_set(*nl)
     ref = orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mdl.mu, choli=mdl.choli)
     np.testing.assert_allclose(out["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
     assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
@@ -126,6 +134,73 @@ def test_full_size_lips4096_against_oracle():
     assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
     vs = np.sqrt([mdl._vscale[int(z)] for z in numbers])
     np.testing.assert_allclose(out["beta"], ref["beta"] * vs, rtol=0, atol=2e-6 * vs.max())
+    mdl.close()
+
+
+def test_sharded_lips4096_against_oracle():
+    """BASELINE configs[3] sizes on one device: the 4096-atom frame sharded over world = 2, 4, 8 ranks
+    (every rank's share evaluated in turn: list build, descriptors and GEMMs of its atoms only, reverse
+    pass in scatter form), partial sums added as the all-reduce does (calculator/active.py:562,600-602,
+    770-777), against the ORACLE on its own neighbour list — not against the unsharded device result."""
+    from oracle import oracle as orc
+    mdl, numbers, pos, cell, pbc = _lips_model(16, 512)
+    N = len(numbers)
+    X = mdl.X
+    species = np.array(mdl.species, np.int32)
+    ind_z = np.array([x.number for x in X], np.int32)
+    ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
+    Pm, nnm = orc.inducing_descriptors(3, 3, 6.0, species, ind_z, ind_ptr, np.concatenate([x._b for x in X]),
+                                       np.concatenate([x._r for x in X]))
+    nl = orc.neighbors_cells(pos, cell, pbc, 6.0)
+    ref = orc.frame(3, 3, 6.0, 4.0, species, numbers, pos, cell, nl, ind_z, nnm, Pm, mdl.mu, choli=mdl.choli)
+    vs = np.sqrt([mdl._vscale[int(z)] for z in numbers])
+    for world in (2, 4, 8):
+        acc = None
+        for r in range(world):
+            part = mdl.predict(numbers, pos, cell, pbc, rank=r, world=world, cov=True)
+            if r == 0:
+                assert np.count_nonzero(np.abs(part["cov"]).sum(1)) <= N // world + 3  # only this rank's rows
+            acc = {k: np.array(v, dtype=float) for k, v in part.items()} if acc is None else \
+                {k: acc[k] + part[k] for k in acc}
+        np.testing.assert_allclose(acc["cov"], ref["cov"], rtol=1e-9, atol=1e-12)
+        assert abs(acc["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
+        assert np.abs(acc["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
+        assert np.abs(acc["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
+        np.testing.assert_allclose(acc["beta"], ref["beta"] * vs, rtol=0, atol=2e-6 * vs.max())
+    mdl.close()
+
+
+def test_native_communicator_single_rank():
+    """The library's own RCCL path on the one GPU of this box: a communicator of one rank, the step's
+    all-reduce enqueued on the step's stream (sgpr_comm_init / sgpr_step_dev), the free-standing
+    all-reduce, and the overflow word of the packed buffer."""
+    import torch
+    from autoforce_amd import _lib
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    lib = _lib.load()
+    N = len(g["numbers"])
+    ref = mdl.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    mdl.comm_init(mdl.comm_unique_id(), 0, 1)
+    out = mdl.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    for k in ("energy", "forces", "stress", "beta"):
+        np.testing.assert_array_equal(np.asarray(out[k]), np.asarray(ref[k]))
+    dev = torch.device("cuda", 0)
+    buf = torch.arange(5, dtype=torch.float64, device=dev)
+    _lib.check(lib.sgpr_comm_allreduce(mdl.handle, buf.data_ptr(), 5, 0, None))
+    _lib.check(lib.sgpr_comm_allreduce(mdl.handle, buf.data_ptr(), 5, 1, None))
+    _lib.check(lib.sgpr_sync_check(mdl.handle, None))
+    np.testing.assert_array_equal(buf.cpu().numpy(), np.arange(5.0))
+    pos = torch.from_numpy(g["positions"].copy()).to(dev)
+    cell = torch.from_numpy(g["cell"].copy()).to(dev)
+    packed = torch.zeros(int(lib.sgpr_packed_len(N)), dtype=torch.float64, device=dev)
+    for _ in range(2):
+        _lib.check(lib.sgpr_step_dev(mdl.handle, pos.data_ptr(), cell.data_ptr(), packed.data_ptr(), None))
+    _lib.check(lib.sgpr_sync_check(mdl.handle, None))
+    got = packed.cpu().numpy()
+    np.testing.assert_array_equal(got[:3 * N].reshape(N, 3), ref["forces"])
+    assert got[4 * N] == ref["energy"] and got[4 * N + 10] == 0.0
+    mdl.comm_destroy()
     mdl.close()
 
 
@@ -235,7 +310,10 @@ def test_baseline_config5_oxide16384_m1024():
     out = mdl.predict(numbers, pos, cell, pbc, cov=False)
     fmax = np.abs(out["forces"]).max()
     assert np.abs(out["forces"].sum(0)).max() <= 1e-8 * fmax
-    ref = _oracle_frame(mdl, numbers, pos, cell, mdl.neighbors(N))
+    from oracle import oracle as orc
+    nl = orc.neighbors_cells(pos, cell, pbc, 6.0)  # independent of the device list (see the 4096-atom test)
+    assert pair_set(*mdl.neighbors(N)) == pair_set(*nl)
+    ref = _oracle_frame(mdl, numbers, pos, cell, nl)
     assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
     assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
     assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()

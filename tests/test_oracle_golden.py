@@ -139,6 +139,33 @@ def test_neighbors(name):
     np.testing.assert_array_equal(off, g["nl_off"])
 
 
+@pytest.mark.parametrize("name", FRAMES)
+def test_neighbors_linked_cells(name):
+    """The linked-cell builder (used for the 4096- and 16384-atom frames) gives the golden list too."""
+    g = load(name)
+    ptr, j, off = orc.neighbors_cells(g["positions"], g["cell"], g["pbc"], float(g["rc"]))
+    np.testing.assert_array_equal(ptr, g["nl_ptr"])
+    np.testing.assert_array_equal(j, g["nl_j"])
+    np.testing.assert_array_equal(off, g["nl_off"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_neighbors_linked_cells_random(seed):
+    """... and equals the brute-force list on random triclinic cells: every periodicity pattern, cells
+    thinner than the cutoff (self images), atoms outside the cell, >= 3 cells per edge."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(20, 160))
+    L = rng.uniform(2.0, 9.0, 3) if seed % 3 else rng.uniform(6.5, 9.5, 3)
+    cell = np.diag(L) + rng.uniform(-0.25, 0.25, (3, 3)) * L.min()
+    pbc = [bool(seed & 1), bool(seed & 2), bool(seed & 4)] if seed < 8 else [True] * 3
+    pos = rng.uniform(-0.7, 1.7, (n, 3)) @ cell
+    rc = float(rng.uniform(1.5, 3.2))
+    a = orc.neighbors(pos, cell, pbc, rc)
+    b = orc.neighbors_cells(pos, cell, pbc, rc)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
 # ---------------------------------------------------------------- G4/G5/G6: frames
 @pytest.mark.parametrize("name", FRAMES)
 def test_frames(name):
