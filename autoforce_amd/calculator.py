@@ -107,6 +107,7 @@ class ActiveCalculator(Calculator):
         self.maximum_force = inf
         self.logfile, self.stdout, self._logpref = logfile, stdout, ""
         self.step = 0
+        self._wildcard = False
         self.get_model(engine if engine is not None else covariance, kernel_kw or {})
         self.ediff = ediff
         self.ediff_lb = ediff_lb or ediff
@@ -153,7 +154,10 @@ class ActiveCalculator(Calculator):
             else:
                 kw = dict(kernel_kw)
                 if not kw.get("species"):
-                    raise ValueError("kernel_kw={'species': [...]} is required to build an empty model")
+                    # the reference's default kernel is the species-wildcard one (active.py:28-38): the table
+                    # starts with the first frame's species and grows when a new one turns up (_ensure_species)
+                    self._wildcard = True
+                    kw["species"] = [0]  # placeholder, replaced before the first evaluation
                 model = default_kernel(**kw)
         if not isinstance(model, PosteriorPotential):
             model = PosteriorPotential(model)
@@ -287,11 +291,26 @@ class ActiveCalculator(Calculator):
         self.results["stress"] = np.asarray(out["stress"])
         self.maximum_force = float(np.abs(self.results["forces"]).max()) if len(self.atoms) else 0.0
 
+    def _ensure_species(self, numbers):
+        """Wildcard mode (no `species` in kernel_kw): extend the model's table to the species met."""
+        if not self._wildcard:
+            return
+        have = [z for z in self.engine.species if z != 0]
+        new = sorted(set(int(z) for z in numbers) - set(have))
+        if new or 0 in self.engine.species:
+            table = sorted(set(have) | set(new))
+            if len(table) > 8:
+                raise RuntimeError(f"{len(table)} species: the device kernels hold at most 8 species slots")
+            self.model.retable(table)
+            self._attach_native_comm()
+            self.log(f"species table -> {table}")
+
     def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
         timings = [time.time()]
         if self.size[1] == 0 and not self.active:
             raise RuntimeError("you forgot to assign a DFT calculator!")  # active.py:429-430
         Calculator.calculate(self, atoms, properties, system_changes)
+        self._ensure_species(self.atoms.numbers)
         self.maximum_force = inf
         timings.append(time.time())
         if self._needs_seed():

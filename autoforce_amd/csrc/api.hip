@@ -134,6 +134,9 @@ struct sgpr_model {
     hipStream_t g_stream = nullptr;
     bool use_graph = false;  // eager launches pipeline fine while a step is >100 us of kernels; graph replay
                              // measured 8 us/step slower (177 vs 169 us) — opt in with sgpr_set_option("graph",1)
+    bool ignore_unknown = false;  // option "ignore_unknown_species": atoms and LCE neighbours whose species is not in
+                                  // the table are invisible (the reference's fixed-species kernels drop them
+                                  // silently, descriptor/sesoap.py:343-346); default: SGPR_E_SPECIES
     bool use_fork = false;   // measured neutral (169.0 vs 167.6 us): kept as an option only
     // profiling
     bool profile = false;
@@ -334,7 +337,8 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
 {
     if (!out || !species_z || S < 1 || S > SGPR_MAX_S) return fail(SGPR_E_INVALID, "sgpr_create: bad species table (S=%d)", S);
     if (!(rc > 0.0) || !(eta > 0.0)) return fail(SGPR_E_INVALID, "sgpr_create: rc and eta must be positive");
-    const bool ok = (lmax == 3 && nmax == 3) || (lmax == 2 && nmax == 2) || (lmax == 4 && nmax == 4 && S <= 4);
+    const bool in234 = lmax >= 2 && lmax <= 4 && nmax >= 2 && nmax <= 4;
+    const bool ok = (lmax == 3 && nmax == 3) || (lmax == 2 && nmax == 2) || (in234 && S <= 4);
     if (!ok) return fail(SGPR_E_UNSUPPORTED, "sgpr_create: (lmax,nmax,S)=(%d,%d,%d) is not compiled in", lmax, nmax, S);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -357,9 +361,10 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     (void)hipMemcpy(h->d_pack.p, h->h_pack.data(), sizeof(PackEntry) * h->Dc, hipMemcpyHostToDevice);
     h->d_radii.alloc(S, false);
     (void)hipMemcpy(h->d_radii.p, h->radii.data(), sizeof(double) * S, hipMemcpyHostToDevice);
-    h->d_vs_sqrt.alloc(S, false);
-    std::vector<double> one(S, 1.0);
-    (void)hipMemcpy(h->d_vs_sqrt.p, one.data(), sizeof(double) * S, hipMemcpyHostToDevice);
+    h->d_vs_sqrt.alloc(S + 1, false);  // (+ a zero for ghost atoms, slot S)
+    std::vector<double> one(S + 1, 1.0);
+    one[S] = 0.0;
+    (void)hipMemcpy(h->d_vs_sqrt.p, one.data(), sizeof(double) * (S + 1), hipMemcpyHostToDevice);
     HarmCoef hc;
     host_build_harm_coef(&hc);
     upload_harm_coef(hc);
@@ -574,14 +579,16 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
         dslot[k] = slot[q];
         h->qoff[slot[q] + 1]++;
         const int64_t a = nbr_ptr[q], b = nbr_ptr[q + 1];
-        nn[k] = (int)(b - a);
+        const size_t before = eslot.size();
         for (int64_t e = a; e < b; e++) {
             const int s = slot_of(h, nbr_z[e]);
+            if (s < 0 && h->ignore_unknown) continue;  // descriptor/sesoap.py:343-346
             if (s < 0) return fail(SGPR_E_SPECIES, "inducing LCE %d: neighbour Z=%d is not in the species table", q, nbr_z[e]);
             eslot.push_back(s);
             er.push_back(nbr_r[3 * e]); er.push_back(nbr_r[3 * e + 1]); er.push_back(nbr_r[3 * e + 2]);
         }
         ptr[k + 1] = (int64_t)eslot.size();
+        nn[k] = (int)(eslot.size() - before);
     }
     for (int s = 0; s < h->S; s++) h->qoff[s + 1] += h->qoff[s];
     {   // keep the caller's list for the edit entry points (copy first: the inputs may alias h->env_*)
@@ -661,9 +668,9 @@ extern "C" int sgpr_get_inducing_descriptors(sgpr_model *h, double *P)
 
 static void upload_vscale(sgpr_model *h)
 {
-    std::vector<double> s(h->S);
+    std::vector<double> s(h->S + 1, 0.0);
     for (int k = 0; k < h->S; k++) s[k] = sqrt(h->vscale[k]);
-    (void)hipMemcpy(h->d_vs_sqrt.p, s.data(), sizeof(double) * h->S, hipMemcpyHostToDevice);
+    (void)hipMemcpy(h->d_vs_sqrt.p, s.data(), sizeof(double) * (h->S + 1), hipMemcpyHostToDevice);
 }
 
 extern "C" int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, const double *vscale,
@@ -789,6 +796,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     std::vector<int> slot(N);
     for (int i = 0; i < N; i++) {
         slot[i] = slot_of(h, numbers[i]);
+        if (slot[i] < 0 && h->ignore_unknown) slot[i] = h->S;  // a ghost: sorted last, never binned, no neighbours
         if (slot[i] < 0) return fail(SGPR_E_SPECIES, "atom %d: Z=%d is not in the model's species table", i, numbers[i]);
     }
     h->N = N; h->rank = rank; h->world = world;
@@ -808,13 +816,15 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     std::vector<int> lslot(h->cnt_rows, -1), lnn(h->cnt_rows, 1);
     for (int il = 0; il < h->cnt; il++) {
         const int s = h->slot_sorted[rank + il * world];
+        if (s >= h->S) { lnn[il] = 0; continue; }  // ghost row: outside every species block, slot -1
         lslot[il] = s;
         h->aoff[s + 1]++;
     }
     for (int s = 0; s < h->S; s++) h->aoff[s + 1] += h->aoff[s];
     h->mean_energy = 0.0;
     if (rank == 0)
-        for (int i = 0; i < N; i++) h->mean_energy += h->mean_w[slot[i]];
+        for (int i = 0; i < N; i++)
+            if (slot[i] < h->S) h->mean_energy += h->mean_w[slot[i]];
     int bad = 0;
     bad |= h->d_perm.alloc(std::max(N, 1), false);
     bad |= h->d_slot.alloc(h->N_rows, false);
@@ -901,7 +911,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         (void)hipEventRecord(h->ev[0], st);
     }
     NlParams np = {};
-    np.N = N;
+    np.N = N; np.S = h->S;
     for (int k = 0; k < 3; k++) np.pbc[k] = h->pbc[k];
     // single-process frames: reverse pass in gather form (reverse index from the list build, pair
     // gradients summed by the last kernel); sharded frames scatter with atomics (remote atoms' lists
@@ -1241,6 +1251,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
+    if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
     return fail(SGPR_E_INVALID, "sgpr_set_option: unknown option %s", name);
 }
 

@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     const double xi = uniform(a.pos[3 * (size_t)i]), yi = uniform(a.pos[3 * (size_t)i + 1]), zi = uniform(a.pos[3 * (size_t)i + 2]);
     const int bi = __builtin_amdgcn_readfirstlane(n.bin_of[i]), ki = __builtin_amdgcn_readfirstlane(n.kslot[i]);
     int wi0 = 0, wi1 = 0, wi2 = 0;
-    if (ki < cap) {  // (ki >= cap: the bin overflowed, the host grows it and reruns the step)
+    const bool ghost = ki < 0;  // species outside the model's table (option "ignore_unknown_species"): no environment
+    if (ki >= 0 && ki < cap) {  // (ki >= cap: the bin overflowed, the host grows it and reruns the step)
         const BinAux own = n.b_aux[(size_t)bi * cap + ki];
         wi0 = own.w0; wi1 = own.w1; wi2 = own.w2;
     }
@@ -572,8 +573,8 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     // reverse-index table: row stride nbox*cap entries; a smaller allocation is reported (sticky) and
     // the host grows it and reruns, like the other capacities
     const bool t_ok = n.T != nullptr && (long long)nbox * cap <= (long long)n.t_stride && cap <= 4096 && maxnn <= 65535 &&
-                      ki < cap;
-    if (n.T != nullptr && !t_ok && ki < cap && lane == 0 && ia == 0)
+                      ki < cap && !ghost;
+    if (n.T != nullptr && !t_ok && ki < cap && !ghost && lane == 0)
         atomicMax(&n.stat[2], cap <= 4096 && maxnn <= 65535 ? nbox * cap : 0x7fffffff);
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int grp = lane >> 4, s16 = lane & 15;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
         base += __popcll(m);
     };
     constexpr int STEPS = NL_STEPS;  // steps (of four bins) whose loads are requested together
-    for (int q0 = 0; q0 < nbox; q0 += 64) {
+    for (int q0 = 0; q0 < (ghost ? 0 : nbox); q0 += 64) {
         // lane = neighbouring bin: index, image code and population of up to 64 bins with one load
         int nbin_l = 0, code_l = 0, cnt_l = 0;
         {
@@ -1325,6 +1326,16 @@ static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ?
         if (p.lmax == 4 && p.nmax == 4) {                                                  \
             if (stv <= 2) return FN(4, 4, 2, __VA_ARGS__);                                  \
             if (stv <= 4) return FN(4, 4, 4, __VA_ARGS__);                                  \
+        }                                                                                  \
+        /* the other (lmax, nmax) pairs of {2,3,4}^2 (similarity/sesoap.py:10-24 takes any): */ \
+        /* one instantiation each, four species slots                                      */ \
+        if (stv <= 4) {                                                                    \
+            if (p.lmax == 2 && p.nmax == 3) return FN(2, 3, 4, __VA_ARGS__);                \
+            if (p.lmax == 2 && p.nmax == 4) return FN(2, 4, 4, __VA_ARGS__);                \
+            if (p.lmax == 3 && p.nmax == 2) return FN(3, 2, 4, __VA_ARGS__);                \
+            if (p.lmax == 3 && p.nmax == 4) return FN(3, 4, 4, __VA_ARGS__);                \
+            if (p.lmax == 4 && p.nmax == 2) return FN(4, 2, 4, __VA_ARGS__);                \
+            if (p.lmax == 4 && p.nmax == 3) return FN(4, 3, 4, __VA_ARGS__);                \
         }                                                                                  \
         return -6;                                                                         \
     } while (0)

@@ -27,7 +27,7 @@ __device__ __forceinline__ double det3d(const double *h)
 }
 
 struct BinArgs {
-    int N, cap;
+    int N, cap, S;
     const int *perm;        // sorted -> caller (may be null: identity)
     const double *pos_in;   // caller order
     const double *cell;
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     }
     const int bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
     a.bin_of[i] = bin;
+    if (slot_i >= a.S) {  // a ghost (species outside the model's table, option "ignore_unknown_species"): nobody's neighbour
+        a.kslot[i] = -1;
+        return;
+    }
     const int k = atomicAdd(&a.bin_count[bin], 1);
     a.kslot[i] = k;
     if (max(max(abs(w[0]), abs(w[1])), abs(w[2])) > 32767) atomicMax(&a.stat[3], 1);  // atoms > 32767 cells away
@@ -145,7 +149,7 @@ void launch_neighbor_bin(const NlParams &p, const int *perm, const double *pos_i
 {
     if (p.N <= 0) return;
     BinArgs a = {};
-    a.N = p.N; a.cap = s.cap; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
+    a.N = p.N; a.cap = s.cap; a.S = p.S; a.perm = perm; a.pos_in = pos_in; a.cell = cell; a.rc = rc;
     for (int k = 0; k < 3; k++) a.pbc[k] = p.pbc[k];
     a.grid = s.grid; a.pos = pos; a.bin_count = s.bin_count; a.b_rec = s.b_rec; a.b_aux = s.b_aux;
     a.slot = s.slot; a.bin_of = s.bin_of; a.kslot = s.kslot; a.stat = s.stat;

@@ -38,6 +38,7 @@ struct DevModel;  // defined in api.hip
 // ---- launchers (each enqueues on `st`, never synchronises) -------------------------------
 struct NlParams {
     int N;            // all atoms (binned)
+    int S;            // species slots of the model; atoms with slot >= S are ghosts (never binned)
     int pbc[3];
 };
 

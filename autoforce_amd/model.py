@@ -36,7 +36,11 @@ def default_radii(species):
 
 
 class SGPRModel:
-    def __init__(self, lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, radii=None, device=0):
+    def __init__(self, lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, radii=None, device=0,
+                 unknown_species="error"):
+        """unknown_species: "error" (default) or "ignore" — atoms and LCE neighbours whose atomic number is
+        not in `species` are invisible, as in the reference's fixed-species kernels
+        (descriptor/sesoap.py:343-346, similarity/heterosoap.py:37-71)."""
         if species is None or len(species) == 0:
             raise ValueError("SGPRModel needs the species table (atomic numbers the model may meet)")
         self.lmax, self.nmax, self.exponent, self.cutoff = int(lmax), int(nmax), float(exponent), float(cutoff)
@@ -47,6 +51,11 @@ class SGPRModel:
         lib = _lib.load()
         check(lib.sgpr_create(self.lmax, self.nmax, self.exponent, self.cutoff, len(self.species),
                               ptr(i32(self.species)), ptr(f64(self.radii)), self.device, C.byref(self._h)))
+        self.unknown_species = unknown_species
+        if unknown_species == "ignore":
+            check(lib.sgpr_set_option(self._h, b"ignore_unknown_species", 1))
+        elif unknown_species != "error":
+            raise ValueError("unknown_species must be 'error' or 'ignore'")
         self.X = []
         self.mu = None
         self.choli = None
@@ -98,7 +107,23 @@ class SGPRModel:
         """A second, empty model with the same kernel on the same device (used for one-off
         K(atoms, atoms) evaluations that must not disturb this model's inducing set)."""
         return SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=self.species, radii=self.radii,
-                         device=self.device)
+                         device=self.device, unknown_species=self.unknown_species)
+
+    def with_species(self, species):
+        """The same model over another species table (same kernel, inducing LCEs, weights): how the
+        wildcard kernel of the reference (calculator/active.py:28-38, a 120-wide sparse table) is
+        served by a dense table — it is re-laid-out when a new species turns up.  Descriptor blocks
+        of absent species are zero, so every kernel value, mu and choli stay what they were."""
+        new = SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=species, device=self.device,
+                        unknown_species=self.unknown_species)
+        new.mean.update(self.mean)
+        new._vscale = dict(self._vscale)
+        if self.X:
+            new.set_inducing(self.X)
+            if self.mu is not None:
+                new.set_weights(self.mu, mean=self.mean, vscale=self._vscale or None, choli=self.choli)
+        new.ridge, new.sigma = self.ridge, self.sigma
+        return new
 
     # ------------------------------------------------------------------ inducing set
     def set_inducing(self, X):

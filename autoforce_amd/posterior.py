@@ -155,6 +155,15 @@ class PosteriorPotential:
         v = [fr.stress * fr.get_volume() for fr in self.data]
         return e, (np.concatenate(f) if f else np.zeros(0)), (np.concatenate(v) if v else np.zeros(0))
 
+    def retable(self, species):
+        """Swap the engine for one over a larger species table (engine.with_species): the training
+        rows K and every model number stay as they are."""
+        old = self.engine
+        self.engine = old.with_species([int(z) for z in species])
+        close = getattr(old, "close", None)
+        if close:
+            close()
+
     # ------------------------------------------------------------------ building K
     def _rows(self, fr):
         ke, kf, kv = self.engine.kernel_rows(*fr.system())

@@ -21,8 +21,10 @@ def start(seed=0):
     return rng, numbers, sites + 0.1 * rng.normal(size=sites.shape), cell
 
 
-def run(engine, tmp, steps=6, seed=0, tape=True, **kw):
-    """Returns (calc, trace): trace[k] = (size, energy, forces, covlog, deltas is not None)."""
+def run(engine, tmp, steps=6, seed=0, tape=True, wildcard=False, **kw):
+    """Returns (calc, trace): trace[k] = (size, energy, forces, covlog, deltas is not None).
+    wildcard: the engine starts with a placeholder species table that the calculator extends on
+    demand (the reference's default, species-wildcard kernel: calculator/active.py:28-38)."""
     np.random.seed(1234)  # sample_rand_lces draws from the global generator, like the reference
     from oracle import oracle as orc
     orc.set_num_threads(1)  # fixed summation order in the oracle (teacher neighbour lists, OracleModel)
@@ -32,6 +34,7 @@ def run(engine, tmp, steps=6, seed=0, tape=True, **kw):
     args.update(kw)
     calc = ActiveCalculator(engine=engine, calculator=teacher, logfile=str(tmp / "active.log"),
                             tape=str(tmp / "model.sgpr") if tape else None, pckl=str(tmp / "model.npz"), **args)
+    calc._wildcard = wildcard
     trace = []
     try:
         for _ in range(steps):

@@ -42,6 +42,17 @@ class OracleModel:
         self._nl = None
         self.calls = 0
 
+    def with_species(self, species):
+        new = OracleModel(self.lmax, self.nmax, self.exponent, self.cutoff, species)
+        new.mean.update(self.mean)
+        new._vscale = dict(self._vscale)
+        if self.X:
+            new.set_inducing(self.X)
+            if self.mu is not None:
+                new.set_weights(self.mu, mean=self.mean, vscale=self._vscale or None, choli=self.choli)
+        new.ridge, new.sigma = self.ridge, self.sigma
+        return new
+
     # ---- inducing set
     def _csr(self, X):
         ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])]).astype(np.int64)

@@ -44,6 +44,20 @@ def test_learning_loop(tmp_path):
     assert teacher.calls == n
 
 
+def test_wildcard_species_table_grows_on_demand(tmp_path):
+    """kernel_kw without `species` = the reference's default wildcard kernel (active.py:28-38): the dense
+    table is laid out from the species met; the run is the fixed-table run."""
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    _, _, fixed = ac.run(engine(), tmp_path / "a", steps=4)
+    calc, _, wild = ac.run(OracleModel(3, 3, 4, 4.5, species=[0]), tmp_path / "b", steps=4, wildcard=True)
+    assert sorted(calc.engine.species) == ac.SPECIES
+    assert [t[0] for t in wild] == [t[0] for t in fixed]
+    for a, b in zip(wild, fixed):
+        assert abs(a[1] - b[1]) <= 1e-10 * max(1.0, abs(b[1]))
+        np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-9)
+    assert "species table -> [3, 9]" in open(tmp_path / "b" / "active.log").read()
+
+
 def test_tape_replay_and_build(tmp_path):
     calc, teacher, trace = ac.run(engine(), tmp_path)
     blocks = SgprIO(str(tmp_path / "model.sgpr")).read()

@@ -233,7 +233,7 @@ def test_fixed_species_table_descriptor():
     sgpr_set_inducing + sgpr_get_inducing_descriptors, incl. a table with an absent species."""
     from autoforce_amd import Local, SGPRModel, SgprError
     g2, g3 = load("g2_sesoap"), load("g3_subsesoap")
-    compiled = {(3, 3), (2, 2), (4, 4)}
+    compiled = {(l, n) for l in (2, 3, 4) for n in (2, 3, 4)}
     seen = 0
     for key in g3["names"]:
         name = str(g3[key + "_case"])
@@ -252,5 +252,42 @@ def test_fixed_species_table_descriptor():
         p = mdl.inducing_descriptors().reshape(S, S, nmax + 1, nmax + 1, lmax + 1)
         np.testing.assert_allclose(p.transpose(1, 0, 2, 3, 4), g3[key + "_p"], rtol=1e-10, atol=1e-13, err_msg=str(key))
         mdl.close()
+        # the reference's own behaviour, behind the flag: neighbours outside the table are dropped
+        # silently (descriptor/sesoap.py:343-346) — the UNFILTERED environment gives the same descriptor
+        mdl = SGPRModel(lmax, nmax, 4, 6.0, species=table, unknown_species="ignore")
+        mdl.set_inducing([Local(table[0], z, r)])
+        p = mdl.inducing_descriptors().reshape(S, S, nmax + 1, nmax + 1, lmax + 1)
+        np.testing.assert_allclose(p.transpose(1, 0, 2, 3, 4), g3[key + "_p"], rtol=1e-10, atol=1e-13, err_msg=str(key))
+        mdl.close()
         seen += 1
-    assert seen >= 8
+    assert seen == len(g3["names"])
+
+
+def test_atoms_outside_the_species_table_can_be_ignored():
+    """Option unknown_species="ignore": a frame with foreign atoms evaluates as the frame without them
+    (no environment of their own, nobody's neighbour: similarity/heterosoap.py:37-71 has no kernel for
+    them, descriptor/sesoap.py:343-346 masks them as neighbours); their forces and covloss are zero."""
+    from autoforce_amd import Local, SGPRModel
+    g = load("g5_mixed64")
+    ptr = g["ind_ptr"]
+    X = [Local(int(z), g["ind_nbr_z"][ptr[q]:ptr[q + 1]], g["ind_nbr_r"][ptr[q]:ptr[q + 1]]) for q, z in enumerate(g["ind_z"])]
+    vs = dict(zip(g["vscale_z"].tolist(), g["vscale"].tolist()))
+    numbers = g["numbers"].copy()
+    ghosts = np.array([3, 17, 40, 63])
+    numbers[ghosts] = 79
+    keep = np.setdiff1d(np.arange(len(numbers)), ghosts)
+    mdl = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=g["species"].tolist(),
+                    unknown_species="ignore")
+    mdl.set_inducing(X)
+    mdl.set_weights(g["mu"], vscale=vs, choli=g["choli"])
+    a = mdl.predict(numbers, g["positions"], g["cell"], g["pbc"], cov=True)
+    b = mdl.predict(numbers[keep], g["positions"][keep], g["cell"], g["pbc"], cov=True)
+    assert abs(a["energy"] - b["energy"]) <= 1e-12 * max(1.0, abs(b["energy"]))
+    fmax = np.abs(b["forces"]).max()
+    assert np.abs(a["forces"][keep] - b["forces"]).max() <= 1e-12 * fmax
+    assert np.abs(a["forces"][ghosts]).max() == 0.0 and np.abs(a["beta"][ghosts]).max() == 0.0
+    np.testing.assert_allclose(a["stress"], b["stress"], rtol=0, atol=1e-12 * np.abs(b["stress"]).max())
+    np.testing.assert_allclose(a["beta"][keep], b["beta"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a["cov"][keep], b["cov"], rtol=0, atol=1e-13)
+    assert np.abs(a["cov"][ghosts]).max() == 0.0
+    mdl.close()
