@@ -203,9 +203,14 @@ class PosteriorPotential:
         ke = np.concatenate([c[0][None, :] for c in cols] + [np.zeros((0, 1))])
         kf = np.concatenate([c[1] for c in cols] + [np.zeros((0, 1))])
         kv = np.concatenate([c[2] for c in cols] + [np.zeros((0, 1))])
-        self.Ke = np.concatenate([self.Ke, ke], axis=1)
-        self.Kf = np.concatenate([self.Kf, kf], axis=1)
-        self.Kv = np.concatenate([self.Kv, kv], axis=1)
+        if self.Ke.size > 0:
+            self.Ke = np.concatenate([self.Ke, ke], axis=1)
+            self.Kf = np.concatenate([self.Kf, kf], axis=1)
+            self.Kv = np.concatenate([self.Kv, kv], axis=1)
+        else:
+            # frames were stored before any inducing LCE existed (add_1atoms_fast with an empty X): their
+            # first rows are this column (gppotential.py:757-764, the numel() == 0 branch)
+            self.Ke, self.Kf, self.Kv = ke, kf, kv
         if remake:
             self.make_munu()
 

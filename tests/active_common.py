@@ -84,3 +84,74 @@ def check_g8_edit_sequence(engine):
     check(4)
     p.select_inducing([4, 0, 7, 2])  # = original numbers 5, 1, 8, 3
     check(5)
+
+
+def check_g11_acceptance(engine):
+    """tests/golden/g11_acceptance.npz: the accept / reject decisions (and the energy / force changes
+    behind them) that the reference's own add_1inducing and add_1atoms_fast
+    (regression/gppotential.py:898-982) take over a sequence of candidate LCEs and data frames,
+    against PosteriorPotential driving `engine` through the same sequence."""
+    from oracle import oracle as orc
+    from autoforce_amd.model import Local
+    from autoforce_amd.posterior import Frame, PosteriorPotential
+    from helpers import load
+    want, g = load("g11_acceptance"), load("g5_big40")
+    numbers, cell, pbc, rc = g["numbers"], g["cell"], g["pbc"], float(g["rc"])
+    ptr, j, off = orc.neighbors(want["cand_pos"], cell, pbc, rc)
+    cand = {}
+    for a in want["cand_atoms"]:
+        sl = slice(ptr[a], ptr[a + 1])
+        r = want["cand_pos"][j[sl]] - want["cand_pos"][a] + off[sl] @ cell
+        cand[int(a)] = Local(int(numbers[a]), numbers[j[sl]], r)
+    pos = [want["pos0"]] + list(want["frames_pos"])
+    frames = [Frame(numbers, pos[k], cell, pbc, float(want["teacher_e"][k]), want["teacher_f"][k], want["teacher_s"][k])
+              for k in range(len(pos))]
+    p = PosteriorPotential(engine)
+    assert p.add_1atoms_fast(frames[0], 0.05, 0.1)[0] == 1
+    for kind, idx, added, de, df, m, nd, ridge, t1, t2 in want["events"]:
+        if kind == 0:
+            got_added, got_de = p.add_1inducing(cand[int(idx)], float(t1))
+            got_df = 0.0
+        else:
+            got_added, got_de, got_df = p.add_1atoms_fast(frames[1 + int(idx)], float(t1), float(t2))
+        assert got_added == int(added), (kind, idx, got_added, added, got_de, de)
+        assert (len(p.X), p.ndata) == (int(m), int(nd))
+        if np.isfinite(de):
+            # the reference's K_f / K_v rows come from its fp32-tainted analytic gradients (1e-6 relative)
+            assert abs(got_de - de) <= 2e-4 * max(abs(de), 1e-2), (kind, idx, got_de, de)
+            assert abs(got_df - df) <= 2e-4 * max(abs(df), 1e-2), (kind, idx, got_df, df)
+        assert p.ridge == float(ridge)
+
+
+def check_g12_bcm(make_engine):
+    """tests/golden/g12_bcm.npz: the committee prediction of the reference's own
+    BCMActiveCalculator.update_results (calculator/active_bcm.py:589-633; forces and stress by autograd
+    through the weighted energy) against autoforce_amd.calculator_bcm on `make_engine()` members."""
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator_bcm import BCMActiveCalculator
+    from autoforce_amd.model import Local
+    from autoforce_amd.posterior import PosteriorPotential
+    from helpers import load
+    want, g = load("g12_bcm"), load("g5_big40")
+    ptr = g["ind_ptr"]
+    locs = [Local(int(z), g["ind_nbr_z"][ptr[q]:ptr[q + 1]], g["ind_nbr_r"][ptr[q]:ptr[q + 1]])
+            for q, z in enumerate(g["ind_z"])]
+    posts = {}
+    for key in ("a", "live"):
+        eng = make_engine()
+        eng.set_inducing([locs[i] for i in want[f"{key}_idx"]])
+        eng.set_weights(want[f"{key}_mu"], mean=dict(zip(want[f"{key}_mean_z"].tolist(), want[f"{key}_mean_w"].tolist())),
+                        vscale=dict(zip(want[f"{key}_vscale_z"].tolist(), want[f"{key}_vscale"].tolist())),
+                        choli=want[f"{key}_choli"])
+        eng.ridge = float(want[f"{key}_ridge"])
+        posts[key] = PosteriorPotential(eng)
+        posts[key].mean.weights.update(dict(zip(want[f"{key}_mean_z"].tolist(), want[f"{key}_mean_w"].tolist())))
+    bcm = BCMActiveCalculator(covariance=posts["live"], kernel_model_dict={"a": posts["a"]}, logfile=None)
+    at = Atoms(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    at.calc = bcm
+    e, f, s = at.get_potential_energy(), at.get_forces(), at.get_stress()
+    assert abs(e - float(want["energy"])) <= 1e-9 * max(1.0, abs(float(want["energy"])))
+    assert np.abs(f - want["forces"]).max() <= 1e-8 * np.abs(want["forces"]).max()
+    assert np.abs(s - want["stress"]).max() <= 1e-8 * np.abs(want["stress"]).max()
+    np.testing.assert_allclose(bcm.get_covloss_total(), np.minimum(want["covloss_a"], want["covloss_live"]), rtol=0, atol=2e-6)
+    assert abs(float(np.max(np.minimum(want["covloss_a"].max(), want["covloss_live"].max()))) - float(want["covloss_max"])) < 1e-12

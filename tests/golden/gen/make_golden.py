@@ -717,6 +717,273 @@ def g8_edits(name="g5_big40"):
     print("g8_edits done:", [len(s) for s in states], "ridges", [out[f"ridge_{k}"] for k in range(len(states))])
 
 
+
+# ----------------------------------------------------------------------------- G11 acceptance rules
+def g11_acceptance(name="g5_big40"):
+    """The decisions of the on-the-fly sampler, taken by the reference's OWN code
+    (regression/gppotential.py:898-953 add_1atoms_fast, :955-982 add_1inducing, with its add_inducing /
+    pop_1inducing / add_data / pop_1data :730-800 and _regression :1204-1339), on a duck-typed model:
+    only the kernel plumbing (which Locals a frame consists of) is supplied here; every number and every
+    accept/reject comes out of the reference functions.  Candidate LCEs carry `counts()` (one atom of
+    their species): the reference evaluates `self.mean(loc)` inside `self(loc)` (:1121-1136)."""
+    from theforce.descriptor.atoms import LocalsData
+    from theforce.regression.gppotential import PosteriorPotential
+
+    g = np.load(os.path.join(OUT, name + ".npz"))
+    kern, efk = make_kernel(int(g["lmax"]), int(g["nmax"]), int(g["eta"]), float(g["rc"]))
+    rc = float(g["rc"])
+    numbers, cell, pbc = g["numbers"], g["cell"], g["pbc"]
+    N = len(numbers)
+    vol = abs(np.linalg.det(cell))
+    rng = np.random.default_rng(110)
+
+    def teacher(pos):
+        """a smooth synthetic label: harmonic pull towards the golden frame + pairwise terms are not
+        needed; what matters is that labels are a deterministic function of the positions."""
+        d = pos - g["positions"]
+        e = 0.5 * 0.8 * float((d * d).sum()) - 3.0
+        return e, -0.8 * d + 0.05 * np.sin(3.0 * pos), 0.002 * np.array([1.0, -0.5, 0.25, 0.1, -0.2, 0.3]) * (1.0 + float(np.abs(d).sum()))
+
+    # (LocalsData accepts exact `Local` instances only: the method is attached to the class, in this process)
+    Local.counts = lambda self: {int(self.number): 1}
+    _Loc = Local
+
+    def locals_of(pos, grad=False):
+        ptr, J, O = brute_force_nl(pos, cell, pbc, rc)
+        xyz = torch.tensor(pos, requires_grad=grad)
+        lll = torch.tensor(cell)
+        locs = []
+        for a in range(N):
+            n = J[ptr[a]:ptr[a + 1]].astype(np.int64)
+            off = O[ptr[a]:ptr[a + 1]]
+            r = xyz[n] - xyz[a] + (torch.from_numpy(off[..., None].astype(float)) * lll).sum(dim=1)
+            loc = _Loc(a, n, numbers[a], numbers[n], r, off, efk.kernels, dont_save_grads=grad)
+            loc.natoms = N
+            locs.append(loc)
+        return locs, xyz
+
+    class _Frame:
+        is_distributed = False
+
+        def __init__(self, pos):
+            self.positions = pos
+            self.locs, _ = locals_of(pos)
+            e, f, s = teacher(pos)
+            self.energy, self.forces, self.stress = e, f, s
+            self.target_energy = torch.tensor([e])
+            self.target_forces = torch.tensor(f)
+            self.target_stress = torch.tensor(s)
+            self.natoms = N
+
+        def includes_species(self, species):
+            return True
+
+        def get_volume(self):
+            return vol
+
+        def counts(self):
+            u, c = np.unique(numbers, return_counts=True)
+            return {int(a): int(b) for a, b in zip(u, c)}
+
+        def __len__(self):
+            return N
+
+    class _Data(list):
+        is_distributed = False
+
+        @property
+        def X(self):
+            return self
+
+        @property
+        def natoms(self):
+            return [fr.natoms for fr in self]
+
+        @property
+        def target_energy(self):
+            return torch.cat([fr.target_energy for fr in self])
+
+        def counts(self):
+            tot = {}
+            for fr in self:
+                for z, c in fr.counts().items():
+                    tot[z] = tot.get(z, 0) + c
+            return tot
+
+    def as_locals(obj):
+        """frames -> their Locals grouped per frame; Locals / LocalsData -> one group per Local"""
+        if isinstance(obj, (_Frame,)):
+            return [obj.locs]
+        if isinstance(obj, Local):
+            return [[obj]]
+        return [grp for o in obj for grp in as_locals(o)]
+
+    def kern_call(first, second, cov="energy_energy"):
+        rows = as_locals(first)
+        cols = [x for grp in as_locals(second) for x in grp]
+        m = len(cols)
+        out = []
+        for grp in rows:
+            n = len(grp)
+            if cov == "energy_energy":
+                out.append(efk.base_kerns(grp, cols, "func").sum(0).view(1, m))
+            elif cov == "forces_energy":
+                out.append(-efk.base_kerns(grp, cols, "leftgrad").view(n, -1, m).sum(0))
+            elif cov == "virial_energy":
+                out.append(efk.base_kerns(grp, cols, "virial").view(n, 6, m).sum(0))
+            else:
+                raise NotImplementedError(cov)
+        return torch.cat(out) if out else torch.zeros(0, m)
+
+    class _Model:
+        ignore_forces = False
+        has_target_forces = False
+        is_distributed = False
+
+        def __init__(self):
+            self.mean_obj = AutoMean()
+            self.gp = SimpleNamespace(species=sorted(set(int(z) for z in numbers)), kern=kern_call,
+                                      noise=White(signal=0.01, requires_grad=False), method_caching=False,
+                                      clear_cached=lambda *a, **k: None, parametric=self.mean_obj,
+                                      mean=lambda dat, forces=False: torch.stack([self.mean_obj(a) for a in dat]))
+            self.data = _Data()
+            self.X = LocalsData([])
+            self.M = torch.empty(0, 0)
+            self.Ke, self.Kf, self.Kv = torch.empty(0, 0), torch.empty(0, 0), torch.empty(0, 0)
+            self.ridge = 0.0
+
+        mean = property(lambda self: self.mean_obj)
+        K = property(lambda self: torch.cat([self.Ke, self.Kf, self.Kv], dim=0))
+
+        def make_munu(self, *a, **k):
+            if len(self.X) == 0 or len(self.data) == 0:
+                return
+            self.mean_obj.set_data(self.data)
+            _regression(self, optimize=False)
+
+        def __call__(self, *a, **k):
+            return PosteriorPotential.forward(self, *a, **k)
+
+        add_inducing = PosteriorPotential.add_inducing
+        pop_1inducing = PosteriorPotential.pop_1inducing
+        add_data = PosteriorPotential.add_data
+        pop_1data = PosteriorPotential.pop_1data
+        add_1inducing = PosteriorPotential.add_1inducing
+        add_1atoms_fast = PosteriorPotential.add_1atoms_fast
+
+    mdl = _Model()
+    pos0 = g["positions"] + 0.03 * rng.normal(size=(N, 3))
+    fr0 = _Frame(pos0)
+    # the inducing candidates: environments of rattled copies of the frame
+    cand_pos = g["positions"] + 0.12 * rng.normal(size=(N, 3))
+    cand_locs, _ = locals_of(cand_pos)
+    order = rng.permutation(N)[:14]
+    out = dict(frame=name, n_cand=len(order), cand_pos=cand_pos, cand_atoms=order.astype(np.int32), pos0=pos0)
+    # seed: first data frame (no inducing yet -> appended bare), first two candidates
+    added, de, df = mdl.add_1atoms_fast(fr0, 0.05, 0.1, None, None, False)
+    assert added == 1
+    events = []  # kind, index, added, de, df, m, n_data, ridge, threshold 1, threshold 2
+    for k, a in enumerate(order):
+        loc = cand_locs[int(a)]
+        ediff = (0.01, 0.3, 0.6)[k % 3]  # thresholds chosen so that both outcomes occur
+        _ediff = ediff if len(mdl.X) > 1 else float(torch.finfo().eps)  # add_ninducing, :1004
+        added, de = mdl.add_1inducing(loc, _ediff, detach=False)
+        events.append((0, int(a), int(added), float(de), 0.0, len(mdl.X), len(mdl.data), float(mdl.ridge), _ediff, 0.0))
+    # data candidates: further rattled frames through add_1atoms_fast with the calculator's cov
+    frames_pos = [g["positions"] + s * rng.normal(size=(N, 3)) for s in (0.02, 0.15, 0.04, 0.3)]
+    out["frames_pos"] = np.stack(frames_pos)
+    for k, pos in enumerate(frames_pos):
+        fr = _Frame(pos)
+        locs_g, xyz = locals_of(pos, grad=True)
+        cov = efk(locs_g, list(mdl.X))
+        ediff_tot, fdiff = ((0.05, 0.1), (0.05, 3.0), (0.05, 0.1), (0.05, 6.0))[k]
+        added, de, df = mdl.add_1atoms_fast(fr, ediff_tot, fdiff, xyz, cov, False)
+        events.append((1, k, int(added), float(de), float(df), len(mdl.X), len(mdl.data), float(mdl.ridge), ediff_tot, fdiff))
+        out[f"mu_after_frame_{k}"] = mdl.mu.detach().numpy().copy()
+    out["events"] = np.array(events, float)
+    out["teacher_e"] = np.array([teacher(p_)[0] for p_ in [pos0] + frames_pos])
+    out["teacher_f"] = np.stack([teacher(p_)[1] for p_ in [pos0] + frames_pos])
+    out["teacher_s"] = np.stack([teacher(p_)[2] for p_ in [pos0] + frames_pos])
+    np.savez_compressed(os.path.join(OUT, "g11_acceptance.npz"), **out)
+    print("g11_acceptance done:")
+    for e in events:
+        print("   ", "indu" if e[0] == 0 else "data", int(e[1]), "added" if e[2] else "rejected", f"de={e[3]:.3e} df={e[4]:.3e}",
+              f"size=({int(e[6])},{int(e[5])}) ridge={e[7]:.1e}")
+
+
+# ----------------------------------------------------------------------------- G12 committee (BCM)
+def g12_bcm(name="g5_big40"):
+    """The committee prediction of BCMActiveCalculator.update_results (calculator/active_bcm.py:589-633,
+    with its get_covloss_with_model :842-858, get_covloss :860-885 and grads :640-663) run on a duck-typed
+    calculator: two members = two inducing subsets of the golden frame's set with their own mu / choli /
+    _vscale; energy = sum_k scale_k E_k / sum_k scale_k, scale_k = -ln(covmax_k) / covmax_k, and forces /
+    stress by torch.autograd through that weighted energy."""
+    import types
+    from theforce.calculator.active_bcm import BCMActiveCalculator
+
+    g = np.load(os.path.join(OUT, name + ".npz"))
+    kern, efk = make_kernel(int(g["lmax"]), int(g["nmax"]), int(g["eta"]), float(g["rc"]))
+    numbers, pos, cell, pbc = g["numbers"], g["positions"], g["cell"], g["pbc"]
+    ptr, J, O = g["nl_ptr"], g["nl_j"], g["nl_off"]
+    N = len(numbers)
+    xyz = torch.tensor(pos, requires_grad=True)
+    lll = torch.tensor(cell, requires_grad=True)
+    locs = []
+    for a in range(N):
+        n = J[ptr[a]:ptr[a + 1]].astype(np.int64)
+        off = O[ptr[a]:ptr[a + 1]]
+        r = xyz[n] - xyz[a] + (torch.from_numpy(off[..., None].astype(float)) * lll).sum(dim=1)
+        loc = Local(a, n, numbers[a], numbers[n], r, off, efk.kernels, dont_save_grads=True)
+        loc.natoms = N
+        locs.append(loc)
+    ip = g["ind_ptr"]
+    X = []
+    for q, zc in enumerate(g["ind_z"]):
+        k = int(ip[q + 1] - ip[q])
+        X.append(Local(0, np.arange(1, k + 1), int(zc), g["ind_nbr_z"][ip[q]:ip[q + 1]].astype(np.int64),
+                       torch.tensor(g["ind_nbr_r"][ip[q]:ip[q + 1]].reshape(k, 3)), None, efk.kernels, True))
+    rng = np.random.default_rng(120)
+    m = len(X)
+    subsets = {"a": list(range(0, m, 2)), "live": list(range(1, m, 2)) + [0]}
+    out = dict(frame=name)
+    members = {}
+    for key, idx in subsets.items():
+        Xs = [X[i] for i in idx]
+        M = efk(Xs, Xs).detach()
+        L, ridge = jitcholesky(M)
+        choli = L.inverse().contiguous()
+        mu = torch.tensor(rng.normal(size=len(idx)) * 0.5)
+        indz = np.array([int(x.number) for x in Xs])
+        mm = mu * (M @ mu)  # gppotential.py:644-649
+        vscale = {int(z): mm[torch.from_numpy(indz == z)].sum() / int((indz == z).sum()) for z in set(indz.tolist())}
+        w = {int(z): float(rng.normal() * 0.1) for z in set(int(q) for q in numbers)}
+        mean = (lambda ww: (lambda atoms: torch.tensor(sum(ww[int(z)] for z in atoms.numbers))))(w)
+        members[key] = SimpleNamespace(choli=choli, mu=mu, _vscale=vscale, mean=mean, cov=efk(locs, Xs))
+        out[f"{key}_idx"] = np.array(idx, np.int32)
+        out[f"{key}_mu"] = mu.numpy()
+        out[f"{key}_choli"] = choli.numpy()
+        out[f"{key}_ridge"] = float(ridge)
+        out[f"{key}_vscale_z"] = np.array(sorted(vscale), np.int32)
+        out[f"{key}_vscale"] = np.array([float(vscale[z]) for z in sorted(vscale)])
+        out[f"{key}_mean_z"] = np.array(sorted(w), np.int32)
+        out[f"{key}_mean_w"] = np.array([w[z] for z in sorted(w)])
+    vol = abs(np.linalg.det(cell))
+    duck = SimpleNamespace(
+        model_dict={"a": members["a"]}, K_sm={"a": members["a"].cov}, model=members["live"], cov=members["live"].cov,
+        atoms=SimpleNamespace(numbers=numbers, is_distributed=False, xyz=xyz, lll=lll, get_volume=lambda: vol),
+        gather=lambda x: x, normalized=True, results={}, maximum_force=None, log=lambda *a, **k: None)
+    for fn in ("update_results", "get_covloss_with_model", "get_covloss", "grads"):
+        setattr(duck, fn, types.MethodType(getattr(BCMActiveCalculator, fn), duck))
+    energy, covloss_max = duck.update_results()
+    out.update(energy=float(energy), forces=np.asarray(duck.results["forces"]), stress=np.asarray(duck.results["stress"]),
+               covloss_max=float(covloss_max),
+               covloss_a=duck.get_covloss_with_model("a", duck.K_sm["a"]).detach().numpy(),
+               covloss_live=duck.get_covloss().detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "g12_bcm.npz"), **out)
+    print(f"g12_bcm done: E={float(energy):.6f} |F|max={np.abs(out['forces']).max():.4f} covmax: a={out['covloss_a'].max():.4f} "
+          f"live={out['covloss_live'].max():.4f}")
+
+
 # ----------------------------------------------------------------------------- G10 .sgpr tape
 def g10_tape():
     """Text produced by the reference's own tape writer (io/sgprio.py:16-22, :67-90) for three
@@ -792,5 +1059,9 @@ if __name__ == "__main__":
             kernel_rows(nm)
     if "g8" in which:
         g8_edits()
+    if "g11" in which:
+        g11_acceptance()
+    if "g12" in which:
+        g12_bcm()
     if "g10" in which:
         g10_tape()

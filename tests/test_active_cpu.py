@@ -281,6 +281,20 @@ def _al_worker(rank, world, port, tmp, q):
     dist.destroy_process_group()
 
 
+def test_acceptance_rules_against_reference():
+    """g11: accept / reject decisions of the reference's own sampler code on the CPU engine."""
+    g = load("g5_big40")
+    ac.check_g11_acceptance(OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                        species=g["species"].tolist()))
+
+
+def test_bcm_against_reference():
+    """g12: the reference's own committee combination (active_bcm.py:589-633) on the CPU engine."""
+    g = load("g5_big40")
+    ac.check_g12_bcm(lambda: OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                         species=g["species"].tolist()))
+
+
 def test_learning_loop_world2_gloo(tmp_path):
     """Atoms sharded over two ranks (one all-reduce per evaluation, LCEs handed out by their
     owner, rank 0's solve broadcast): every rank takes the same decisions as a single process."""

@@ -22,6 +22,24 @@ def test_edit_sequence_against_reference():
                                         species=g["species"].tolist()))
 
 
+def test_acceptance_rules_against_reference():
+    """g11: the accept / reject decisions of the reference's own add_1inducing / add_1atoms_fast
+    (regression/gppotential.py:898-982), with every kernel row, K_mm edit and solve on the device."""
+    from autoforce_amd import SGPRModel
+    g = load("g5_big40")
+    ac.check_g11_acceptance(SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                      species=g["species"].tolist()))
+
+
+def test_bcm_against_reference():
+    """g12: the reference's own committee combination (calculator/active_bcm.py:589-633, forces by autograd
+    through the weighted energy) against the device committee."""
+    from autoforce_amd import SGPRModel
+    g = load("g5_big40")
+    ac.check_g12_bcm(lambda: SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                       species=g["species"].tolist()))
+
+
 @pytest.mark.parametrize("name", ["g5_mixed64", "g5_big40"])
 def test_edit_entry_points_equal_rebuild(name):
     """sgpr_add/remove/select_inducing leave the library in the state sgpr_set_inducing builds for
