@@ -706,6 +706,7 @@ class ActiveCalculator(Calculator):
         try:
             for cls, obj in tape.read(exclude=self.tape):
                 if cls == "atoms":
+                    obj.check_labels()  # a frame without energy / forces cannot be learned from (stress is optional)
                     if np.abs(obj.forces).max() > self.include_params["fmax"] and len(self.model.data) > 0:
                         continue
                     _save()

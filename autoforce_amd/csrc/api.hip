@@ -553,17 +553,22 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
 {
     if (!h || m < 0 || (m > 0 && (!zc || !nbr_ptr))) return fail(SGPR_E_INVALID, "sgpr_set_inducing: bad arguments");
     HIPCHK(hipSetDevice(h->device));
+    // validate everything first: on an error the handle keeps its previous inducing set untouched
+    std::vector<int> slot(m);
+    for (int q = 0; q < m; q++) {
+        slot[q] = slot_of(h, zc[q]);
+        if (slot[q] < 0) return fail(SGPR_E_SPECIES, "inducing LCE %d: Z=%d is not in the species table", q, zc[q]);
+        if (!h->ignore_unknown)
+            for (int64_t e = nbr_ptr[q]; e < nbr_ptr[q + 1]; e++)
+                if (slot_of(h, nbr_z[e]) < 0)
+                    return fail(SGPR_E_SPECIES, "inducing LCE %d: neighbour Z=%d is not in the species table", q, nbr_z[e]);
+    }
     drop_graph(h);
     h->has_mu = h->has_choli = false;
     h->chol_valid = h->r1_valid = false;
     h->m = m;
     h->m_pad = rup(std::max(m, 1), 32);
     h->m_rows = rup(std::max(m, 1), 64);
-    std::vector<int> slot(m);
-    for (int q = 0; q < m; q++) {
-        slot[q] = slot_of(h, zc[q]);
-        if (slot[q] < 0) return fail(SGPR_E_SPECIES, "inducing LCE %d: Z=%d is not in the species table", q, zc[q]);
-    }
     h->ind_perm.resize(m);
     std::iota(h->ind_perm.begin(), h->ind_perm.end(), 0);
     std::stable_sort(h->ind_perm.begin(), h->ind_perm.end(), [&](int a, int b) { return slot[a] < slot[b]; });
@@ -1012,6 +1017,7 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         HIPCHK(hipGetLastError());
         int stat[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+        if (stat[3] == 2) return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero");
         if (stat[3])
             return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 "
                         "cells from the origin): wrap the positions into the cell");
@@ -1231,6 +1237,7 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
     int stat[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stat.p, 0, 4 * sizeof(int)));
+    if (stat[3] == 2) { h->warm = false; return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero"); }
     if (stat[3]) {
         h->warm = false;
         return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 cells "

@@ -46,10 +46,44 @@ struct BinArgs {
     double *zero_b; int n_zero_b;
 };
 
-__device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGrid &g)
+__device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGrid &g, int *stat)
 {
     double h[9];
     for (int k = 0; k < 9; k++) h[k] = cell[k];
+    // Slabs and wires may come with a zero vector along an open direction (cell = [a, b, 0], pbc = TTF is
+    // valid in ASE): complete such vectors orthogonally to the others before inverting (ase.geometry
+    // complete_cell, which ASE's neighbour list applies), so the periodic directions keep their images.
+    // A zero vector along a PERIODIC direction is an input error (stat[3] = 2).
+    {
+        int zero[3], nz = 0;
+        for (int k = 0; k < 3; k++) {
+            zero[k] = h[3 * k] * h[3 * k] + h[3 * k + 1] * h[3 * k + 1] + h[3 * k + 2] * h[3 * k + 2] < 1e-24;
+            nz += zero[k];
+            if (zero[k] && pbc[k] && stat) atomicMax(&stat[3], 2);
+        }
+        if (nz > 0 && nz < 3) {
+            for (int k = 0; k < 3; k++) {
+                if (!zero[k] || pbc[k]) continue;
+                const double *p = h + 3 * ((k + 1) % 3), *q = h + 3 * ((k + 2) % 3);
+                double v[3];
+                if (!zero[(k + 1) % 3] && !zero[(k + 2) % 3]) {
+                    v[0] = p[1] * q[2] - p[2] * q[1]; v[1] = p[2] * q[0] - p[0] * q[2]; v[2] = p[0] * q[1] - p[1] * q[0];
+                } else {
+                    // one vector only: any direction perpendicular to it (the other open axis follows next)
+                    const double *w = zero[(k + 1) % 3] ? q : p;
+                    const int a = fabs(w[0]) <= fabs(w[1]) && fabs(w[0]) <= fabs(w[2]) ? 0 : (fabs(w[1]) <= fabs(w[2]) ? 1 : 2);
+                    double e[3] = {0.0, 0.0, 0.0};
+                    e[a] = 1.0;
+                    v[0] = w[1] * e[2] - w[2] * e[1]; v[1] = w[2] * e[0] - w[0] * e[2]; v[2] = w[0] * e[1] - w[1] * e[0];
+                }
+                const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                if (nv > 1e-12) {
+                    h[3 * k] = v[0] / nv; h[3 * k + 1] = v[1] / nv; h[3 * k + 2] = v[2] / nv;
+                    zero[k] = 0;
+                }
+            }
+        }
+    }
     const double dt = det3d(h);
     if (fabs(dt) > 1e-12) {
         const double *p = h, *q = h + 3, *r = h + 6;
@@ -89,7 +123,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     __shared__ NlGrid g;
     const int tid = threadIdx.x, wg = blockIdx.x;
     if (tid == 0) {
-        nl_make_grid(a.cell, a.pbc, a.rc, g);
+        nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
         if (wg == 0) *a.grid = g;
     }
     const int gsz = gridDim.x * 256, gid = wg * 256 + tid;

@@ -36,7 +36,9 @@ def save_model(path, model):
             data_cell=np.array([fr.cell for fr in data]).reshape(-1, 3, 3),
             data_pbc=np.array([fr.pbc for fr in data], bool).reshape(-1, 3),
             data_energy=np.array([fr.energy for fr in data], float),
-            data_stress=np.array([fr.stress for fr in data], float).reshape(-1, 6),
+            # frames labelled without stress are stored as NaN rows and come back as stress=None
+            data_stress=np.array([fr.stress if fr.stress is not None else np.full(6, np.nan) for fr in data],
+                                 float).reshape(-1, 6),
             noise_logit=post._noise["all"],
         )
     with open(path, "wb") as f:  # np.savez would append ".npz" to a bare path
@@ -81,7 +83,8 @@ def load_model(path, device=0, engine=None):
         for k in range(len(dp) - 1):
             a, b = int(dp[k]), int(dp[k + 1])
             post.data.append(Frame(g["data_z"][a:b], g["data_pos"][a:b], g["data_cell"][k], g["data_pbc"][k],
-                                   g["data_energy"][k], g["data_forces"][a:b], g["data_stress"][k]))
+                                   g["data_energy"][k], g["data_forces"][a:b],
+                                   None if np.isnan(g["data_stress"][k]).any() else g["data_stress"][k]))
         post._noise["all"] = float(g["noise_logit"])
         if X and post.data:
             rows = [post._rows(fr) for fr in post.data]

@@ -45,6 +45,18 @@ class Frame:
     def natoms(self):
         return len(self.numbers)
 
+    @property
+    def nv(self):
+        """virial rows this frame contributes to K / Y: 6, or 0 for a frame labelled without stress
+        (teachers for clusters and molecules have none; ASE then omits it)."""
+        return 0 if self.stress is None else 6
+
+    def check_labels(self):
+        if self.energy is None or self.forces is None:
+            raise ValueError("a data frame needs energy and forces labels (stress is optional)")
+        if self.forces.shape != (self.natoms, 3):
+            raise ValueError(f"forces of shape {self.forces.shape} for {self.natoms} atoms")
+
     def get_volume(self):
         return abs(float(np.linalg.det(self.cell)))
 
@@ -152,7 +164,7 @@ class PosteriorPotential:
     def targets(self):
         e = np.array([fr.energy - self.mean(fr.counts()) for fr in self.data])
         f = [fr.forces.reshape(-1) for fr in self.data]
-        v = [fr.stress * fr.get_volume() for fr in self.data]
+        v = [fr.stress * fr.get_volume() for fr in self.data if fr.stress is not None]
         return e, (np.concatenate(f) if f else np.zeros(0)), (np.concatenate(v) if v else np.zeros(0))
 
     def retable(self, species):
@@ -166,8 +178,9 @@ class PosteriorPotential:
 
     # ------------------------------------------------------------------ building K
     def _rows(self, fr):
+        fr.check_labels()
         ke, kf, kv = self.engine.kernel_rows(*fr.system())
-        return ke[None, :], kf, kv
+        return ke[None, :], kf, kv[:fr.nv]
 
     def set_data(self, data, inducing):
         """gppotential.py:484-509."""
@@ -202,7 +215,7 @@ class PosteriorPotential:
         cols = [self.engine.kernel_columns(*fr.system(), q, 1) for fr in self.data]
         ke = np.concatenate([c[0][None, :] for c in cols] + [np.zeros((0, 1))])
         kf = np.concatenate([c[1] for c in cols] + [np.zeros((0, 1))])
-        kv = np.concatenate([c[2] for c in cols] + [np.zeros((0, 1))])
+        kv = np.concatenate([c[2][:fr.nv] for c, fr in zip(cols, self.data)] + [np.zeros((0, 1))])
         if self.Ke.size > 0:
             self.Ke = np.concatenate([self.Ke, ke], axis=1)
             self.Kf = np.concatenate([self.Kf, kf], axis=1)
@@ -215,15 +228,15 @@ class PosteriorPotential:
             self.make_munu()
 
     def pop_1data(self, remake=True):
-        n = self.data[-1].natoms
-        self.Ke, self.Kf, self.Kv = self.Ke[:-1], self.Kf[:-3 * n], self.Kv[:-6]
+        n, nv = self.data[-1].natoms, self.data[-1].nv
+        self.Ke, self.Kf, self.Kv = self.Ke[:-1], self.Kf[:-3 * n], self.Kv[:len(self.Kv) - nv]
         del self.data[-1]
         if remake:
             self.make_munu()
 
     def popfirst_1data(self, remake=True):
-        n = self.data[0].natoms
-        self.Ke, self.Kf, self.Kv = self.Ke[1:], self.Kf[3 * n:], self.Kv[6:]
+        n, nv = self.data[0].natoms, self.data[0].nv
+        self.Ke, self.Kf, self.Kv = self.Ke[1:], self.Kf[3 * n:], self.Kv[nv:]
         del self.data[0]
         if remake:
             self.make_munu()

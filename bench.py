@@ -171,9 +171,22 @@ def main():
     sp = C.c_void_p(stream.cuda_stream)
     native = world > 1 and args.collective == "native"
     if native:
-        box = [mdl.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        mdl.comm_init(box[0], rank, world)  # collective: ncclCommInitRank on every rank
+        # every rank takes the same branch: the outcome of the attempt is agreed on before anyone steps
+        ok = 1
+        try:
+            box = [mdl.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            mdl.comm_init(box[0], rank, world)  # collective: ncclCommInitRank on every rank
+        except Exception as exc:  # noqa: BLE001 - report and fall back rather than lose the measurement
+            print(f"[bench] rank {rank}: native RCCL communicator failed ({exc}); host-staged all-reduce instead",
+                  file=sys.stderr, flush=True)
+            ok = 0
+        t = torch.tensor([ok])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            native = False
+            if ok:
+                mdl.comm_destroy()
 
     def step():
         # with a communicator attached the step ends with the all-reduce of `packed`, same stream

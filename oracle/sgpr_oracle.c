@@ -326,10 +326,42 @@ static double det3(const double *h)
            h[2] * (h[3] * h[7] - h[4] * h[6]);
 }
 
-int64_t orc_neighbors(int N, const double *pos, const double *cell, const int *pbc, double rc,
+/* ase.geometry.complete_cell as ASE's neighbour list applies it: a zero cell vector along an OPEN
+ * direction (slab / wire cells such as [a, b, 0] with pbc = TTF) is replaced by a unit vector orthogonal
+ * to the others, for the purpose of measuring heights and fractional coordinates only. */
+static void complete_cell(const double *cell, const int *pbc, double *h)
+{
+    int zero[3], nz = 0;
+    for (int k = 0; k < 9; k++) h[k] = cell[k];
+    for (int k = 0; k < 3; k++) {
+        zero[k] = h[3 * k] * h[3 * k] + h[3 * k + 1] * h[3 * k + 1] + h[3 * k + 2] * h[3 * k + 2] < 1e-24;
+        nz += zero[k];
+    }
+    if (nz == 0 || nz == 3) return;
+    for (int k = 0; k < 3; k++) {
+        if (!zero[k] || pbc[k]) continue;
+        const double *p = h + 3 * ((k + 1) % 3), *q = h + 3 * ((k + 2) % 3);
+        double v[3];
+        if (!zero[(k + 1) % 3] && !zero[(k + 2) % 3]) cross3(p, q, v);
+        else {
+            const double *w = zero[(k + 1) % 3] ? q : p;
+            const int a = fabs(w[0]) <= fabs(w[1]) && fabs(w[0]) <= fabs(w[2]) ? 0 : (fabs(w[1]) <= fabs(w[2]) ? 1 : 2);
+            double e[3] = {0, 0, 0};
+            e[a] = 1.0;
+            cross3(w, e, v);
+        }
+        const double nv = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (nv > 1e-12) { h[3 * k] = v[0] / nv; h[3 * k + 1] = v[1] / nv; h[3 * k + 2] = v[2] / nv; zero[k] = 0; }
+    }
+}
+
+int64_t orc_neighbors(int N, const double *pos, const double *cell_in, const int *pbc, double rc,
                       int64_t *ptr, int32_t *j_out, int32_t *off_out)
 {
     int nmax[3] = {0, 0, 0};
+    double hc[9];
+    complete_cell(cell_in, pbc, hc);
+    const double *cell = hc;  /* heights and fractional coordinates; image shifts use cell_in below */
     const double V = fabs(det3(cell));
     if (V > 1e-12) {
         /* fractional span of the positions (atoms may sit outside the cell) */
@@ -363,7 +395,7 @@ int64_t orc_neighbors(int N, const double *pos, const double *cell, const int *p
                         if (j == i && !o0 && !o1 && !o2) continue;
                         double d[3];
                         for (int a = 0; a < 3; a++)
-                            d[a] = pos[3 * j + a] + (o0 * cell[a] + o1 * cell[3 + a] + o2 * cell[6 + a]) - pos[3 * i + a];
+                            d[a] = pos[3 * j + a] + (o0 * cell_in[a] + o1 * cell_in[3 + a] + o2 * cell_in[6 + a]) - pos[3 * i + a];
                         const double rr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
                         if (rr < rc) {
                             if (j_out) {
@@ -404,10 +436,13 @@ static int nbr_cmp(const void *pa, const void *pb)
 
 static int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-int64_t orc_neighbors_cells(int N, const double *pos, const double *cell, const int *pbc, double rc,
+int64_t orc_neighbors_cells(int N, const double *pos, const double *cell_in, const int *pbc, double rc,
                             int64_t *ptr, int32_t *j_out, int32_t *off_out)
 {
     if (N <= 0) { ptr[0] = 0; return 0; }
+    double hc[9];
+    complete_cell(cell_in, pbc, hc);
+    const double *cell = hc;  /* heights and fractional coordinates; image shifts use cell_in below */
     const double V = fabs(det3(cell));
     double inv[9] = {0};
     double hgt[3] = {0, 0, 0};
@@ -474,7 +509,7 @@ int64_t orc_neighbors_cells(int N, const double *pos, const double *cell, const 
                                 if (j == i && !s0 && !s1 && !s2) continue;
                                 double d[3];
                                 for (int a = 0; a < 3; a++)
-                                    d[a] = pos[3 * j + a] + (s0 * cell[a] + s1 * cell[3 + a] + s2 * cell[6 + a]) - pos[3 * i + a];
+                                    d[a] = pos[3 * j + a] + (s0 * cell_in[a] + s1 * cell_in[3 + a] + s2 * cell_in[6 + a]) - pos[3 * i + a];
                                 const double rr = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
                                 if (rr < rc) {
                                     if (n == cap) { cap *= 2; buf = (nbr_t *)realloc(buf, sizeof(nbr_t) * (size_t)cap); }

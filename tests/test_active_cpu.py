@@ -11,7 +11,7 @@ from autoforce_amd.ase_shim import Atoms
 from autoforce_amd.calculator import ActiveCalculator, Switch
 from autoforce_amd.posterior import Frame, PosteriorPotential
 from autoforce_amd.sgprio import SgprIO
-from helpers import OracleModel, PairTeacher, load
+from helpers import OracleEngine, OracleModel, PairTeacher, load
 
 
 def engine():
@@ -279,6 +279,38 @@ def _al_worker(rank, world, port, tmp, q):
     q.put((rank, [t[0] for t in trace], [t[1] for t in trace], trace[-1][2], calc.model.mu))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_frames_without_stress_labels(tmp_path):
+    """A teacher without stress (clusters, molecules): the frame contributes energy and force rows only,
+    through add / pop / column edits and the model file."""
+    from autoforce_amd.modelio import load_model, save_model
+    g = load("g5_big40")
+    eng = OracleEngine(g)
+    rng = np.random.default_rng(3)
+    N = len(g["numbers"])
+    fr = [Frame(g["numbers"], g["positions"] + 0.02 * k, g["cell"], g["pbc"], float(rng.normal()), rng.normal(size=(N, 3)),
+                None if k == 1 else rng.normal(size=6) * 0.01) for k in range(3)]
+    p = PosteriorPotential(eng)
+    p.Ke, p.Kf, p.Kv = (np.zeros((0, eng.m)),) * 3
+    p.add_data(fr)
+    assert p.Kv.shape == (12, eng.m) and len(p.targets()[2]) == 12 and p.K.shape[0] == len(np.concatenate(p.targets()))
+    x = p.X[3]
+    p.add_inducing(x)
+    assert p.Kv.shape == (12, eng.m) and p.Ke.shape == (3, eng.m)
+    p.pop_1data()       # frame 2 (with stress)
+    assert p.Kv.shape[0] == 6
+    p.pop_1data()       # frame 1 (without)
+    assert p.Kv.shape[0] == 6 and p.ndata == 1
+    p.add_data([fr[1]])
+    path = str(tmp_path / "m.npz")
+    save_model(path, p)
+    q = load_model(path, engine=OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                             species=g["species"].tolist()))
+    assert q.data[1].stress is None and q.Kv.shape == p.Kv.shape
+    np.testing.assert_allclose(q.K, p.K, rtol=0, atol=1e-12)
+    with pytest.raises(ValueError, match="energy and forces"):
+        p.add_data([Frame(g["numbers"], g["positions"], g["cell"], g["pbc"], 1.0, None, None)])
 
 
 def test_acceptance_rules_against_reference():

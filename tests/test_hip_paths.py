@@ -151,6 +151,29 @@ def test_dense_cluster_in_one_bin():
     mdl.close()
 
 
+def test_slab_cell_with_zero_open_vector():
+    """cell = [a, b, 0] with pbc = TTF: the device completes the open direction (ase complete_cell) and keeps
+    the in-plane images; same numbers as with an explicit out-of-plane vector and as the oracle.  A zero
+    vector along a periodic direction is an error."""
+    from autoforce_amd import SgprError
+    rng = np.random.default_rng(7)
+    inplane = np.array([[7.0, 0.3, 0.0], [-0.5, 6.6, 0.0]])
+    cell0 = np.vstack([inplane, np.zeros(3)])
+    cell1 = np.vstack([inplane, [0.0, 0.0, 40.0]])
+    pos = rng.uniform(0, 1, (30, 3)) @ np.vstack([inplane, [0.0, 0.0, 3.0]])
+    numbers = rng.choice([3, 16], 30).astype(np.int32)
+    mdl, X = build(3, 3, 4.0, 6.0, [3, 16], numbers, pos, cell1, [True, True, False], m=8, seed=5)
+    mdl.set_weights(rng.normal(size=8))
+    a = mdl.predict(numbers, pos, cell0, [True, True, False])
+    b = mdl.predict(numbers, pos, cell1, [True, True, False])
+    assert abs(a["energy"] - b["energy"]) <= 1e-12 * max(1.0, abs(b["energy"]))
+    np.testing.assert_allclose(a["forces"], b["forces"], rtol=0, atol=1e-12 * np.abs(b["forces"]).max())
+    assert mdl.neighbors(30)[0][-1] > 30 * 20
+    with pytest.raises(SgprError):
+        mdl.predict(numbers, pos, cell0, [True, True, True])
+    mdl.close()
+
+
 def test_degenerate_inputs():
     from autoforce_amd import SGPRModel, SgprError
     mdl = SGPRModel(3, 3, 4.0, 6.0, species=[14])

@@ -93,8 +93,12 @@ def test_calculator_errors():
     atoms.calc = calc
     with pytest.raises(RuntimeError, match="you forgot to assign a DFT calculator"):
         atoms.get_potential_energy()
-    with pytest.raises(ValueError, match="species"):
+    # no `species` in kernel_kw = the reference's wildcard kernel (table laid out from the frames met): an
+    # empty device model is created, which on a box without a GPU fails loudly (no CPU fallback)
+    from autoforce_amd import SgprError
+    with pytest.raises(SgprError) as e:
         ActiveCalculator(covariance=None, logfile=None)
+    assert e.value.code == -2
 
 
 def _worker(rank, world, port, name, tmp, q):

@@ -166,6 +166,22 @@ def test_neighbors_linked_cells_random(seed):
         np.testing.assert_array_equal(x, y)
 
 
+def test_neighbors_slab_with_zero_open_vector():
+    """cell = [a, b, 0], pbc = TTF (valid in ASE, whose neighbour list completes the cell): the periodic
+    directions keep their images; equal to the same slab with an explicit out-of-plane vector."""
+    rng = np.random.default_rng(7)
+    cell0 = np.array([[4.0, 0.3, 0.0], [-0.5, 3.6, 0.0], [0.0, 0.0, 0.0]])
+    cell1 = cell0.copy()
+    cell1[2] = [0.0, 0.0, 30.0]
+    pos = rng.uniform(0, 1, (20, 3)) @ np.array([[4.0, 0.3, 0.0], [-0.5, 3.6, 0.0], [0.0, 0.0, 2.5]])
+    pbc = [True, True, False]
+    for fn in (orc.neighbors, orc.neighbors_cells):
+        a, b = fn(pos, cell0, pbc, 3.0), fn(pos, cell1, pbc, 3.0)
+        assert a[0][-1] > 20 * 5  # periodic images are there
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
 # ---------------------------------------------------------------- G4/G5/G6: frames
 @pytest.mark.parametrize("name", FRAMES)
 def test_frames(name):
