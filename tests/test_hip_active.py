@@ -89,6 +89,49 @@ def test_edit_entry_points_equal_rebuild(name):
     full.close()
 
 
+@pytest.mark.parametrize("name", ["g5_mixed64", "g5_big40"])
+def test_bordered_cholesky_after_edits(name):
+    """sgpr_add_inducing borders the cached Cholesky factor and its inverse (one row of K_mm, O(m^2)),
+    sgpr_remove_inducing(-1) deletes the row again: the solves that follow must agree with a model that
+    was set up from scratch and refactored (the reference refactors at every edit, gppotential.py:745-791)."""
+    g = load(name)
+    full = model_from_fixture(g)
+    X = list(full.X)
+    m = len(X)
+    rng = np.random.default_rng(5)
+    rows = full.kernel_rows(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    K = np.concatenate([rows[0][None], rows[1], rows[2]])
+    Y = rng.normal(size=len(K))
+    inc = full.scratch()
+    inc.set_inducing(X[:m - 3])
+    inc.solve(K[:, :m - 3], Y)                       # factor cached: the edits below border it
+    for k in range(m - 3, m):
+        inc.add_inducing(X[k])
+        ref = full.scratch()
+        ref.set_inducing(X[:k + 1])
+        mu_i, mu_r = inc.solve(K[:, :k + 1], Y), ref.solve(K[:, :k + 1], Y)
+        assert inc.ridge == ref.ridge
+        np.testing.assert_allclose(inc.choli, ref.choli, rtol=0, atol=1e-9 * np.abs(ref.choli).max())
+        pred_i, pred_r = K[:, :k + 1] @ mu_i, K[:, :k + 1] @ mu_r
+        np.testing.assert_allclose(pred_i, pred_r, rtol=0, atol=1e-8 * np.abs(pred_r).max())
+        ref.close()
+    inc.remove_inducing(-1)
+    ref = full.scratch()
+    ref.set_inducing(X[:m - 1])
+    inc.solve(K[:, :m - 1], Y); ref.solve(K[:, :m - 1], Y)
+    np.testing.assert_allclose(inc.choli, ref.choli, rtol=0, atol=1e-9 * np.abs(ref.choli).max())
+    np.testing.assert_array_equal(inc.M, ref.M)
+    # and the evaluator built on the edited model predicts like the one built from scratch
+    for mdl in (inc, ref):
+        mdl.set_weights(mdl.mu, choli=mdl.choli, vscale=mdl.make_vscale())
+    a = inc.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    b = ref.predict(g["numbers"], g["positions"], g["cell"], g["pbc"])
+    assert abs(a["energy"] - b["energy"]) <= 1e-8 * max(1.0, abs(b["energy"]))
+    np.testing.assert_allclose(a["forces"], b["forces"], rtol=0, atol=1e-8 * np.abs(b["forces"]).max())
+    np.testing.assert_allclose(a["beta"], b["beta"], rtol=0, atol=1e-6)
+    inc.close(); ref.close(); full.close()
+
+
 def test_learning_loop_matches_oracle_engine(tmp_path):
     """Same scenario, same host logic, two engines: the HIP library and the CPU oracle.  The
     sampled sets must coincide step by step and the predictions agree to solver precision."""
