@@ -117,6 +117,7 @@ struct sgpr_model {
     DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
+    DevBuf<double> d_edit_tmp;  // scratch of the incremental inducing-set edits
     bool chol_valid = false, r1_valid = false;
     double chol_ridge = 0.0, chol_dmean = 0.0;
     // per-step work arrays (local rows)
@@ -432,7 +433,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
                             &h->d_vs_sqrt, &h->d_gpart, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed,
-                            &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1};
+                            &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1, &h->d_edit_tmp};
     for (auto b : db) b->release();
     h->d_pack.release();
     h->d_T.release();
