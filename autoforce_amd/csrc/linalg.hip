@@ -444,7 +444,10 @@ size_t lstsq_qr_blocked_work_doubles(int rows, int cols)
     return 2 * QNB * ldr + 3 * QNB * QNB + 2 * QNB + 8 + QNB * cpad + cpad * QNB + (size_t)cols * cols + cols + 64;
 }
 
-int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st)
+// band > 0: column c is known to be zero below row band * (c + 1) (the stacked triangular system of the second
+// solve stage, rows interleaved: band = 2).  A panel of columns [k0, k0 + nb) then lives in rows < band (k0 + nb):
+// its reflectors, the products with them and the trailing update are restricted to those rows.
+int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band)
 {
     if (cols > 2048 || rows < cols || ldr % 64 || ldr < rows) return -1;
     const int cpad = (cols + 1 + 63) / 64 * 64 + 64;
@@ -474,17 +477,22 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
     if (lds_panels)
         (void)hipFuncSetAttribute((const void *)qr_panel_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   rows * PNB * (int)sizeof(double));
+    auto rows_of_panel = [&](int k0) {  // rows the panel at k0 can touch
+        const int nbp = std::min(PNB, cols - k0);
+        return band > 0 ? std::min(rows, band * (k0 + nbp)) : rows;
+    };
     for (int k0 = 0; k0 < cols; k0 += PNB) {
         const int ntrail = cols + 1 - (k0 + std::min(PNB, cols - k0));
+        const int rlim = band > 0 ? std::min(ldr, (rows_of_panel(k0) + 63) / 64 * 64) : ldr;
         Span sp = {tiles.size(), 0, 0, 0};
         if (ntrail > 0) {
             const int ctl = (ntrail + 63) / 64;
             const int kb0 = k0 / 32 * 32;
-            for (int kb = kb0; kb < ldr; kb += KSPLIT)
-                for (int ct = 0; ct < ctl; ct++) tiles.push_back(make_int4(0, ct, kb, std::min(ldr, kb + KSPLIT)));
+            for (int kb = kb0; kb < rlim; kb += KSPLIT)
+                for (int ct = 0; ct < ctl; ct++) tiles.push_back(make_int4(0, ct, kb, std::min(rlim, kb + KSPLIT)));
             sp.wn = tiles.size() - sp.w0;
             sp.u0 = tiles.size();
-            for (int ct = k0 / 64; ct < ldr / 64; ct++)
+            for (int ct = k0 / 64; ct < rlim / 64; ct++)
                 for (int rt = 0; rt < ctl; rt++) tiles.push_back(make_int4(rt, ct, 0, QNB));
             sp.un = tiles.size() - sp.u0;
         }
@@ -499,12 +507,13 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
     for (int k0 = 0; k0 < cols; k0 += PNB, pi++) {
         q.k0 = k0;
         q.nb = std::min(PNB, cols - k0);
+        q.rows = rows_of_panel(k0);
         (void)hipMemsetAsync(q.Vt, 0, sizeof(double) * 2 * (size_t)QNB * ldr, st);  // Vt and Vrm
         (void)hipMemsetAsync(q.G, 0, sizeof(double) * (2 * QNB * QNB + 2 * QNB + 8), st);  // G, T, scal, nrm2
         if (lds_panels) {
-            hipLaunchKernelGGL(qr_panel_lds_kernel, dim3(1), dim3(1024), (size_t)(rows - k0) * PNB * sizeof(double), st, q);
+            hipLaunchKernelGGL(qr_panel_lds_kernel, dim3(1), dim3(1024), (size_t)(q.rows - k0) * PNB * sizeof(double), st, q);
         } else {
-            const int nwg0 = (rows - k0 + QCH - 1) / QCH;
+            const int nwg0 = (q.rows - k0 + QCH - 1) / QCH;
             hipLaunchKernelGGL(qr_colnorm_kernel, dim3(nwg0), dim3(256), 0, st, q, 0);
             for (int j = 0; j < q.nb; j++) {
                 const int nwg = (ldr - (k0 + j) + QCH - 1) / QCH;

@@ -168,7 +168,7 @@ void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, 
 // panels of 32 reflectors, compact-WY trailing updates on the MFMA GEMM.  At is overwritten.
 size_t lstsq_qr_blocked_work_doubles(int rows, int cols);
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /*[cols] or NULL: factor only*/,
-                            double *work, hipStream_t st);
+                            double *work, hipStream_t st, int band = 0 /*> 0: column c is zero below row band (c + 1)*/);
 // R (row-major [cols][cols], upper) and z = (Q^T y)[0:cols] out of a factored At
 void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st);
 
