@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic_*.json from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE):
-median per-launch bytes per kernel.  usage: pmc_json.py <fetch.csv> <write.csv> <out.json>"""
+"""profiles/rNN_pmc_traffic_*.json from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE):
+median per-launch bytes per kernel.  usage: pmc_json.py <fetch.csv> <write.csv> <out.json> [source note]"""
 import csv, json, statistics as st, sys
 from collections import defaultdict
 
-STAGE = [("nl_bin_kernel", "neighbor_bin"), ("nl_build_kernel", "neighbor_build"), ("desc_fwd_kernel", "descriptor_fwd"),
+STAGE = [("nl_bin_kernel", "neighbor_bin"), ("nl_fwd_kernel", "list_forward"), ("desc_rev_kernel", "descriptor_rev"),
+         ("finalize_gather_kernel", "finalize"),
+         ("nl_build_kernel", "neighbor_build"), ("desc_fwd_kernel", "descriptor_fwd"),
          ("gemm_nt_kernel<1", "gemm_knm"), ("gemm_nt_kernel<(GemmEpilogue)1", "gemm_knm"),
          ("gemm_nt_kernel<4", "gemm_w_covloss"), ("gemm_nt_kernel<(GemmEpilogue)4", "gemm_w_covloss"),
          ("desc_dc_kernel", "descriptor_dc"), ("desc_pair_kernel", "descriptor_pair"), ("finalize_kernel", "finalize")]
@@ -26,6 +28,7 @@ def medians(path, counter):
 fetch, write = medians(sys.argv[1], "FETCH_SIZE"), medians(sys.argv[2], "WRITE_SIZE")
 out = {
     "workload": "LiPS 4096 atoms / 512 inducing, 1 GPU",
+    "source": sys.argv[4] if len(sys.argv) > 4 else "builder run",
     "unit": "bytes per launch",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc.sh), median over the "
               "launches of the run; counters are in KiB; fetch_x2 applies the gfx950 correction of MI355X_MICROARCH.md "
