@@ -111,6 +111,15 @@ struct sgpr_model {
     DevBuf<int> d_kslot, d_aux;
     DevBuf<unsigned short> d_T;
     int t_stride = 0;
+    // Verlet candidates (lists of |r| < rc + skin, rebuilt on the device when needed; descriptor.hip)
+    double skin = 0.5;          // Angstrom; 0: rebuild every step (option "skin_milliangstrom")
+    bool lists_valid = false;   // false: the next step is told to rebuild (new frame, capacity change)
+    unsigned step_count = 0;
+    DevBuf<int> d_flag, d_ncand, d_cand_j, d_cand_code, d_cidx;
+    DevBuf<double> d_pos0, d_cell0;
+    DevBuf<unsigned long long> d_hm;
+    int hmw = 1;
+    const int *step_flag = nullptr;  // the rebuild flag of the step being enqueued
     bool gather_ok = true;   // false: bin capacity / list length beyond the reverse-index format -> scatter form
     DevBuf<double> d_prec, d_G;
     DevBuf<double> d_gpart;
@@ -178,6 +187,10 @@ struct FinArgs {
     double mean_energy;
     double *packed;
     int *stat, *bin_count;
+    const int *flag;            // this step's rebuild flag: set -> the candidates were rebuilt from `pos`
+    int *rebuilds;              // running count of rebuilds
+    const double *pos;          // [N][3] sorted order
+    double *pos0;               // [N][3] positions the candidate lists were built at
 };
 
 // reducer workgroup q: E (0), the nine virial components (1..9), the largest neighbour count (10)
@@ -203,6 +216,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
     __syncthreads();
     if (tid == 0) {
         if (q == 10) {
+            if (*f.flag) atomicAdd(f.rebuilds, 1);
             const int mx = (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3]));
             f.stat[0] = max(f.stat[0], mx);  // sticky
             // packed[4N+10]: 1 when this rank's step overflowed a capacity (its results are invalid); summed
@@ -222,6 +236,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
     for (int k = i; k < 4096; k += nA * blockDim.x) f.bin_count[k] = 0;
     if (i < f.N) {
         const int c = f.perm[i];
+        if (*f.flag) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) f.pos0[3 * i + k] = f.pos[3 * i + k];
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) f.packed[3 * c + k] = f.Fnbr[3 * i + k] + f.Fself[3 * i + k];
         double bt = 0.0;
@@ -266,6 +284,7 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
         fz += __shfl_xor(fz, o, 64);
     }
     if (lane < 3) f.packed[3 * (size_t)c + lane] = fs - (lane == 0 ? fx : lane == 1 ? fy : fz);
+    if (lane < 3 && *f.flag) f.pos0[3 * (size_t)i + lane] = f.pos[3 * (size_t)i + lane];
     if (lane == 3) {
         const double v = 1.0 - cs;
         f.packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
@@ -373,6 +392,8 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_stat.alloc(4);
     h->d_bin_count.alloc(4096);
     h->d_cell_in.alloc(9);
+    h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds
+    h->d_cell0.alloc(9);
     if (getenv("SGPR_STAMPS")) h->d_stamps.alloc(4 * 4096);
     *out = h;
     return SGPR_OK;
@@ -428,7 +449,8 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     for (auto e : h->ev) (void)hipEventDestroy(e);
     DevBuf<int> *ib[] = {&h->d_ind_slot, &h->d_ind_nn, &h->d_qoff, &h->d_perm, &h->d_slot, &h->d_aoff, &h->d_lslot,
                          &h->d_lnn, &h->d_bin_of, &h->d_bin_count, &h->d_nn_raw, &h->d_nn,
-                         &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear, &h->d_kslot, &h->d_aux};
+                         &h->d_nbr_j, &h->d_nbr_shift, &h->d_stat, &h->d_shear, &h->d_kslot, &h->d_aux,
+                         &h->d_flag, &h->d_ncand, &h->d_cand_j, &h->d_cand_code, &h->d_cidx};
     for (auto b : ib) b->release();
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
                             &h->d_vs_sqrt, &h->d_gpart, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
@@ -437,6 +459,9 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     for (auto b : db) b->release();
     h->d_pack.release();
     h->d_T.release();
+    h->d_hm.release();
+    h->d_pos0.release();
+    h->d_cell0.release();
     h->d_b_rec.release();
     h->d_b_aux.release();
     h->d_grid.release();
@@ -765,6 +790,12 @@ static int ensure_nl(sgpr_model *h, int maxnn)
     bad |= h->d_aux.alloc((size_t)h->N * maxnn, false);
     bad |= h->d_prec.alloc((size_t)h->N * maxnn * 4, false);
     bad |= h->d_G.alloc((size_t)h->N * maxnn * 4, false);
+    bad |= h->d_cand_j.alloc((size_t)h->N * maxnn, false);
+    bad |= h->d_cand_code.alloc((size_t)h->N * maxnn, false);
+    bad |= h->d_cidx.alloc((size_t)h->N * maxnn, false);
+    h->hmw = (maxnn + 63) / 64;
+    bad |= h->d_hm.alloc((size_t)h->N * h->hmw);
+    h->lists_valid = false;
     return bad ? fail(SGPR_E_NODEVICE, "hipMalloc failed (neighbour list, maxnn=%d)", maxnn) : 0;
 }
 
@@ -773,6 +804,7 @@ static int ensure_rev(sgpr_model *h, int stride)
 {
     if (stride <= h->t_stride && h->d_T.p) return 0;
     h->t_stride = stride;
+    h->lists_valid = false;
     drop_graph(h);
     if (h->d_T.alloc((size_t)std::max(h->N, 1) * stride, false))
         return fail(SGPR_E_NODEVICE, "hipMalloc failed (reverse index, %d entries per atom)", stride);
@@ -783,6 +815,7 @@ static int ensure_bins(sgpr_model *h, int cap)
 {
     if (cap <= h->bin_cap && h->d_b_rec.p) return 0;
     h->bin_cap = cap;
+    h->lists_valid = false;
     drop_graph(h);
     const size_t slots = (size_t)4096 * cap;
     int bad = 0;
@@ -841,6 +874,9 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_pos.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_bin_of.alloc(std::max(N, 1));
     bad |= h->d_kslot.alloc(std::max(N, 1));
+    bad |= h->d_ncand.alloc(std::max(N, 1));
+    bad |= h->d_pos0.alloc((size_t)3 * std::max(N, 1));
+    h->lists_valid = false;
     bad |= h->d_nn_raw.alloc(h->cnt_rows);
     bad |= h->d_nn.alloc(std::max(N, 1));
     bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
@@ -896,6 +932,8 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
     f.nn_raw = h->d_nn_raw.p; f.T = h->d_T.p; f.G = h->d_G.p; f.Fnbr = h->d_F.p; f.Fself = h->d_F.p + 3 * (size_t)N;
     f.csq = h->d_csq.p; f.vs_sqrt = h->d_vs_sqrt.p; f.Epart = h->d_Epart.p; f.virpart = h->d_virpart.p;
     f.mean_energy = mean_energy; f.packed = packed_dev; f.stat = h->d_stat.p; f.bin_count = h->d_bin_count.p;
+    f.flag = h->step_flag ? h->step_flag : h->d_flag.p; f.pos = h->d_pos.p; f.pos0 = h->d_pos0.p;
+    f.rebuilds = h->d_flag.p + 2;
     if (gather)
         hipLaunchKernelGGL(finalize_gather_kernel, dim3((std::max(N, 1) + 3) / 4 + 11), dim3(256), 0, st, f);
     else
@@ -926,7 +964,16 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     NlScratch sc = {(NlGrid *)h->d_grid.p, h->d_bin_of.p, h->d_kslot.p, h->d_bin_count.p, h->bin_cap, h->d_b_rec.p,
                     h->d_b_aux.p, h->d_slot.p, h->d_stat.p, h->d_nn_raw.p, h->d_aux.p, gather ? h->d_T.p : nullptr,
                     h->t_stride};
-    launch_neighbor_bin(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc, sc, h->d_F.p, 3 * N, h->d_csq.p, cnt, st);
+    // candidate lists: reused while nobody moved more than skin/2 (decided on the device, neighbor.hip); a
+    // captured graph cannot alternate the flag parity, so it rebuilds every step
+    const double skin = h->use_graph ? 0.0 : h->skin;
+    sc.flag = h->d_flag.p; sc.parity = (int)(h->step_count++ & 1u);
+    sc.force = (!h->lists_valid || skin <= 0.0) ? 1 : 0;
+    sc.skin = skin; sc.pos0 = h->d_pos0.p; sc.cell0 = h->d_cell0.p; sc.ncand = h->d_ncand.p; sc.cand_j = h->d_cand_j.p;
+    sc.cand_code = h->d_cand_code.p; sc.cidx = h->d_cidx.p; sc.hm = h->d_hm.p; sc.hmw = h->hmw;
+    h->step_flag = h->d_flag.p + sc.parity;
+    launch_neighbor_bin(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc + skin, sc, h->d_F.p, 3 * N, h->d_csq.p, cnt,
+                        st);
     stamp(h, "neighbor_bin", st);
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
@@ -982,7 +1029,8 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p, h->d_nbr_j.p,
                                          h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p,
                                          h->d_W.p, h->d_prec.p, gather ? h->d_G.p : nullptr, h->d_aux.p,
-                                         h->d_T.p, h->t_stride, h->d_F.p, h->d_virpart.p, st);
+                                         h->d_T.p, h->t_stride, h->d_cidx.p, h->d_hm.p, h->hmw, h->d_F.p, h->d_virpart.p,
+                                         st);
         if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
         stamp(h, "descriptor_rev", st);
     }
@@ -1046,8 +1094,10 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         if (stat[0] <= h->maxnn) {
             h->nn_max_seen = stat[0];
             HIPCHK(hipMemset(h->d_stat.p, 0, 4 * sizeof(int)));
+            h->lists_valid = true;  // candidates complete: later steps rebuild them only when atoms have moved
             return SGPR_OK;
         }
+        h->lists_valid = false;
         if (stat[0] > 100000) return fail(SGPR_E_OVERFLOW, "neighbour count %d is unreasonable", stat[0]);
         const int rc2 = ensure_nl(h, rup(stat[0] + stat[0] / 8 + 4, 8));
         if (rc2) return rc2;
@@ -1260,6 +1310,12 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "skin_milliangstrom")) {
+        if (value < 0) return fail(SGPR_E_INVALID, "sgpr_set_option: negative skin");
+        h->skin = 1e-3 * value;
+        h->lists_valid = false;
+        return SGPR_OK;
+    }
     return fail(SGPR_E_INVALID, "sgpr_set_option: unknown option %s", name);
 }
 
@@ -1368,6 +1424,17 @@ extern "C" int sgpr_get_dims(sgpr_model *h, int32_t *out)
     if (!h || !out) return fail(SGPR_E_INVALID, "sgpr_get_dims: bad arguments");
     out[0] = h->m; out[1] = h->S; out[2] = h->D; out[3] = h->Dc; out[4] = h->maxnn; out[5] = h->N;
     out[6] = h->nn_max_seen; out[7] = h->Dpad;
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_get_list_rebuilds(sgpr_model *h, int64_t *count)
+{
+    if (!h || !count) return fail(SGPR_E_INVALID, "sgpr_get_list_rebuilds: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int c = 0;
+    HIPCHK(hipMemcpy(&c, h->d_flag.p + 2, sizeof(int), hipMemcpyDeviceToHost));
+    *count = c;
     return SGPR_OK;
 }
 

@@ -184,9 +184,12 @@ struct DescArgs {
     long long *stamps;      // diagnostic build (-DSGPR_PHASE_STAMPS) only: [N][8] s_memtime per phase
     double *prec;           // [Nall][maxnn][4] pair records (r_x, r_y, r_z, exp(-d^2/2)): forward -> reverse pass
     double *G;              // reverse pass, gather form: [Nall][maxnn][4]: G[j][rev] = gradient of the pair (i -> j)
-    const int *aux;         // [Nall][maxnn] candidate id of each list entry   } reverse index of the list build:
-    const unsigned short *T; // [Nall][t_stride]                               } rev = T[i][aux[i][t]]
-    int t_stride;
+    const int *aux;         // [Nall][maxnn] bin-sweep id of each CANDIDATE    } reverse index of the candidate build:
+    const unsigned short *T; // [Nall][t_stride]                               } T[i][aux[i][c]] = position of i among
+    int t_stride;           //                                                   the candidates of its candidate c
+    const int *cidx;        // [Nall][maxnn] candidate position of each list entry of this step
+    const unsigned long long *hm;  // [Nall][hmw] this step's hit mask over the candidates
+    int hmw;
     int rsz;                // reverse pass: doubles of the per-wave scratch region
     int *shear;             // [N]
     const double *W;        // backward: [N][Dpad]
@@ -472,21 +475,24 @@ __global__ __launch_bounds__(256) void desc_fwd_kernel(DescArgs a)
 // =========================================================================== list build + forward
 // One wave64 per atom i (reference: ase NeighborList as driven by descriptor/atoms.py:348-363,:402, then
 // descriptor/sesoap.py:161-260).
-//  sweep   the (2R+1)^3 neighbouring bins, FOUR bins x 16 slots per step (lane = bin of the group, slot):
-//          bin index and population need no search, and the eight steps of a 32-bin chunk issue their
-//          loads back to back (one 32-B + one 8-B record per candidate).  Hits are compacted into LDS
-//          by ballot/popcount and SORTED by (j, image): the placement order inside a bin comes from
-//          atomics and is not reproducible, the sorted list is.  Up to 64 keys sort in registers.
-//  list    neighbour index, image/species code, and the reverse index for the reverse pass: atom i found
-//          j as candidate (q, k) = (bin offset index, slot in that bin); j finds i under the mirrored
-//          offset nbox-1-q at i's own slot.  So i writes its list position t into T[j][(nbox-1-q)*cap+k_i]
-//          and keeps aux[i][t] = q*cap + k_j: later rev = T[i][aux[i][t]] is the position of i in the
-//          list of its t-th neighbour — one scattered 2-byte store per pair, no search.
+//  candidates (only when the rebuild flag of this step is set — an atom moved more than skin/2 since the
+//          last build, the cell changed, or the frame is new; neighbor.hip decides): sweep of the
+//          (2R+1)^3 neighbouring bins for |r| < rc + skin, FOUR bins x 16 slots per step (lane = bin of the
+//          group, slot), bins beyond reach dropped; hits compacted into LDS and SORTED by (j, image): the
+//          placement order inside a bin comes from atomics and is not reproducible, the sorted list is.
+//          Written once per build: the candidate list and the reverse-index ingredients — atom i found j as
+//          candidate (q, k) = (bin offset index, slot in that bin); j finds i under the mirrored offset
+//          nbox-1-q at i's own slot, so i writes its candidate position c into T[j][(nbox-1-q)*cap + k_i]
+//          and keeps aux[i][c] = q*cap + k_j: T[i][aux[i][c]] is the position of i among j's candidates.
+//  list    every step: one pass over the ~51 candidates (lane = candidate): displacement from the current
+//          positions, |r| < rc, ballot compaction — a subsequence of a sorted sequence, so the list has
+//          exactly the pairs AND the order of a from-scratch build.  The hit mask hm[i] lets the reverse
+//          pass turn a candidate position into a list position by a popcount.
 //  forward lane = neighbour (tiles of 48): radial weights, solid harmonics, staged in LDS;
 //          c[lm][(s,n)] += sum_t Y[t][lm] f[t][n] [s_t = s] on v_mfma_f64_16x16x4 (K = four neighbours);
 //          power spectrum with one lane per (u,v) pair; norm in-wave.  The displacement and exp(-d^2/2)
 //          of every pair are left in `prec` for the reverse pass.
-#define NL_SORT_MAX 256  // lists up to this length are sorted (longer ones keep sweep order beyond it)
+#define NL_SORT_MAX 256  // candidate lists up to this length are sorted (longer ones keep sweep order beyond it)
 #ifndef NL_STEPS
 #define NL_STEPS 4
 #endif
@@ -501,6 +507,12 @@ struct NlArgs {
     unsigned short *T;
     int t_stride;
     int *stat;
+    // Verlet candidates
+    const int *flag;       // this step's rebuild flag (neighbor.hip)
+    double rc_list;        // rc + skin
+    int *ncand, *cand_j, *cand_code, *cidx;   // [N], [N][maxnn] x2, per-step list entry -> candidate position
+    unsigned long long *hm;                   // [N][hmw] hit mask over the candidates
+    int hmw;
 };
 
 #ifdef SGPR_PHASE_STAMPS
@@ -513,11 +525,13 @@ template <int LMAX, int NMAX, int ST>
 struct FwdLds {
     using WL = WaveLds<LMAX, NMAX>;
     static constexpr int CH = WL::CH;
-    static constexpr int NLV = NL_SORT_MAX + NL_SORT_MAX / 2 + 3 * 64;           // keys | candidate ids | first 64 displacements
+    // list-build view of the shared region: keys | candidate ids | bins worth visiting | hits of the first tile
+    static constexpr int BINL = NL_SORT_MAX + NL_SORT_MAX / 2, HIT0 = BINL + 2 * 64;
+    static constexpr int NLV = HIT0 + 4 * CH;
     static constexpr int FWV = CH * WL::N1 + CH * WL::LLP + CH / 2;              // radial rows | harmonic rows | species
     static constexpr int P4V = ST * WL::NSLOT;                                   // c for the power spectrum
     static constexpr int RA = (NLV > FWV ? (NLV > P4V ? NLV : P4V) : (FWV > P4V ? FWV : P4V));
-    static constexpr int PW = CH + RA;  // + the keys of the second tile
+    static constexpr int PW = 4 * CH + RA;  // + the hits of the second tile
 };
 
 template <int LMAX, int NMAX, int ST>
@@ -533,229 +547,296 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     if (ia >= a.N) return;  // (no workgroup barrier in this kernel)
     const int i = a.first + ia * a.stride;
     double *wbase = smem + (size_t)wave * FL::PW;
-    unsigned long long *k2 = (unsigned long long *)wbase;          // [CH] sorted keys of the second tile
-    double *RA = wbase + CH;
+    double *hit1 = wbase;                                          // [CH][4] hits of the second tile (r, species)
+    double *RA = wbase + 4 * CH;
     unsigned long long *keys = (unsigned long long *)RA;           // [NL_SORT_MAX]   } list build view
     int *hq = (int *)(RA + NL_SORT_MAX);                           // [NL_SORT_MAX]   }
-    double *rl = RA + NL_SORT_MAX + NL_SORT_MAX / 2;               // [64][3]         }
+    int4 *binl = (int4 *)(RA + FL::BINL);                          // [64]            }
+    double *hit0 = RA + FL::HIT0;                                  // [CH][4]         }
     double *fl = RA;                                               // [CH][N1]        } forward view
     double *Yl = fl + CH * N1;                                     // [CH][LLP]       }
     int *sl = (int *)(Yl + CH * LLP);                              // [CH]            }
     double *cl = RA;                                               // [ST][NSLOT]       power-spectrum view
 
     PHASE_STAMP(0);
-    // ------------------------------------------------------------------ sweep
-    const NlGrid g = *n.grid;
     const int cap = n.cap, maxnn = a.maxnn;
     double h[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) h[k] = a.cell[k];
     const double xi = uniform(a.pos[3 * (size_t)i]), yi = uniform(a.pos[3 * (size_t)i + 1]), zi = uniform(a.pos[3 * (size_t)i + 2]);
-    const int bi = __builtin_amdgcn_readfirstlane(n.bin_of[i]), ki = __builtin_amdgcn_readfirstlane(n.kslot[i]);
-    int wi0 = 0, wi1 = 0, wi2 = 0;
+    const int ki = __builtin_amdgcn_readfirstlane(n.kslot[i]);
     const bool ghost = ki < 0;  // species outside the model's table (option "ignore_unknown_species"): no environment
-    if (ki >= 0 && ki < cap) {  // (ki >= cap: the bin overflowed, the host grows it and reruns the step)
-        const BinAux own = n.b_aux[(size_t)bi * cap + ki];
-        wi0 = own.w0; wi1 = own.w1; wi2 = own.w2;
-    }
-    // index arithmetic without integer division (a ~30-instruction sequence each on this ISA): small
-    // non-negative operands, so floor((q + 1/2) * (1/w)) in fp32 is exact
-    auto fdiv = [](int q, float inv) { return (int)(((float)q + 0.5f) * inv); };
-    const float i_n2 = 1.0f / (float)g.nb[2], i_n1 = 1.0f / (float)g.nb[1];
-    const int bq = fdiv(bi, i_n2);
-    const int b2 = bi - bq * g.nb[2];
-    const int b0 = fdiv(bq, i_n1);
-    const int b1 = bq - b0 * g.nb[1];
-    const int w0 = 2 * g.rng[0] + 1, w1 = 2 * g.rng[1] + 1, w2 = 2 * g.rng[2] + 1;
-    const float i_w2 = 1.0f / (float)w2, i_w1 = 1.0f / (float)w1;
-    const double r_n0 = 1.0 / g.nb[0], r_n1 = 1.0 / g.nb[1], r_n2 = 1.0 / g.nb[2];
-    const int nbox = w0 * w1 * w2;
-    // reverse-index table: row stride nbox*cap entries; a smaller allocation is reported (sticky) and
-    // the host grows it and reruns, like the other capacities
-    const bool t_ok = n.T != nullptr && (long long)nbox * cap <= (long long)n.t_stride && cap <= 4096 && maxnn <= 65535 &&
-                      ki < cap && !ghost;
-    if (n.T != nullptr && !t_ok && ki < cap && !ghost && lane == 0)
-        atomicMax(&n.stat[2], cap <= 4096 && maxnn <= 65535 ? nbox * cap : 0x7fffffff);
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    const int grp = lane >> 4, s16 = lane & 15;
-    const double rc2_lo = a.rc * a.rc * (1.0 - 1e-14), rc2_hi = a.rc * a.rc * (1.0 + 1e-14);
-    int base = 0;
-    bool near = false;
-    // one candidate per lane: distance test, compaction, key
-    auto consume = [&](bool valid, const BinRec &rec, const BinAux &ax, int code, int q, int k) {
-        bool hit = false;
-        int f0 = 0, f1 = 0, f2 = 0;
-        double dx = 0.0, dy = 0.0, dz = 0.0;
-        if (valid) {
-            f0 = (int)(int8_t)(code & 0xff) - ax.w0 + wi0;
-            f1 = (int)(int8_t)((code >> 8) & 0xff) - ax.w1 + wi1;
-            f2 = (int)(int8_t)((code >> 16) & 0xff) - ax.w2 + wi2;
-            dx = rec.x - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
-            dy = rec.y - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
-            dz = rec.z - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
-            // |r| < rc on the squared distance; only within a few ulp of the cutoff the square root decides
-            // (the pair rule of the reference list is on |r| itself)
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            bool in = d2 < rc2_lo;
-            if (!in && d2 < rc2_hi) in = sqrt(d2) < a.rc;
-            hit = in && !(rec.idx == i && f0 == 0 && f1 == 0 && f2 == 0);
+    const bool rebuild = __builtin_amdgcn_readfirstlane(*n.flag) != 0;
+    int ncand = 0;
+    if (rebuild) {
+        // -------------------------------------------------------------- candidates: sweep + sort
+        const NlGrid g = *n.grid;
+        const int bi = __builtin_amdgcn_readfirstlane(n.bin_of[i]);
+        int wi0 = 0, wi1 = 0, wi2 = 0;
+        if (ki >= 0 && ki < cap) {  // (ki >= cap: the bin overflowed, the host grows it and reruns the step)
+            const BinAux own = n.b_aux[(size_t)bi * cap + ki];
+            wi0 = own.w0; wi1 = own.w1; wi2 = own.w2;
         }
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const int slot = base + __popcll(m & lt);
-            const int j = rec.idx, sj = ax.slot;
-            // key: neighbour index (24 bits), the image triple biased to sort as unsigned (24), species
-            // slot (4), sweep ordinal (12: finds candidate id and displacement again after the sort)
-            const unsigned img = (unsigned)((f0 + 128) & 0xff) << 16 | (unsigned)((f1 + 128) & 0xff) << 8 |
-                                 (unsigned)((f2 + 128) & 0xff);
-            const unsigned long long key = ((unsigned long long)(unsigned)j << 40) | ((unsigned long long)img << 16) |
-                                           ((unsigned long long)(unsigned)sj << 12) | (unsigned)(slot & 0xfff);
-            if (max(max(abs(f0), abs(f1)), abs(f2)) > 127) atomicMax(&n.stat[3], 1);  // image shift beyond the packed code
-            if (slot < NL_SORT_MAX) {
-                keys[slot] = key;
-                hq[slot] = (q << 12) | k;
-                if (slot < 64) { rl[3 * slot] = dx; rl[3 * slot + 1] = dy; rl[3 * slot + 2] = dz; }
-            } else if (slot < maxnn) {  // very long lists: keep sweep order beyond the sortable part
-                const size_t e = (size_t)i * maxnn + slot;
-                n.nbr_j[e] = j;
-                n.nbr_shift[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
-                n.aux[e] = 0;
-                if (t_ok) {
-                    n.aux[e] = q * cap + k;
-                    n.T[(size_t)j * n.t_stride + (size_t)(nbox - 1 - q) * cap + ki] = (unsigned short)slot;
-                }
+        // index arithmetic without integer division (a ~30-instruction sequence each on this ISA): small
+        // non-negative operands, so floor((q + 1/2) * (1/w)) in fp32 is exact
+        auto fdiv = [](int q, float inv) { return (int)(((float)q + 0.5f) * inv); };
+        const float i_n2 = 1.0f / (float)g.nb[2], i_n1 = 1.0f / (float)g.nb[1];
+        const int bq = fdiv(bi, i_n2);
+        const int b2 = bi - bq * g.nb[2];
+        const int b0 = fdiv(bq, i_n1);
+        const int b1 = bq - b0 * g.nb[1];
+        const int w0 = 2 * g.rng[0] + 1, w1 = 2 * g.rng[1] + 1, w2 = 2 * g.rng[2] + 1;
+        const float i_w2 = 1.0f / (float)w2, i_w1 = 1.0f / (float)w1;
+        const double r_n0 = 1.0 / g.nb[0], r_n1 = 1.0 / g.nb[1], r_n2 = 1.0 / g.nb[2];
+        const int nbox = w0 * w1 * w2;
+        // reverse-index table: row stride nbox*cap entries; a smaller allocation is reported (sticky) and
+        // the host grows it and reruns, like the other capacities
+        const bool t_ok = n.T != nullptr && (long long)nbox * cap <= (long long)n.t_stride && cap <= 4096 && maxnn <= 65535 &&
+                          ki < cap && !ghost;
+        if (n.T != nullptr && !t_ok && ki < cap && !ghost && lane == 0)
+            atomicMax(&n.stat[2], cap <= 4096 && maxnn <= 65535 ? nbox * cap : 0x7fffffff);
+        const int grp = lane >> 4, s16 = lane & 15;
+        const double rl2 = n.rc_list * n.rc_list;
+        int base = 0;
+        // one candidate per lane: distance test, compaction, key
+        auto consume = [&](bool valid, const BinRec &rec, const BinAux &ax, int code, int q, int k) {
+            bool hit = false;
+            int f0 = 0, f1 = 0, f2 = 0;
+            if (valid) {
+                f0 = (int)(int8_t)(code & 0xff) - ax.w0 + wi0;
+                f1 = (int)(int8_t)((code >> 8) & 0xff) - ax.w1 + wi1;
+                f2 = (int)(int8_t)((code >> 16) & 0xff) - ax.w2 + wi2;
+                const double dx = rec.x - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
+                const double dy = rec.y - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
+                const double dz = rec.z - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
+                hit = dx * dx + dy * dy + dz * dz < rl2 && !(rec.idx == i && f0 == 0 && f1 == 0 && f2 == 0);
             }
-            // does the neighbour sit inside the z cone? (ylm.py:10-23: then the whole environment shears)
-            // (the length unit scales all three components alike)
-            const double tol = SGPR_TINY_ANGLE * fabs(dz);
-            near |= (fabs(dx) < tol) && (fabs(dy) < tol);
-        }
-        base += __popcll(m);
-    };
-    constexpr int STEPS = NL_STEPS;  // steps (of four bins) whose loads are requested together
-    for (int q0 = 0; q0 < (ghost ? 0 : nbox); q0 += 64) {
-        // lane = neighbouring bin: index, image code and population of up to 64 bins with one load
-        int nbin_l = 0, code_l = 0, cnt_l = 0;
-        {
-            const int q = q0 + lane;
-            if (q < nbox) {
-                const int qa = fdiv(q, i_w2), qb = fdiv(qa, i_w1);
-                const int o2 = q - qa * w2 - g.rng[2], o1 = qa - qb * w1 - g.rng[1], o0 = qb - g.rng[0];
-                const int t0 = b0 + o0, t1 = b1 + o1, t2 = b2 + o2;
-                const int c0 = (int)floor((double)t0 * r_n0 + 1e-9), c1 = (int)floor((double)t1 * r_n1 + 1e-9),
-                          c2 = (int)floor((double)t2 * r_n2 + 1e-9);
-                nbin_l = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
-                code_l = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16);
-                cnt_l = min(n.bin_count[nbin_l], cap);
-            }
-        }
-        const int nsteps = (min(64, nbox - q0) + 3) >> 2;
-        for (int u0 = 0; u0 < nsteps; u0 += STEPS) {
-            // step u of the chunk: the 16 lanes of group grp take bin 4*(u0+u) + grp
-            int nbin[STEPS], code[STEPS], cnt[STEPS], cmax = 0;
-#pragma unroll
-            for (int u = 0; u < STEPS; u++) {
-                const int src = 4 * (u0 + u) + grp;  // (>= 64 only beyond nsteps: masked below)
-                nbin[u] = __shfl(nbin_l, src & 63, 64);
-                code[u] = __shfl(code_l, src & 63, 64);
-                cnt[u] = u0 + u < nsteps ? __shfl(cnt_l, src & 63, 64) : 0;
-                cmax = max(cmax, cnt[u]);
-            }
-            // 16 slots of every bin per pass: one pass unless a bin holds more than 16 atoms
-            for (int s0 = 0; __any(s0 < cmax); s0 += 16) {
-                BinRec rec[STEPS];
-                BinAux ax[STEPS];
-#pragma unroll
-                for (int u = 0; u < STEPS; u++) {
-                    const size_t e = (size_t)nbin[u] * cap + (s0 + s16 < cnt[u] ? s0 + s16 : 0);
-                    rec[u] = n.b_rec[e];
-                    ax[u] = n.b_aux[e];
-                }
-#pragma unroll
-                for (int u = 0; u < STEPS; u++)
-                    if (__any(s0 + s16 < cnt[u]))
-                        consume(s0 + s16 < cnt[u], rec[u], ax[u], code[u], q0 + 4 * (u0 + u) + grp, s0 + s16);
-            }
-        }
-    }
-    const bool shear = __any(near);
-    PHASE_STAMP(1);
-    // ------------------------------------------------------------------ sort
-    // bitonic sort of the first min(base, NL_SORT_MAX) keys.  Up to 64 keys (the usual case) sort in
-    // registers, one key per lane, partners by cross-lane shuffle: a third of the instructions of the
-    // LDS network below and no barriers.
-    const int ns = min(base, NL_SORT_MAX);
-    wave_sync();
-    if (ns <= 64) {
-        unsigned long long key = lane < ns ? keys[lane] : ~0ull;
-#pragma unroll
-        for (int k2s = 2; k2s <= 64; k2s <<= 1)
-#pragma unroll
-            for (int j2 = k2s >> 1; j2 > 0; j2 >>= 1) {
-                const unsigned lo = __shfl_xor((unsigned)key, j2, 64), hi = __shfl_xor((unsigned)(key >> 32), j2, 64);
-                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-                const bool lower = (lane & j2) == 0, up = (lane & k2s) == 0;
-                const bool take_min = lower == up;  // the lower lane of a pair keeps the smaller key in an ascending block
-                key = take_min ? (other < key ? other : key) : (other > key ? other : key);
-            }
-        wave_sync();  // all lanes have read their unsorted key
-        if (lane < ns) keys[lane] = key;
-    } else {
-        int np2 = 1;
-        while (np2 < ns) np2 <<= 1;
-        for (int t = ns + lane; t < np2; t += 64) keys[t] = ~0ull;
-        wave_sync();
-        for (int k2s = 2; k2s <= np2; k2s <<= 1)
-            for (int j2 = k2s >> 1; j2 > 0; j2 >>= 1) {
-                for (int t = lane; t < np2; t += 64) {
-                    const int p = t ^ j2;
-                    if (p > t) {
-                        const unsigned long long a0 = keys[t], a1 = keys[p];
-                        const bool up = (t & k2s) == 0;
-                        if ((a0 > a1) == up) { keys[t] = a1; keys[p] = a0; }
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int slot = base + __popcll(m & lt);
+                const int j = rec.idx, sj = ax.slot;
+                // key: neighbour index (24 bits), the image triple biased to sort as unsigned (24), species
+                // slot (4), sweep ordinal (12: finds the candidate id again after the sort)
+                const unsigned img = (unsigned)((f0 + 128) & 0xff) << 16 | (unsigned)((f1 + 128) & 0xff) << 8 |
+                                     (unsigned)((f2 + 128) & 0xff);
+                const unsigned long long key = ((unsigned long long)(unsigned)j << 40) | ((unsigned long long)img << 16) |
+                                               ((unsigned long long)(unsigned)sj << 12) | (unsigned)(slot & 0xfff);
+                if (max(max(abs(f0), abs(f1)), abs(f2)) > 127) atomicMax(&n.stat[3], 1);  // image shift beyond the packed code
+                if (slot < NL_SORT_MAX) {
+                    keys[slot] = key;
+                    hq[slot] = (q << 12) | k;
+                } else if (slot < maxnn) {  // very long lists: keep sweep order beyond the sortable part
+                    const size_t e = (size_t)i * maxnn + slot;
+                    n.cand_j[e] = j;
+                    n.cand_code[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+                    n.aux[e] = 0;
+                    if (t_ok) {
+                        n.aux[e] = q * cap + k;
+                        n.T[(size_t)j * n.t_stride + (size_t)(nbox - 1 - q) * cap + ki] = (unsigned short)slot;
                     }
                 }
-                wave_sync();
             }
-    }
-    wave_sync();
-    PHASE_STAMP(2);
-    // ------------------------------------------------------------------ list out
-    const int nn = base < maxnn ? base : maxnn;
-    for (int t = lane; t < ns && t < maxnn; t += 64) {
-        const unsigned long long key = keys[t];
-        const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
-        const int f0 = (int)((img >> 16) & 0xff) - 128, f1 = (int)((img >> 8) & 0xff) - 128, f2 = (int)(img & 0xff) - 128,
-                  sj = (int)(key >> 12) & 0xf, j = (int)(key >> 40);
-        const size_t e = (size_t)i * maxnn + t;
-        n.nbr_j[e] = j;
-        n.nbr_shift[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
-        int hs = 0;
-        if (t_ok) {
-            const int hv = hq[(int)key & 0xfff];
-            const int qq = hv >> 12, kk = hv & 0xfff;
-            hs = qq * cap + kk;
-            n.T[(size_t)j * n.t_stride + (size_t)(nbox - 1 - qq) * cap + ki] = (unsigned short)t;
+            base += __popcll(m);
+        };
+        constexpr int STEPS = NL_STEPS;  // steps (of four bins) whose loads are requested together
+        // position of the atom inside its own bin, in bin units: bounds the distance to the neighbouring bins
+        double tb[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double fk = xi * g.inv[k] + yi * g.inv[3 + k] + zi * g.inv[6 + k];
+            const double uk = (fk - floor(fk)) * g.nb[k] - (k == 0 ? b0 : k == 1 ? b1 : b2);
+            tb[k] = g.rng[k] > 0 ? fmin(fmax(uk, 0.0), 1.0) : 0.0;
         }
-        n.aux[e] = hs;
+        const double rl2_skip = rl2 * (1.0 + 1e-9);
+        for (int q0 = 0; q0 < (ghost ? 0 : nbox); q0 += 64) {
+            // lane = neighbouring bin: index, image code and population of up to 64 bins with one load; bins that
+            // are empty or whose nearest point lies beyond reach are dropped (about 19 of 27 remain)
+            int nbin_l = 0, code_l = 0, cnt_l = 0;
+            bool keep = false;
+            {
+                const int q = q0 + lane;
+                if (q < nbox) {
+                    const int qa = fdiv(q, i_w2), qb = fdiv(qa, i_w1);
+                    const int o2 = q - qa * w2 - g.rng[2], o1 = qa - qb * w1 - g.rng[1], o0 = qb - g.rng[0];
+                    const int t0 = b0 + o0, t1 = b1 + o1, t2 = b2 + o2;
+                    const int c0 = (int)floor((double)t0 * r_n0 + 1e-9), c1 = (int)floor((double)t1 * r_n1 + 1e-9),
+                              c2 = (int)floor((double)t2 * r_n2 + 1e-9);
+                    nbin_l = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
+                    code_l = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16);
+                    cnt_l = min(n.bin_count[nbin_l], cap);
+                    // gap between the atom and the bin along each plane normal (bin units -> length)
+                    const double g0 = (o0 > 0 ? o0 - tb[0] : o0 < 0 ? tb[0] - o0 - 1.0 : 0.0) * g.w[0];
+                    const double g1 = (o1 > 0 ? o1 - tb[1] : o1 < 0 ? tb[1] - o1 - 1.0 : 0.0) * g.w[1];
+                    const double g2 = (o2 > 0 ? o2 - tb[2] : o2 < 0 ? tb[2] - o2 - 1.0 : 0.0) * g.w[2];
+                    const double gm = fmax(g0, fmax(g1, g2));
+                    const double lb2 = g.ortho ? g0 * g0 + g1 * g1 + g2 * g2 : gm * gm;
+                    keep = cnt_l > 0 && lb2 < rl2_skip;
+                }
+            }
+            const unsigned long long km = __ballot(keep);
+            const int nlist = __popcll(km);
+            wave_sync();  // the previous chunk's readers of binl are done
+            if (keep) binl[__popcll(km & lt)] = make_int4(nbin_l, code_l, cnt_l, q0 + lane);
+            wave_sync();
+            const int nsteps = (nlist + 3) >> 2;
+            for (int u0 = 0; u0 < nsteps; u0 += STEPS) {
+                // step u of the chunk: the 16 lanes of group grp take entry 4*(u0+u) + grp of the bin list
+                int nbin[STEPS], code[STEPS], cnt[STEPS], qq[STEPS], cmax = 0;
+#pragma unroll
+                for (int u = 0; u < STEPS; u++) {
+                    const int e = 4 * (u0 + u) + grp;
+                    const int4 bb = binl[e < nlist ? e : 0];
+                    nbin[u] = bb.x; code[u] = bb.y; qq[u] = bb.w;
+                    cnt[u] = e < nlist ? bb.z : 0;
+                    cmax = max(cmax, cnt[u]);
+                }
+                // 16 slots of every bin per pass: one pass unless a bin holds more than 16 atoms
+                for (int s0 = 0; __any(s0 < cmax); s0 += 16) {
+                    BinRec rec[STEPS];
+                    BinAux ax[STEPS];
+#pragma unroll
+                    for (int u = 0; u < STEPS; u++) {
+                        const size_t e = (size_t)nbin[u] * cap + (s0 + s16 < cnt[u] ? s0 + s16 : 0);
+                        rec[u] = n.b_rec[e];
+                        ax[u] = n.b_aux[e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < STEPS; u++)
+                        if (__any(s0 + s16 < cnt[u])) consume(s0 + s16 < cnt[u], rec[u], ax[u], code[u], qq[u], s0 + s16);
+                }
+            }
+        }
+        PHASE_STAMP(1);
+        // bitonic sort of the first min(base, NL_SORT_MAX) keys.  Up to 64 keys sort in registers, one key per
+        // lane, partners by cross-lane shuffle: a third of the instructions of the LDS network and no barriers.
+        const int ns = min(base, NL_SORT_MAX);
+        wave_sync();
+        if (ns <= 64) {
+            unsigned long long key = lane < ns ? keys[lane] : ~0ull;
+#pragma unroll
+            for (int k2s = 2; k2s <= 64; k2s <<= 1)
+#pragma unroll
+                for (int j2 = k2s >> 1; j2 > 0; j2 >>= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)key, j2, 64), hi = __shfl_xor((unsigned)(key >> 32), j2, 64);
+                    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                    const bool lower = (lane & j2) == 0, up = (lane & k2s) == 0;
+                    const bool take_min = lower == up;  // the lower lane of a pair keeps the smaller key in an ascending block
+                    key = take_min ? (other < key ? other : key) : (other > key ? other : key);
+                }
+            wave_sync();  // all lanes have read their unsorted key
+            if (lane < ns) keys[lane] = key;
+        } else {
+            int np2 = 1;
+            while (np2 < ns) np2 <<= 1;
+            for (int t = ns + lane; t < np2; t += 64) keys[t] = ~0ull;
+            wave_sync();
+            for (int k2s = 2; k2s <= np2; k2s <<= 1)
+                for (int j2 = k2s >> 1; j2 > 0; j2 >>= 1) {
+                    for (int t = lane; t < np2; t += 64) {
+                        const int p = t ^ j2;
+                        if (p > t) {
+                            const unsigned long long a0 = keys[t], a1 = keys[p];
+                            const bool up = (t & k2s) == 0;
+                            if ((a0 > a1) == up) { keys[t] = a1; keys[p] = a0; }
+                        }
+                    }
+                    wave_sync();
+                }
+        }
+        wave_sync();
+        // candidate list out (kept until the next rebuild)
+        ncand = base < maxnn ? base : maxnn;
+        for (int c = lane; c < ns && c < maxnn; c += 64) {
+            const unsigned long long key = keys[c];
+            const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
+            const int f0 = (int)((img >> 16) & 0xff) - 128, f1 = (int)((img >> 8) & 0xff) - 128, f2 = (int)(img & 0xff) - 128,
+                      sj = (int)(key >> 12) & 0xf, j = (int)(key >> 40);
+            const size_t e = (size_t)i * maxnn + c;
+            n.cand_j[e] = j;
+            n.cand_code[e] = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (sj << 24);
+            int hs = 0;
+            if (t_ok) {
+                const int hv = hq[(int)key & 0xfff];
+                const int qv = hv >> 12, kk = hv & 0xfff;
+                hs = qv * cap + kk;
+                n.T[(size_t)j * n.t_stride + (size_t)(nbox - 1 - qv) * cap + ki] = (unsigned short)c;
+            }
+            n.aux[e] = hs;
+        }
+        if (lane == 0) {
+            n.ncand[i] = ncand;
+            n.nn_raw[ia] = base;  // unclamped: finalize reduces the max for the overflow check
+        }
+        if (ncand > NL_SORT_MAX) __threadfence();  // rare: the unsorted tail written during the sweep is read back below
+        PHASE_STAMP(2);
+    } else {
+        ncand = __builtin_amdgcn_readfirstlane(n.ncand[i]);
+        if (lane == 0) n.nn_raw[ia] = ncand;
     }
+    // ------------------------------------------------------------------ this step's list: filter the candidates
+    const double rc2_lo = a.rc * a.rc * (1.0 - 1e-14), rc2_hi = a.rc * a.rc * (1.0 + 1e-14);
+    int nn = 0;
+    bool near = false;
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+        const int c = c0 + lane;
+        bool hit = false;
+        int j = 0, cd = 0;
+        double r0 = 1.0, r1 = 0.0, r2 = 0.0;
+        if (c < ncand) {
+            if (rebuild && c < NL_SORT_MAX) {
+                const unsigned long long key = keys[c];
+                const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
+                const int f0 = (int)((img >> 16) & 0xff) - 128, f1 = (int)((img >> 8) & 0xff) - 128, f2 = (int)(img & 0xff) - 128;
+                j = (int)(key >> 40);
+                cd = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (((int)(key >> 12) & 0xf) << 24);
+            } else {
+                const size_t e = (size_t)i * maxnn + c;
+                j = n.cand_j[e];
+                cd = n.cand_code[e];
+            }
+            const int f0 = (int)(int8_t)(cd & 0xff), f1 = (int)(int8_t)((cd >> 8) & 0xff), f2 = (int)(int8_t)((cd >> 16) & 0xff);
+            r0 = a.pos[3 * (size_t)j] - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
+            r1 = a.pos[3 * (size_t)j + 1] - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
+            r2 = a.pos[3 * (size_t)j + 2] - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
+            // |r| < rc on the squared distance; only within a few ulp of the cutoff the square root decides
+            // (the pair rule of the reference list is on |r| itself)
+            const double d2 = r0 * r0 + r1 * r1 + r2 * r2;
+            hit = d2 < rc2_lo || (d2 < rc2_hi && sqrt(d2) < a.rc);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) n.hm[(size_t)i * n.hmw + (c0 >> 6)] = m;
+        if (hit) {
+            const int t = nn + __popcll(m & lt);
+            const int sj = (cd >> 24) & 0xff;
+            const size_t e = (size_t)i * maxnn + t;
+            n.nbr_j[e] = j;
+            n.nbr_shift[e] = cd;
+            n.cidx[e] = c;
+            double *dst = t < CH ? hit0 + 4 * t : (t < 2 * CH ? hit1 + 4 * (t - CH) : nullptr);
+            if (dst) { dst[0] = r0; dst[1] = r1; dst[2] = r2; dst[3] = __hiloint2double(0, sj); }
+            // does the neighbour sit inside the z cone? (ylm.py:10-23: then the whole environment shears;
+            // the length unit scales all three components alike)
+            const double tol = SGPR_TINY_ANGLE * fabs(r2);
+            near |= (fabs(r0) < tol) && (fabs(r1) < tol);
+        }
+        nn += __popcll(m);
+    }
+    for (int w = (ncand + 63) / 64 + lane; w < n.hmw; w += 64) n.hm[(size_t)i * n.hmw + w] = 0ull;
+    const bool shear = __any(near);
     if (lane == 0) {
         n.nn[i] = nn;
         n.nn_local[ia] = nn;
-        n.nn_raw[ia] = base;  // unclamped: finalize reduces the max for the overflow check
     }
-    // what the forward tiles need from the list-build view of the region before it is reused: tile 0
-    // keeps key and displacement in registers, tile 1 its keys in k2; further tiles (> 96 neighbours)
-    // read the list back from memory
-    unsigned long long key0 = 0ull;
-    double r0[3] = {1.0, 0.0, 0.0};
-    bool have_r0 = false;
+    wave_sync();
+    // tile 0 keeps its hits in registers (the region is about to be reused); tile 1 reads hit1; further tiles
+    // (> 96 neighbours) read the list back from memory
+    double h0r[3] = {1.0, 0.0, 0.0};
+    int h0s = 0;
     if (lane < min(nn, CH)) {
-        key0 = keys[lane];
-        const int ord = (int)key0 & 0xfff;
-        if (ord < 64) { r0[0] = rl[3 * ord]; r0[1] = rl[3 * ord + 1]; r0[2] = rl[3 * ord + 2]; have_r0 = true; }
+        h0r[0] = hit0[4 * lane]; h0r[1] = hit0[4 * lane + 1]; h0r[2] = hit0[4 * lane + 2];
+        h0s = __double2loint(hit0[4 * lane + 3]);
     }
-    if (lane < CH && CH + lane < min(nn, NL_SORT_MAX)) k2[lane] = keys[CH + lane];
     if (nn > 2 * CH) __threadfence();  // rare: the list entries written above are read back below
     PHASE_STAMP(3);
     // ------------------------------------------------------------------ forward
@@ -772,23 +853,16 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
         double r[3] = {1.0, 0.0, 0.0};
         int s = 0;
         if (on) {
-            int j, f0, f1, f2;
-            bool have_r = false;
-            if (t0 < 2 * CH) {
-                const unsigned long long key = t0 == 0 ? key0 : k2[lane];
-                const unsigned img = (unsigned)(key >> 16) & 0xffffffu;
-                f0 = (int)((img >> 16) & 0xff) - 128; f1 = (int)((img >> 8) & 0xff) - 128; f2 = (int)(img & 0xff) - 128;
-                s = (int)(key >> 12) & 0xf; j = (int)(key >> 40);
-                have_r = t0 == 0 && have_r0;
+            if (t0 == 0) { r[0] = h0r[0]; r[1] = h0r[1]; r[2] = h0r[2]; s = h0s; }
+            else if (t0 == CH) {
+                r[0] = hit1[4 * lane]; r[1] = hit1[4 * lane + 1]; r[2] = hit1[4 * lane + 2];
+                s = __double2loint(hit1[4 * lane + 3]);
             } else {
                 const size_t e = (size_t)i * maxnn + t;
-                j = n.nbr_j[e];
+                const int j = n.nbr_j[e];
                 const int cd = n.nbr_shift[e];
-                f0 = (int)(int8_t)(cd & 0xff); f1 = (int)(int8_t)((cd >> 8) & 0xff); f2 = (int)(int8_t)((cd >> 16) & 0xff);
+                const int f0 = (int)(int8_t)(cd & 0xff), f1 = (int)(int8_t)((cd >> 8) & 0xff), f2 = (int)(int8_t)((cd >> 16) & 0xff);
                 s = (cd >> 24) & 0xff;
-            }
-            if (have_r) { r[0] = r0[0]; r[1] = r0[1]; r[2] = r0[2]; }
-            else {
                 r[0] = a.pos[3 * (size_t)j] - xi + (f0 * h[0] + f1 * h[3] + f2 * h[6]);
                 r[1] = a.pos[3 * (size_t)j + 1] - yi + (f0 * h[1] + f1 * h[4] + f2 * h[7]);
                 r[2] = a.pos[3 * (size_t)j + 2] - zi + (f0 * h[2] + f1 * h[5] + f2 * h[8]);
@@ -1101,10 +1175,17 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                 s = (a.nbr_shift[e] >> 24) & 0xff;
                 j = a.nbr_j[e];
                 if constexpr (GATHER) {
-                    // where atom j keeps this pair: position of i in j's list.  (Clamped: an attempt that
-                    // overflowed a capacity leaves these words unwritten; the host discards its results.)
-                    const int hs = min(max(a.aux[e], 0), a.t_stride - 1);
-                    rvp = min((int)a.T[(size_t)gi * a.t_stride + hs], a.maxnn - 1);
+                    // where atom j keeps this pair: the position of i in j's list of THIS step = the number of
+                    // j's candidates before i that are inside the cutoff now (popcount of j's hit mask).
+                    // (Clamped: an attempt that overflowed a capacity leaves these words unwritten; the host
+                    // discards its results.)
+                    const int c = min(max(a.cidx[e], 0), a.maxnn - 1);
+                    const int hs = min(max(a.aux[(size_t)gi * a.maxnn + c], 0), a.t_stride - 1);
+                    const int cr = min((int)a.T[(size_t)gi * a.t_stride + hs], a.maxnn - 1);
+                    const unsigned long long *hj = a.hm + (size_t)j * a.hmw;
+                    int pcount = __popcll(hj[cr >> 6] & ((1ull << (cr & 63)) - 1ull));
+                    for (int w = 0; w < (cr >> 6); w++) pcount += __popcll(hj[w]);
+                    rvp = min(pcount, a.maxnn - 1);
                 }
             }
             const double u = unit_of<ST>(a, s);
@@ -1380,6 +1461,8 @@ int launch_list_forward(const DescParams &p, const NlScratch &nl, const double *
     n.grid = nl.grid; n.bin_of = nl.bin_of; n.kslot = nl.kslot; n.bin_count = nl.bin_count; n.cap = nl.cap;
     n.b_rec = nl.b_rec; n.b_aux = nl.b_aux; n.nn = nn; n.nn_local = nn_local; n.nn_raw = nl.nn_raw; n.nbr_j = nbr_j;
     n.nbr_shift = nbr_shift; n.aux = nl.aux; n.T = nl.T; n.t_stride = nl.t_stride; n.stat = nl.stat;
+    n.flag = nl.flag + nl.parity; n.rc_list = p.rc + nl.skin; n.ncand = nl.ncand; n.cand_j = nl.cand_j;
+    n.cand_code = nl.cand_code; n.cidx = nl.cidx; n.hm = nl.hm; n.hmw = nl.hmw;
     DISPATCH_LNS(LISTFWD, a, n, st);
 }
 
@@ -1397,7 +1480,8 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const double *radii, const int *nn, const int *nbr_j, const int *nbr_shift,
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
                                const int *shear, const double *W, const double *prec, double *G, const int *aux,
-                               const unsigned short *T, int t_stride, double *F, double *virial, hipStream_t st)
+                               const unsigned short *T, int t_stride, const int *cidx, const unsigned long long *hm,
+                               int hmw, double *F, double *virial, hipStream_t st)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
@@ -1406,7 +1490,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
     a.stamps = p.stamps ? p.stamps + 8 * (size_t)p.Nall : nullptr;
     // gather form (G != null): pair gradients go to G[Nall][maxnn][4], the step's last kernel sums them.
     // scatter form: F points at [Fnbr | Fself] (fp64 atomics into Fnbr; sharded frames).
-    a.G = G; a.aux = aux; a.T = T; a.t_stride = t_stride;
+    a.G = G; a.aux = aux; a.T = T; a.t_stride = t_stride; a.cidx = cidx; a.hm = hm; a.hmw = hmw;
     a.Fnbr = F;
     a.Fself = F ? F + 3 * (size_t)p.Nall : nullptr;
     a.vir_part = virial;

@@ -44,6 +44,11 @@ struct BinArgs {
     int *stat;              // [4]: [1] = largest bin population seen beyond cap, [3] = wrap beyond int16
     double *zero_a; int n_zero_a;   // accumulators to clear for this step
     double *zero_b; int n_zero_b;
+    // Verlet candidates: rebuild decision of this step
+    int *flag; int parity, force;
+    double half_skin2;      // (skin / 2)^2
+    const double *pos0;     // [N][3] positions at the last rebuild (sorted order)
+    double *cell0;          // [9]
 };
 
 __device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGrid &g, int *stat)
@@ -109,11 +114,20 @@ __device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGr
                 g.nb[k] = 1;  // open direction: one slab, no images
                 g.rng[k] = 0;
             }
+            g.w[k] = hgt[k] / g.nb[k];
         }
+        // plane normals bc, ca, ab: orthogonal cells let the sweep bound the distance to a bin by the
+        // Euclidean norm of the three plane gaps (otherwise only by the largest gap)
+        const double d01 = bc[0] * ca[0] + bc[1] * ca[1] + bc[2] * ca[2], d02 = bc[0] * ab[0] + bc[1] * ab[1] + bc[2] * ab[2],
+                     d12 = ca[0] * ab[0] + ca[1] * ab[1] + ca[2] * ab[2];
+        const double n0 = bc[0] * bc[0] + bc[1] * bc[1] + bc[2] * bc[2], n1 = ca[0] * ca[0] + ca[1] * ca[1] + ca[2] * ca[2],
+                     n2 = ab[0] * ab[0] + ab[1] * ab[1] + ab[2] * ab[2];
+        g.ortho = (d01 * d01 < 1e-20 * n0 * n1 && d02 * d02 < 1e-20 * n0 * n2 && d12 * d12 < 1e-20 * n1 * n2) ? 1 : 0;
     } else {
         // no usable cell (cluster): everything in one bin, no images
         for (int k = 0; k < 9; k++) g.inv[k] = 0.0;
-        for (int k = 0; k < 3; k++) { g.nb[k] = 1; g.rng[k] = 0; }
+        for (int k = 0; k < 3; k++) { g.nb[k] = 1; g.rng[k] = 0; g.w[k] = 0.0; }
+        g.ortho = 0;
     }
     g.nbins = g.nb[0] * g.nb[1] * g.nb[2];
 }
@@ -124,7 +138,18 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     const int tid = threadIdx.x, wg = blockIdx.x;
     if (tid == 0) {
         nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
-        if (wg == 0) *a.grid = g;
+        if (wg == 0) {
+            *a.grid = g;
+            // rebuild decision, part 1: forced, or the cell differs from the one the candidates were built in;
+            // the other parity's flag is cleared for the next step (nobody reads it during this one)
+            bool changed = a.force != 0;
+            for (int k = 0; k < 9; k++) changed |= a.cell[k] != a.cell0[k];
+            if (changed) {
+                for (int k = 0; k < 9; k++) a.cell0[k] = a.cell[k];
+                atomicMax(&a.flag[a.parity], 1);
+            }
+            a.flag[a.parity ^ 1] = 0;
+        }
     }
     const int gsz = gridDim.x * 256, gid = wg * 256 + tid;
     // this atom's position is requested before the barrier: the gather (perm -> pos_in) and the grid
@@ -142,6 +167,10 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     __syncthreads();
     if (i >= a.N) return;
     a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
+    {   // rebuild decision, part 2: has this atom moved more than half the skin since the candidates were built?
+        const double dx = x - a.pos0[3 * i], dy = y - a.pos0[3 * i + 1], dz = z - a.pos0[3 * i + 2];
+        if (!(dx * dx + dy * dy + dz * dz <= a.half_skin2)) atomicMax(&a.flag[a.parity], 1);
+    }
     int bidx[3], w[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -188,5 +217,7 @@ void launch_neighbor_bin(const NlParams &p, const int *perm, const double *pos_i
     a.grid = s.grid; a.pos = pos; a.bin_count = s.bin_count; a.b_rec = s.b_rec; a.b_aux = s.b_aux;
     a.slot = s.slot; a.bin_of = s.bin_of; a.kslot = s.kslot; a.stat = s.stat;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
+    a.flag = s.flag; a.parity = s.parity; a.force = s.force; a.half_skin2 = 0.25 * s.skin * s.skin; a.pos0 = s.pos0;
+    a.cell0 = s.cell0;
     hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
 }

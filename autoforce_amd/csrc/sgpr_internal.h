@@ -48,7 +48,8 @@ struct NlGrid {
     int nb[3];       // bins per cell vector
     int rng[3];      // neighbouring bins searched on either side
     int nbins;
-    int pad;
+    int ortho;       // 1: the three bin-plane normals are mutually orthogonal (point-to-bin distances add in squares)
+    double w[3];     // bin width along each cell vector's normal (perpendicular height / nb)
 };
 
 // binned copy of an atom: one 32-B record + one 8-B record per candidate of the list sweep
@@ -69,9 +70,21 @@ struct NlScratch {
                        //      (all sticky)
     int *nn_raw;       // [count] unclamped neighbour counts (overflow check)
     // reverse index (descriptor.hip, list build): null T = not built (sharded frames use the scatter form)
-    int *aux;          // [N][maxnn] candidate id q*cap + k of each list entry
-    unsigned short *T; // [N][t_stride] list position of the pair as seen from the other end
+    int *aux;          // [N][maxnn] bin-sweep id q*cap + k of each candidate
+    unsigned short *T; // [N][t_stride] candidate position of the pair as seen from the other end
     int t_stride;
+    // Verlet candidates: lists of |r| < rc + skin, rebuilt on the device when an atom moved > skin/2 since the
+    // last build or the cell changed (flag[parity] of this step, set by the binning kernel; the other entry is
+    // cleared for the next step); every step filters them down to |r| < rc
+    int *flag;         // [2]
+    int parity;        // step counter & 1
+    int force;         // 1: rebuild regardless (new frame, capacity change, skin = 0)
+    double skin;
+    double *pos0;      // [N][3] positions at the last rebuild (sorted order)
+    double *cell0;     // [9] cell at the last rebuild
+    int *ncand, *cand_j, *cand_code, *cidx;  // [N], [N][maxnn] x 3
+    unsigned long long *hm;  // [N][hmw]
+    int hmw;
 };
 
 // Bins ALL N atoms (also: gathers pos_in[perm] -> pos in species-sorted order and clears the
@@ -116,7 +129,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const double *norm, const double *C, const int *shear,
                                const double *W /*[N][Dpad] dE/dp-hat*/, const double *prec /*from the forward pass*/,
                                double *G /*[Nall][maxnn][4] or null*/, const int *aux, const unsigned short *T,
-                               int t_stride,
+                               int t_stride, const int *cidx, const unsigned long long *hm, int hmw,
                                double *F /*[2][Nall][3]: atomic part | own part*/,
                                double *virial /*[9][workgroups]*/, hipStream_t st);
 

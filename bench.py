@@ -124,6 +124,11 @@ def main():
     ap.add_argument("--atoms-side", type=int, default=16, help="simple-cubic sites per edge (16 -> 4096 atoms)")
     ap.add_argument("--inducing", type=int, default=512)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--walk-sigma", type=float, default=0.012,
+                    help="the atoms move every step, as in MD: Gaussian random walk, this sigma per component per step "
+                         "(A; 600 K thermal velocities are 0.007-0.015 A per 1 fs step here); 0 = static frame")
+    ap.add_argument("--walk-frames", type=int, default=64, help="frames of the walk (traversed forth and back)")
+    ap.add_argument("--skin", type=float, default=0.5, help="Verlet skin of the neighbour candidates, A (0 = rebuild every step)")
     ap.add_argument("--overlap", type=int, default=0, help="1: covloss GEMM on a side stream next to the reverse pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--collective", default="native", choices=["native", "torch"],
@@ -160,9 +165,21 @@ def main():
     h = mdl.handle
     _lib.check(lib.sgpr_set_option(h, b"graph", 1 if args.graph else 0))
     _lib.check(lib.sgpr_set_option(h, b"overlap", args.overlap))
+    _lib.check(lib.sgpr_set_option(h, b"skin_milliangstrom", int(round(1000 * args.skin))))
 
     dev = torch.device("cuda", local_rank)
-    pos_d = torch.from_numpy(pos).to(dev)
+    # MD-like input: a Gaussian random walk away from the frame and back (closed loop of 2W - 2 frames, resident
+    # in HBM), so that the atoms move every step and the neighbour candidates are rebuilt at the rate an MD run
+    # would rebuild them; step k reads frame k of the loop (a pointer, no op on the step)
+    W = max(args.walk_frames, 1) if args.walk_sigma > 0 else 1
+    wrng = np.random.default_rng(7)
+    walk = [pos]
+    for _ in range(W - 1):
+        walk.append(walk[-1] + args.walk_sigma * wrng.normal(size=pos.shape))
+    loop = walk + walk[-2:0:-1]
+    frames_d = torch.from_numpy(np.stack(loop)).to(dev)
+    nframes = len(loop)
+    pos_d = frames_d[0]
     cell_d = torch.from_numpy(cell).to(dev)
     packed = torch.zeros(int(lib.sgpr_packed_len(N)), dtype=torch.float64, device=dev)
     _lib.check(lib.sgpr_bind_system(h, N, _lib.ptr(_lib.i32(numbers)), _lib.ptr(_lib.i32(pbc.astype(np.int32))),
@@ -188,9 +205,14 @@ def main():
             if ok:
                 mdl.comm_destroy()
 
+    frame_ptr = [frames_d[k].data_ptr() for k in range(nframes)]
+    counter = [0]
+
     def step():
         # with a communicator attached the step ends with the all-reduce of `packed`, same stream
-        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+        k = counter[0] % nframes
+        counter[0] += 1
+        _lib.check(lib.sgpr_step_dev(h, frame_ptr[k], cell_d.data_ptr(), packed.data_ptr(), sp))
         if world > 1 and not native:
             t = packed.cpu()
             dist.all_reduce(t)
@@ -207,11 +229,15 @@ def main():
         torch.cuda.synchronize(dev)
 
     fence()
+    rb0 = C.c_int64(0)
+    _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb0)))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    rb1 = C.c_int64(0)
+    _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb1)))
     _lib.check(lib.sgpr_sync_check(h, sp))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -238,7 +264,7 @@ def main():
     torch.cuda.synchronize(dev)
     tp = time.perf_counter()
     for _ in range(nprof):
-        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+        step()
     torch.cuda.synchronize(dev)
     t_plain_ms = (time.perf_counter() - tp) / nprof * 1e3
     overhead_ms = max((sum(stage_ms.values()) - t_plain_ms) / max(len(stage_ms), 1), 0.0)
@@ -255,8 +281,9 @@ def main():
             mdl.predict(numbers, pos, cell, pbc, beta=True)
         host_rate = N * nh / (time.perf_counter() - th)
         # wall time of one calculate() (NL + descriptors + K_nm + E/F/stress + covloss) through
-        # the drop-in surface, median of >= 50 calls after 5 warm-ups; the atoms move a little every call,
-        # as in MD, so nothing is served from ASE's result cache
+        # the drop-in surface, median of >= 50 calls after 5 warm-ups; the atoms move every call by the same
+        # random-walk step as above, so nothing is served from ASE's result cache and the neighbour candidates
+        # are rebuilt at the MD rate
         from autoforce_amd.ase_shim import Atoms
         from autoforce_amd.calculator import ActiveCalculator
         calc = ActiveCalculator(covariance=mdl, logfile=None)
@@ -265,7 +292,7 @@ def main():
         rng = np.random.default_rng(5)
         walls = []
         for it in range(55):
-            atoms.positions = atoms.positions + 1e-3 * rng.normal(size=pos.shape)
+            atoms.positions = atoms.positions + (args.walk_sigma or 1e-3) * rng.normal(size=pos.shape)
             tc = time.perf_counter()
             atoms.get_forces()
             walls.append(time.perf_counter() - tc)
@@ -334,6 +361,10 @@ def main():
                 "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
                 "packed_row": Dc, "graph": bool(args.graph),
+                "input": (f"closed Gaussian random walk, sigma {args.walk_sigma} A per component per step, {nframes} frames "
+                          f"resident in HBM" if nframes > 1 else "static frame"),
+                "neighbor_skin_A": args.skin,
+                "list_rebuilds_in_timed_steps": int(rb1.value - rb0.value),
                 "host_array_path_atom_steps_per_s": host_rate,
                 "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step "
                                f"({'issued by libsgpr_hip on the step stream' if native else 'torch.distributed, host staged' if world > 1 else 'single rank: none'})",

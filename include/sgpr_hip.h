@@ -213,9 +213,21 @@ int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_ma
  * check overflowed the neighbour-list capacity.  Returns SGPR_E_OVERFLOW if one did (those
  * steps' results are invalid; capacity has been grown, the next step re-sizes eagerly). */
 int sgpr_sync_check(sgpr_model *h, void *stream);
-/* Options: "graph" = 0/1 (replay sgpr_step_dev from a captured HIP graph; default 0: eager launches
- * pipeline well while a step is >100 us of kernels and measured faster than replay). */
+/* Options:
+ *  "graph" = 0/1            replay sgpr_step_dev from a captured HIP graph (default 0: eager launches pipeline
+ *                           well while a step is ~100 us of kernels and measured faster than replay)
+ *  "skin_milliangstrom"     Verlet skin of the neighbour candidates (default 500 = 0.5 A).  The reference asks ASE
+ *                           for a list with skin 0 at every step (descriptor/atoms.py:349-355); here candidate
+ *                           lists of |r| < rc + skin are kept and rebuilt ON THE DEVICE whenever an atom has moved
+ *                           more than skin/2 since the last build or the cell changed, and every step filters them
+ *                           to |r| < rc: the same pairs in the same order as a from-scratch list, bit for bit.
+ *                           0 = rebuild every step
+ *  "ignore_unknown_species" = 0/1  atoms and LCE neighbours outside the species table are invisible
+ *                           (descriptor/sesoap.py:343-346) instead of SGPR_E_SPECIES
+ *  "overlap" = 0/1          covloss product on a side stream (measured slower; default 0) */
 int sgpr_set_option(sgpr_model *h, const char *name, int value);
+/* How many times the neighbour candidates were rebuilt since sgpr_create (see "skin_milliangstrom"). */
+int sgpr_get_list_rebuilds(sgpr_model *h, int64_t *count);
 /* stress[6] (Voigt, eV/A^3) from a (summed) packed buffer on the host:
  * calculator/active.py:604-610, volume = |det cell| or -2 for a rank-deficient cell. */
 int sgpr_stress_from_virial(const double *virial9, const double *cell, double *stress6);

@@ -174,6 +174,37 @@ def test_slab_cell_with_zero_open_vector():
     mdl.close()
 
 
+@pytest.mark.parametrize("name", ["g5_mixed64", "g5_si32", "g5_tric24"])
+def test_candidate_lists_are_reused_without_changing_anything(name):
+    """Verlet candidates (|r| < rc + skin, rebuilt on the device when an atom has moved more than skin/2 or the
+    cell changed): over an MD-like walk — small moves, one jump, a cell strain, a wrap through the cell — every
+    step gives bit for bit what a model that rebuilds its lists every step gives, and the same neighbour list."""
+    from autoforce_amd import _lib
+    from test_hip_parity import load, model_from_fixture
+    g = load(name)
+    fast, slow = model_from_fixture(g), model_from_fixture(g)
+    _lib.check(_lib.load().sgpr_set_option(slow.handle, b"skin_milliangstrom", 0))
+    rng = np.random.default_rng(11)
+    pos, cell = g["positions"].copy(), g["cell"].copy()
+    N = len(pos)
+    for step in range(14):
+        if step in (1, 2, 3, 4, 5, 6, 9, 10, 12):
+            pos = pos + 0.03 * rng.normal(size=pos.shape)          # thermal-size moves: lists are reused
+        elif step == 7:
+            pos[rng.integers(N)] += np.array([0.9, -0.4, 0.2])      # one atom jumps: rebuild
+        elif step == 8:
+            cell = cell @ (np.eye(3) + 0.002 * rng.normal(size=(3, 3)))  # strained cell: rebuild
+        elif step == 11 and g["pbc"].all():
+            pos[0] = pos[0] + cell[0]                                # wrapped through the cell: rebuild
+        a = fast.predict(g["numbers"], pos, cell, g["pbc"], cov=True)
+        b = slow.predict(g["numbers"], pos, cell, g["pbc"], cov=True)
+        for k in ("energy", "forces", "stress", "beta", "cov"):
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=f"step {step}: {k}")
+        for x, y in zip(fast.neighbors(N), slow.neighbors(N)):
+            np.testing.assert_array_equal(x, y)
+    fast.close(); slow.close()
+
+
 def test_degenerate_inputs():
     from autoforce_amd import SGPRModel, SgprError
     mdl = SGPRModel(3, 3, 4.0, 6.0, species=[14])
