@@ -187,6 +187,8 @@ struct FinArgs {
     double mean_energy;
     double *packed;
     int *stat, *bin_count;
+    size_t g_stride, f_stride, v_stride, p_stride;  // batch (blockIdx.y, training rows): doubles between entries of
+                                                    // G, [Fnbr | Fself], virpart, packed
     const int *flag;            // this step's rebuild flag: set -> the candidates were rebuilt from `pos`
     int *rebuilds;              // running count of rebuilds
     const double *pos;          // [N][3] sorted order
@@ -198,6 +200,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
 {
     __shared__ double wsum[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const size_t by = blockIdx.y;
     double s = 0.0;
     if (q == 10) {
         int mx = 0;
@@ -206,7 +209,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
     } else {
-        const double *src = q == 0 ? f.Epart : f.virpart + (size_t)(q - 1) * f.nV;
+        const double *src = q == 0 ? f.Epart : f.virpart + by * f.v_stride + (size_t)(q - 1) * f.nV;
         const int n = q == 0 ? f.nE : f.nV;
         for (int k = tid; k < n; k += 256) s += src[k];
 #pragma unroll
@@ -215,7 +218,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
     if (lane == 0) wsum[wave] = s;
     __syncthreads();
     if (tid == 0) {
-        if (q == 10) {
+        if (q == 10 && by == 0) {
             if (*f.flag) atomicAdd(f.rebuilds, 1);
             const int mx = (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3]));
             f.stat[0] = max(f.stat[0], mx);  // sticky
@@ -223,7 +226,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
             // over ranks by the all-reduce, so every rank learns that the step must be repeated
             const bool ov = mx > f.maxnn || f.stat[1] > f.bin_cap || (f.t_check && f.stat[2] > f.t_stride) || f.stat[3] != 0;
             f.packed[4 * (size_t)f.N + 10] = ov ? 1.0 : 0.0;
-        } else f.packed[4 * (size_t)f.N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
+        } else if (q != 10) f.packed[by * f.p_stride + 4 * (size_t)f.N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
     }
 }
 
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
     const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
     if (b >= nA) { finalize_reduce(f, b - nA); return; }
     const int i = b * blockDim.x + tid;
+    const size_t by = blockIdx.y;
     for (int k = i; k < 4096; k += nA * blockDim.x) f.bin_count[k] = 0;
     if (i < f.N) {
         const int c = f.perm[i];
@@ -240,15 +244,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
 #pragma unroll
             for (int k = 0; k < 3; k++) f.pos0[3 * i + k] = f.pos[3 * i + k];
         }
+        double *packed = f.packed + by * f.p_stride;
 #pragma unroll
-        for (int k = 0; k < 3; k++) f.packed[3 * c + k] = f.Fnbr[3 * i + k] + f.Fself[3 * i + k];
+        for (int k = 0; k < 3; k++) packed[3 * c + k] = f.Fnbr[by * f.f_stride + 3 * i + k] + f.Fself[by * f.f_stride + 3 * i + k];
         double bt = 0.0;
         const int il = (i - f.first) / f.stride;
         if (f.has_beta && i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt) {
             const double v = 1.0 - f.csq[il];
             bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
         }
-        f.packed[3 * f.N + c] = bt;
+        packed[3 * f.N + c] = bt;
     }
 }
 
@@ -264,7 +269,9 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     const int i = b * 4 + wave;
     if (i >= f.N) return;
     const int n = f.nn[i];
-    double fs = lane < 3 ? f.Fself[3 * (size_t)i + lane] : 0.0;
+    const size_t by = blockIdx.y;
+    double fs = lane < 3 ? f.Fself[by * f.f_stride + 3 * (size_t)i + lane] : 0.0;
+    double *packed = f.packed + by * f.p_stride;
     const int c = f.perm[i];
     const double cs = f.has_beta ? f.csq[i] : 1.0;
     const double vs = f.has_beta ? f.vs_sqrt[f.slot[i]] : 0.0;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     for (int t0 = 0; t0 < n; t0 += 64) {
         const int t = t0 + lane;
         if (t < n) {
-            const double2 *row = (const double2 *)(f.G + ((size_t)i * f.maxnn + t) * 4);
+            const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + t) * 4);
             const double2 b0 = row[0], b1 = row[1];
             fx += b0.x; fy += b0.y; fz += b1.x;
         }
@@ -283,11 +290,11 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
         fy += __shfl_xor(fy, o, 64);
         fz += __shfl_xor(fz, o, 64);
     }
-    if (lane < 3) f.packed[3 * (size_t)c + lane] = fs - (lane == 0 ? fx : lane == 1 ? fy : fz);
+    if (lane < 3) packed[3 * (size_t)c + lane] = fs - (lane == 0 ? fx : lane == 1 ? fy : fz);
     if (lane < 3 && *f.flag) f.pos0[3 * (size_t)i + lane] = f.pos[3 * (size_t)i + lane];
     if (lane == 3) {
         const double v = 1.0 - cs;
-        f.packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
+        packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
     }
 }
 
@@ -920,8 +927,10 @@ static void stamp(sgpr_model *h, const char *name, hipStream_t st)
 
 // the step's last kernel.  gather: forces from the pair gradients G (reverse pass in gather form);
 // otherwise from the two force buffers of the scatter form (zero when no reverse pass ran).
+struct FinBatch { int batch; double *G, *F, *virpart; size_t g_stride, f_stride, v_stride, p_stride; };
+
 static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool beta, double mean_energy,
-                            double *packed_dev, hipStream_t st)
+                            double *packed_dev, hipStream_t st, const FinBatch *fb = nullptr)
 {
     const int N = h->N;
     FinArgs f = {};
@@ -934,10 +943,16 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
     f.mean_energy = mean_energy; f.packed = packed_dev; f.stat = h->d_stat.p; f.bin_count = h->d_bin_count.p;
     f.flag = h->step_flag ? h->step_flag : h->d_flag.p; f.pos = h->d_pos.p; f.pos0 = h->d_pos0.p;
     f.rebuilds = h->d_flag.p + 2;
+    int batch = 1;
+    if (fb) {
+        batch = fb->batch;
+        f.G = fb->G; f.Fnbr = fb->F; f.Fself = fb->F + 3 * (size_t)N; f.virpart = fb->virpart;
+        f.g_stride = fb->g_stride; f.f_stride = fb->f_stride; f.v_stride = fb->v_stride; f.p_stride = fb->p_stride;
+    }
     if (gather)
-        hipLaunchKernelGGL(finalize_gather_kernel, dim3((std::max(N, 1) + 3) / 4 + 11), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(finalize_gather_kernel, dim3((std::max(N, 1) + 3) / 4 + 11, batch), dim3(256), 0, st, f);
     else
-        hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256 + 11), dim3(256), 0, st, f);
+        hipLaunchKernelGGL(finalize_kernel, dim3((std::max(N, 1) + 255) / 256 + 11, batch), dim3(256), 0, st, f);
 }
 
 static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell_dev, double *packed_dev,

@@ -192,6 +192,13 @@ struct DescArgs {
     int hmw;
     int rsz;                // reverse pass: doubles of the per-wave scratch region
     int *shear;             // [N]
+    // training rows (sgpr_kernel_rows): blockIdx.y = column of the batch; the reverse-pass seed of column q is
+    // W_i = Aw[i][q] * Pm[q][:], formed on the fly (no W array), and every output is strided by the batch index
+    const double *rows_aw;  // [N][rows_ld] d k(i,q) / d(dot), or null (predict path: W below)
+    const double *rows_pm;  // [m][Dpad]
+    const int *rows_cols;   // [gridDim.y] species-sorted inducing index of each column of the batch
+    int rows_ld, batch;
+    size_t g_stride, f_stride, v_stride;  // doubles between the batch entries of G, F (= [Fnbr | Fself]), vir_part
     const double *W;        // backward: [N][Dpad]
     double *Fnbr;           // backward: [Nall][3] (atomic)
     double *Fself;          // backward: [Nall][3] (plain store, one writer)
@@ -1043,14 +1050,24 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
     int *sl = (int *)(R + a.rsz);                 // [CH] species slot per tile row
     const int gi = a.first + (active ? ia : 0) * a.stride;
     const int nn = active ? a.nn[gi] : 0;
+    // batch entry (training rows): column, seed scale and output bases
+    const int bq = a.rows_aw ? a.rows_cols[blockIdx.y] : 0;
+    const double aw_q = (a.rows_aw && active) ? a.rows_aw[(size_t)ia * a.rows_ld + bq] : 1.0;
+    double *Gb = a.G ? a.G + blockIdx.y * a.g_stride : nullptr;
+    double *Fnbr_b = a.Fnbr ? a.Fnbr + blockIdx.y * a.f_stride : nullptr;
+    double *Fself_b = a.Fself ? a.Fself + blockIdx.y * a.f_stride : nullptr;
+    double *vir_b = a.vir_part + blockIdx.y * a.v_stride;
     double tot = 0.0;  // lanes < 48 with (lane & 3) == 0: running sum of virial component / force component lane >> 2
+    bool zero_dc = false;  // dE/dp^ of this atom is identically zero (training rows: the column belongs to another
+                           // species): every pair gradient is zero, only the hand-over slots have to be cleared
 
     PHASE_STAMP(0);
     if (nn > 0) {
         // ---------------------------------------------------------------- phase A: dE/dc -> dcl
         const double nrm = a.norm[ia];
-        if (!(nrm > 0.0)) {
+        if (!(nrm > 0.0) || (a.rows_aw && aw_q == 0.0)) {  // (aw_q: wave-uniform; 0 for atoms of other species)
             for (int k = lane; k < ST * NSLOT; k += 64) dcl[k] = 0.0;
+            zero_dc = true;
         } else {
             const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
             // Up to 4 species the packed gradient is expanded into the full symmetric [u][v][l] array in
@@ -1061,7 +1078,8 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             double *gl = R + ST * NSLOT;    // EXPAND: [UT][UT][L1] else [Dpad]:  dE/dp~ * coef * (1 or 2)
             const double sden = nrm + SGPR_EPS;
             constexpr int MAXE = ((UT * (UT + 1)) / 2 * L1 + 63) / 64;
-            const double *Wi = a.W + (size_t)ia * a.Dpad, *Pi = a.Pn + (size_t)ia * a.Dpad;
+            const double *Wi = a.rows_aw ? a.rows_pm + (size_t)bq * a.Dpad : a.W + (size_t)ia * a.Dpad;
+            const double *Pi = a.Pn + (size_t)ia * a.Dpad;
             if constexpr (MAXE <= 10) {
                 // all global reads of this atom are issued up front (W, p^, pack entries, c)
                 double wv[MAXE], pv[MAXE];
@@ -1070,7 +1088,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                 for (int k = 0; k < MAXE; k++) {
                     const int e = lane + 64 * k;
                     const bool in = e < a.Dc;
-                    wv[k] = in ? Wi[e] : 0.0;
+                    wv[k] = in ? aw_q * Wi[e] : 0.0;
                     pv[k] = in ? Pi[e] : 0.0;
                     pe[k] = a.pack[in ? e : 0];
                 }
@@ -1082,6 +1100,12 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                         if (SPL * 64 == NSLOT || slot < NSLOT)
                             cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
                     }
+                {
+                    bool nz = false;
+#pragma unroll
+                    for (int k = 0; k < MAXE; k++) nz |= wv[k] != 0.0;
+                    zero_dc = !__any(nz);
+                }
                 // dE/dp~ = (W - p^ (p^.W) sden/nrm) / sden
                 double pw = 0.0;
 #pragma unroll
@@ -1092,7 +1116,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
 #pragma unroll
                 for (int k = 0; k < MAXE; k++) {
                     const int e = lane + 64 * k;
-                    if (e < a.Dc) {
+                    if (e < a.Dc && !zero_dc) {
                         const double gv = (wv[k] - pv[k] * corr) * isden * pe[k].coef * (pe[k].u == pe[k].v ? 2.0 : 1.0);
                         if constexpr (EXPAND) {
                             gl[(pe[k].u * UT + pe[k].v) * L1 + pe[k].l] = gv;
@@ -1104,12 +1128,12 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             } else {
                 // many species / high lmax: too many entries per lane to hold in registers
                 double pw = 0.0;
-                for (int e = lane; e < a.Dc; e += 64) pw += Wi[e] * Pi[e];
+                for (int e = lane; e < a.Dc; e += 64) pw += aw_q * Wi[e] * Pi[e];
                 pw = wave_sum(pw);
                 const double corr = pw * sden / nrm;
                 for (int e = lane; e < a.Dc; e += 64) {
                     const PackEntry pe = a.pack[e];
-                    const double gv = (Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
+                    const double gv = (aw_q * Wi[e] - Pi[e] * corr) / sden * pe.coef * (pe.u == pe.v ? 2.0 : 1.0);
                     if constexpr (EXPAND) {
                         gl[(pe.u * UT + pe.v) * L1 + pe.l] = gv;
                         gl[(pe.v * UT + pe.u) * L1 + pe.l] = gv;
@@ -1127,6 +1151,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             }
             wave_sync();
             // dE/dc[u][lm] = sum_v G[u][v][l] c[v][lm]
+            if (!zero_dc)
 #pragma unroll
             for (int s = 0; s < ST; s++)
 #pragma unroll
@@ -1187,6 +1212,16 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                     for (int w = 0; w < (cr >> 6); w++) pcount += __popcll(hj[w]);
                     rvp = min(pcount, a.maxnn - 1);
                 }
+            }
+            if (zero_dc) {  // wave-uniform
+                if constexpr (GATHER) {
+                    if (on) {
+                        double2 *dst = (double2 *)(Gb + ((size_t)j * a.maxnn + rvp) * 4);
+                        dst[0] = make_double2(0.0, 0.0);
+                        dst[1] = make_double2(0.0, 0.0);
+                    }
+                }
+                continue;
             }
             const double u = unit_of<ST>(a, s);
             const double iu = inv_unit_of<ST>(a, s);
@@ -1275,12 +1310,12 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             if (on) {
                 if constexpr (GATHER) {
                     // handed to atom j at ITS list position: the last kernel reads whole rows, coalesced
-                    double2 *dst = (double2 *)(a.G + ((size_t)j * a.maxnn + rvp) * 4);
+                    double2 *dst = (double2 *)(Gb + ((size_t)j * a.maxnn + rvp) * 4);
                     dst[0] = make_double2(gr[0], gr[1]);
                     dst[1] = make_double2(gr[2], 0.0);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&a.Fnbr[3 * (size_t)j + k], -gr[k]);
+                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&Fnbr_b[3 * (size_t)j + k], -gr[k]);
                 }
             }
             // 9 virial sums (+ 3 force sums in the sharded form) through the region: [12][CH], then 48
@@ -1310,11 +1345,11 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
     if (lane < 48 && (lane & 3) == 0) {
         const int k = lane >> 2;
         if (k < 9) vred[wave][k] = tot;
-        else if (active) a.Fself[3 * (size_t)gi + (k - 9)] = tot;
+        else if (active) Fself_b[3 * (size_t)gi + (k - 9)] = tot;
     }
     __syncthreads();
     if (wave == 0 && lane < 9)
-        a.vir_part[(size_t)lane * gridDim.x + blockIdx.x] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
+        vir_b[(size_t)lane * gridDim.x + blockIdx.x] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
 }
 
 // =========================================================================== unpack (tests)
@@ -1382,8 +1417,9 @@ static int run_bwd(DescArgs a, hipStream_t st)
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[gather] = lds;
     }
-    if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false>), dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+    const dim3 grid((a.N + 3) / 4, a.rows_aw ? a.batch : 1);
+    if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false>), grid, dim3(256), lds, st, a);
     return 0;
 }
 
@@ -1481,7 +1517,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
                                const int *shear, const double *W, const double *prec, double *G, const int *aux,
                                const unsigned short *T, int t_stride, const int *cidx, const unsigned long long *hm,
-                               int hmw, double *F, double *virial, hipStream_t st)
+                               int hmw, double *F, double *virial, hipStream_t st, const RowsBatch *rows)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
@@ -1494,5 +1530,9 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
     a.Fnbr = F;
     a.Fself = F ? F + 3 * (size_t)p.Nall : nullptr;
     a.vir_part = virial;
+    if (rows) {
+        a.rows_aw = rows->aw; a.rows_pm = rows->pm; a.rows_cols = rows->cols; a.rows_ld = rows->ld; a.batch = rows->batch;
+        a.g_stride = rows->g_stride; a.f_stride = rows->f_stride; a.v_stride = rows->v_stride;
+    }
     DISPATCH_LNS(BWD, a, st);
 }

@@ -119,6 +119,15 @@ int launch_descriptor_forward_env(const DescParams &p, const int64_t *env_ptr, c
                                   const double *env_r, const double *radii, const PackEntry *pack,
                                   double *Pn, double *norm, hipStream_t st);
 
+// Training rows: a batch of inducing columns per launch (blockIdx.y); the seed of column q is Aw[i][q] * Pm[q][:]
+struct RowsBatch {
+    const double *aw;   // [N][ld]
+    const double *pm;   // [m][Dpad]
+    const int *cols;    // [batch] species-sorted inducing index (device)
+    int ld, batch;
+    size_t g_stride, f_stride, v_stride;  // doubles between batch entries of G, F, virial partials
+};
+
 // Reverse pass (one launch).  Own sums go to F[3*Nall:6*Nall].  G != null: gather form, the gradient of
 // pair (i -> j) is stored to G[j][rev] (rev = T[i][aux[i][t]], the reverse index of the neighbour list)
 // and the finalize kernel subtracts each atom's row.  G == null: scatter form (sharded frames), fp64
@@ -131,7 +140,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                double *G /*[Nall][maxnn][4] or null*/, const int *aux, const unsigned short *T,
                                int t_stride, const int *cidx, const unsigned long long *hm, int hmw,
                                double *F /*[2][Nall][3]: atomic part | own part*/,
-                               double *virial /*[9][workgroups]*/, hipStream_t st);
+                               double *virial /*[9][workgroups]*/, hipStream_t st, const RowsBatch *rows = nullptr);
 
 // Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
 void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,
