@@ -40,6 +40,13 @@ SIGNATURES = {
     "sgpr_make_vscale": (C.c_int, [_vp, _vp]),
     "sgpr_kernel_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgpr_kernel_columns": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "sgpr_data_push": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
+    "sgpr_data_pop": (C.c_int, [_vp, C.c_int]),
+    "sgpr_data_clear": (C.c_int, [_vp]),
+    "sgpr_data_info": (C.c_int, [_vp, _vp, _vp]),
+    "sgpr_data_matvec": (C.c_int, [_vp, _vp, _vp]),
+    "sgpr_data_get": (C.c_int, [_vp, _vp]),
+    "sgpr_data_solve": (C.c_int, [_vp, _vp, C.c_int, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_add_inducing": (C.c_int, [_vp, _i32, C.c_int, _vp, _vp]),
     "sgpr_remove_inducing": (C.c_int, [_vp, C.c_int]),
     "sgpr_select_inducing": (C.c_int, [_vp, C.c_int, _vp]),
@@ -106,8 +113,48 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("SGPR_API_TRACE"):
+            lib = _Traced(lib)
         _lib = lib
     return _lib
+
+
+class _Traced:
+    """SGPR_API_TRACE=1: per-entry-point wall time, the device drained before and after each call (so
+    asynchronous work is billed to the call that queued it); the table is printed at exit."""
+
+    def __init__(self, lib):
+        import atexit
+        import time
+        self._lib, self._time, self._acc = lib, time.perf_counter, {}
+        try:
+            self._sync = C.CDLL(None).hipDeviceSynchronize  # the runtime that is already mapped
+        except AttributeError:
+            self._sync = C.CDLL("libamdhip64.so.7").hipDeviceSynchronize
+        atexit.register(self._report)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in ("sgpr_last_error", "sgpr_version", "sgpr_device_count", "sgpr_packed_len", "sgpr_destroy"):
+            return fn
+
+        def call(*a):
+            self._sync()
+            t0 = self._time()
+            r = fn(*a)
+            t1 = self._time()
+            self._sync()
+            t2 = self._time()
+            acc = self._acc.setdefault(name, [0, 0.0, 0.0])
+            acc[0] += 1; acc[1] += t1 - t0; acc[2] += t2 - t1
+            return r
+        return call
+
+    def _report(self):
+        import sys
+        print("# SGPR_API_TRACE: entry point, calls, ms in the call (mean), ms drained after it (mean), total ms", file=sys.stderr)
+        for name, (n, a, b) in sorted(self._acc.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+            print(f"# {name:32s} {n:6d} {1e3 * a / n:10.3f} {1e3 * b / n:10.3f} {1e3 * (a + b):10.1f}", file=sys.stderr)
 
 
 def check(code):

@@ -124,6 +124,23 @@ struct sgpr_model {
     DevBuf<double> d_prec, d_G;
     DevBuf<double> d_gpart;
     DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
+    DevBuf<double> d_rows_bG, d_rows_bF, d_rows_bV;     // (batch of columns: G, [Fnbr | Fself], virial partials)
+    DevBuf<int> d_rows_cols;
+    std::vector<int> rows_cols;
+    // resident training set (data.inc): the design matrix [K_e; K_f; K_v] of the stored frames, column-major in the
+    // caller's column order, design[c * design_rcap + r]; rows in frame-major blocks (e, 3N f, nv v)
+    struct DataFrame {
+        int N = 0, nv = 0;
+        int64_t row0 = 0, rows = 0;
+        std::vector<int32_t> numbers;
+        std::vector<double> pos;
+        double cell[9];
+        int32_t pbc[3];
+    };
+    std::vector<DataFrame> frames;
+    DevBuf<double> d_design, d_qr_A, d_qr_work;
+    int64_t design_rcap = 0, design_ccap = 0, design_rows = 0;
+    bool design_hold = false;  // an edit entry point is re-indexing the columns itself
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
     DevBuf<double> d_edit_tmp;  // scratch of the incremental inducing-set edits
@@ -462,8 +479,10 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     DevBuf<double> *db[] = {&h->d_radii, &h->d_Pm, &h->d_PmT, &h->d_pm_norm, &h->d_M, &h->d_mu, &h->d_choli,
                             &h->d_vs_sqrt, &h->d_gpart, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed,
-                            &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1, &h->d_edit_tmp};
+                            &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1, &h->d_edit_tmp,
+                            &h->d_rows_bG, &h->d_rows_bF, &h->d_rows_bV, &h->d_design, &h->d_qr_A, &h->d_qr_work};
     for (auto b : db) b->release();
+    h->d_rows_cols.release();
     h->d_pack.release();
     h->d_T.release();
     h->d_hm.release();
@@ -580,6 +599,9 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
 }
 
 static int alloc_work(sgpr_model *h);
+static int design_after_set(sgpr_model *h);   // data.inc: the resident design matrix follows the inducing set
+static int design_after_add(sgpr_model *h);
+static int design_select(sgpr_model *h, int count, const int32_t *idx);
 
 extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const int64_t *nbr_ptr,
                                  const int32_t *nbr_z, const double *nbr_r)
@@ -672,8 +694,11 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     d_ptr.release(); d_eslot.release(); d_er.release();
-    if (h->N > 0) return alloc_work(h);  // a system is bound: K/Aw buffers and tile tables follow m
-    return SGPR_OK;
+    if (h->N > 0) {  // a system is bound: K/Aw buffers and tile tables follow m
+        const int rc_ = alloc_work(h);
+        if (rc_) return rc_;
+    }
+    return design_after_set(h);
 }
 
 extern "C" int sgpr_get_kmm(sgpr_model *h, double *M)
@@ -1481,3 +1506,4 @@ extern "C" int sgpr_get_stage_times(sgpr_model *h, double *ms, int cap, char *na
 }
 
 #include "solve.inc"
+#include "data.inc"

@@ -135,6 +135,7 @@ class SGPRModel:
         nptr = i64(np.concatenate([[0], np.cumsum([len(x._b) for x in X])]))
         nz = i32(np.concatenate([x._b for x in X] + [np.zeros(0, np.int32)]))
         nr = f64(np.concatenate([x._r for x in X] + [np.zeros((0, 3))]))
+        self.generation += 1
         check(_lib.load().sgpr_set_inducing(self._h, m, ptr(zc), ptr(nptr), ptr(nz), ptr(nr)))
         self.X = X  # (after the device accepted it: on an error host and device lists still agree)
         self.mu = None
@@ -147,6 +148,7 @@ class SGPRModel:
     def add_inducing(self, loc):
         """Append one LCE (PosteriorPotential.add_inducing, gppotential.py:745-772, without the
         data columns — those are `kernel_columns`)."""
+        self.generation += 1  # (stored data frames are re-bound for their new column)
         check(_lib.load().sgpr_add_inducing(self._h, loc.number, len(loc._b), ptr(loc._b), ptr(loc._r)))
         self.X.append(loc)
         self._weights_dropped()
@@ -263,6 +265,61 @@ class SGPRModel:
         check(_lib.load().sgpr_kernel_columns(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc),
                                               int(q_first), int(q_count), ptr(Ke), ptr(Kf), ptr(Kv)))
         return Ke, Kf, Kv
+
+    # ------------------------------------------------------------------ resident training set
+    def data_push(self, numbers, positions, cell, pbc, nv=6):
+        """Append a data frame to the device-resident design matrix (PosteriorPotential.add_data,
+        gppotential.py:730-743): its K_e / K_f / K_v rows are computed on the device and stay there."""
+        numbers = i32(numbers)
+        N = len(numbers)
+        positions = f64(positions).reshape(N, 3)
+        cell = f64(np.asarray(cell, float).reshape(3, 3))
+        pbc = i32(np.asarray(pbc, bool).astype(np.int32))
+        self.generation += 1
+        check(_lib.load().sgpr_data_push(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), int(nv)))
+
+    def data_pop(self, index=-1):
+        """pop_1data (index -1) / popfirst_1data (index 0), gppotential.py:793-813."""
+        check(_lib.load().sgpr_data_pop(self._h, int(index)))
+
+    def data_clear(self):
+        check(_lib.load().sgpr_data_clear(self._h))
+
+    def data_info(self):
+        n, rows = C.c_int32(0), C.c_int64(0)
+        check(_lib.load().sgpr_data_info(self._h, C.addressof(n), C.addressof(rows)))
+        return n.value, rows.value
+
+    def data_matvec(self, v):
+        """K v over all stored rows (frame-major: e, 3N f, nv v per frame)."""
+        v = f64(v).reshape(self.m)
+        out = np.zeros(self.data_info()[1])
+        check(_lib.load().sgpr_data_matvec(self._h, ptr(v), ptr(out)))
+        return out
+
+    def data_get(self):
+        """The resident design matrix [rows, m] (diagnostics / tests)."""
+        out = np.zeros((self.data_info()[1], self.m))
+        if out.size:
+            check(_lib.load().sgpr_data_get(self._h, ptr(out)))
+        return out
+
+    def data_solve(self, Y, with_energies=True, noise=0.01):
+        """`solve` on the resident matrix (Y in its row order)."""
+        Y = f64(Y).reshape(-1)
+        if len(Y) != self.data_info()[1]:
+            raise ValueError(f"data_solve: {len(Y)} targets for {self.data_info()[1]} stored rows")
+        mu, choli = np.zeros(self.m), np.zeros((self.m, self.m))
+        ridge, sigma = C.c_double(0), C.c_double(0)
+        self.generation += 1
+        code = _lib.load().sgpr_data_solve(self._h, ptr(Y), int(bool(with_energies)), float(noise), ptr(mu), ptr(choli),
+                                           C.addressof(ridge), C.addressof(sigma))
+        if code == _lib.E_NOT_PD:
+            raise RuntimeError("cholesky was not successful!")  # theforce/regression/algebra.py:45-46
+        check(code)
+        self.mu, self.choli, self.ridge, self.sigma = mu, choli, ridge.value, sigma.value
+        self.make_vscale()
+        return mu
 
     def fit(self, frames, noise=0.01):
         """set_data + make_munu (gppotential.py:484-509, :548-605) for a list of labelled frames

@@ -87,10 +87,9 @@ def load_model(path, device=0, engine=None):
                                    None if np.isnan(g["data_stress"][k]).any() else g["data_stress"][k]))
         post._noise["all"] = float(g["noise_logit"])
         if X and post.data:
-            rows = [post._rows(fr) for fr in post.data]
-            post.Ke = np.concatenate([r[0] for r in rows])
-            post.Kf = np.concatenate([r[1] for r in rows])
-            post.Kv = np.concatenate([r[2] for r in rows])
+            post.restore_rows()
             if g["mu"].size:
                 post.make_stats()
+        elif post.data and post.resident:
+            post.restore_rows()
     return post

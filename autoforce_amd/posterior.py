@@ -104,14 +104,24 @@ def _r2(pred, target):
 
 
 class PosteriorPotential:
-    def __init__(self, engine, noise=0.01, sync=None):
+    def __init__(self, engine, noise=0.01, sync=None, resident=None):
         """engine: SGPRModel (or an object with the same methods);  noise: White(signal=0.01)
         (gppotential.py:234-236);  sync: optional callable(list of ndarrays) that makes rank 0's
-        copy authoritative in place (the reference's broadcasts, gppotential.py:592-596)."""
+        copy authoritative in place (the reference's broadcasts, gppotential.py:592-596).
+
+        resident: keep the design matrix [Ke; Kf; Kv] inside the engine (device memory: SGPRModel.data_push /
+        data_solve / data_matvec) instead of as host arrays here.  Default: whenever the engine offers it.  The
+        two modes run the same regression on the same numbers; `Ke`, `Kf`, `Kv`, `K` read the same in both
+        (in resident mode they are downloads, for tests and diagnostics only)."""
         self.engine = engine
         self.data = []
         m = engine.m
-        self.Ke, self.Kf, self.Kv = np.zeros((0, m)), np.zeros((0, m)), np.zeros((0, m))
+        if resident is None:
+            resident = hasattr(engine, "data_push") and getattr(engine, "resident_data", True)
+        self.resident = bool(resident)
+        if self.resident:
+            engine.data_clear()
+        self._Ke, self._Kf, self._Kv = np.zeros((0, m)), np.zeros((0, m)), np.zeros((0, m))
         self.mean = AutoMean(getattr(engine, "mean", None))
         self._noise = {"all": _logit(noise)}  # optimisation variable of _regression (:1213-1222)
         self.scaled_noise = {}
@@ -157,9 +167,56 @@ class PosteriorPotential:
     def ndata(self):
         return len(self.data)
 
+    # ------------------------------------------------------------------ the design matrix
+    def _split(self, y):
+        """A vector over the engine's stored rows (frame-major: e, 3N f, nv v) -> (e, f, v) in the
+        reference's block order."""
+        e, f, v, a = [], [], [], 0
+        for fr in self.data:
+            n3 = 3 * fr.natoms
+            e.append(y[a:a + 1]); f.append(y[a + 1:a + 1 + n3]); v.append(y[a + 1 + n3:a + 1 + n3 + fr.nv])
+            a += 1 + n3 + fr.nv
+        z = np.zeros((0,) + y.shape[1:])
+        return np.concatenate(e + [z]), np.concatenate(f + [z]), np.concatenate(v + [z])
+
+    def _blocks(self):
+        if not self.data or self.engine.m == 0:
+            z = np.zeros((0, self.engine.m))
+            return z, z, z
+        return self._split(self.engine.data_get())
+
+    def _matvec(self, v):
+        """(Ke v, Kf v, Kv v)."""
+        if self.resident:
+            return self._split(self.engine.data_matvec(v))
+        return self._Ke @ v, self._Kf @ v, self._Kv @ v
+
+    Ke = property(lambda self: self._blocks()[0] if self.resident else self._Ke,
+                  lambda self, val: setattr(self, "_Ke", val))
+    Kf = property(lambda self: self._blocks()[1] if self.resident else self._Kf,
+                  lambda self, val: setattr(self, "_Kf", val))
+    Kv = property(lambda self: self._blocks()[2] if self.resident else self._Kv,
+                  lambda self, val: setattr(self, "_Kv", val))
+
     @property
     def K(self):
-        return np.concatenate([self.Ke, self.Kf, self.Kv], axis=0)
+        return np.concatenate(self._blocks() if self.resident else [self._Ke, self._Kf, self._Kv], axis=0)
+
+    def _push(self, fr):
+        fr.check_labels()
+        self.engine.data_push(*fr.system(), fr.nv)
+
+    def restore_rows(self):
+        """Rows of every stored frame from scratch (model files keep the frames, not K)."""
+        if self.resident:
+            self.engine.data_clear()
+            for fr in self.data:
+                self._push(fr)
+        elif self.engine.m and self.data:
+            rows = [self._rows(fr) for fr in self.data]
+            self.Ke = np.concatenate([r[0] for r in rows])
+            self.Kf = np.concatenate([r[1] for r in rows])
+            self.Kv = np.concatenate([r[2] for r in rows])
 
     def targets(self):
         e = np.array([fr.energy - self.mean(fr.counts()) for fr in self.data])
@@ -175,6 +232,8 @@ class PosteriorPotential:
         close = getattr(old, "close", None)
         if close:
             close()
+        if self.resident:  # the new engine's store: the same rows, computed over the wider table
+            self.restore_rows()
 
     # ------------------------------------------------------------------ building K
     def _rows(self, fr):
@@ -185,6 +244,13 @@ class PosteriorPotential:
     def set_data(self, data, inducing):
         """gppotential.py:484-509."""
         self.data = [fr for fr in data if fr.includes_species(self.species)]
+        if self.resident:
+            self.engine.data_clear()
+            self.engine.set_inducing(list(inducing))
+            for fr in self.data:
+                self._push(fr)
+            self.make_munu()
+            return
         self.engine.set_inducing(list(inducing))
         m = self.engine.m
         rows = [self._rows(fr) for fr in self.data]
@@ -197,6 +263,10 @@ class PosteriorPotential:
         """gppotential.py:730-743.  `rows` lets a caller that already evaluated the frame's rows
         (add_1atoms_fast) hand them over."""
         for k, fr in enumerate(frames):
+            if self.resident:
+                self._push(fr)
+                self.data.append(fr)
+                continue
             ke, kf, kv = rows[k] if rows is not None else self._rows(fr)
             self.Ke = np.concatenate([self.Ke, ke])
             self.Kf = np.concatenate([self.Kf, kf])
@@ -211,6 +281,10 @@ class PosteriorPotential:
         if loc.number not in self.species:
             raise ValueError(f"LCE with Z={loc.number} is outside the species table")
         self.engine.add_inducing(loc)
+        if self.resident:  # the engine appended the column of every stored frame itself
+            if remake:
+                self.make_munu()
+            return
         q = self.engine.m - 1
         cols = [self.engine.kernel_columns(*fr.system(), q, 1) for fr in self.data]
         ke = np.concatenate([c[0][None, :] for c in cols] + [np.zeros((0, 1))])
@@ -229,19 +303,27 @@ class PosteriorPotential:
 
     def pop_1data(self, remake=True):
         n, nv = self.data[-1].natoms, self.data[-1].nv
-        self.Ke, self.Kf, self.Kv = self.Ke[:-1], self.Kf[:-3 * n], self.Kv[:len(self.Kv) - nv]
+        if self.resident:
+            self.engine.data_pop(-1)
+        else:
+            self.Ke, self.Kf, self.Kv = self.Ke[:-1], self.Kf[:-3 * n], self.Kv[:len(self.Kv) - nv]
         del self.data[-1]
         if remake:
             self.make_munu()
 
     def popfirst_1data(self, remake=True):
         n, nv = self.data[0].natoms, self.data[0].nv
-        self.Ke, self.Kf, self.Kv = self.Ke[1:], self.Kf[3 * n:], self.Kv[nv:]
+        if self.resident:
+            self.engine.data_pop(0)
+        else:
+            self.Ke, self.Kf, self.Kv = self.Ke[1:], self.Kf[3 * n:], self.Kv[nv:]
         del self.data[0]
         if remake:
             self.make_munu()
 
     def _keep_columns(self, idx):
+        if self.resident:
+            return  # the engine's edit entry points re-index the stored columns
         self.Ke, self.Kf, self.Kv = self.Ke[:, idx], self.Kf[:, idx], self.Kv[:, idx]
 
     def pop_1inducing(self, remake=True):
@@ -286,19 +368,23 @@ class PosteriorPotential:
     # ------------------------------------------------------------------ regression
     def _solve(self, with_energies, x=None):
         """One make_mu of _regression (gppotential.py:1245-1263) on the device."""
+        noise = _sigmoid(self._noise["all"] if x is None else x)
+        if self.resident:
+            Y = [np.concatenate([[fr.energy - self.mean(fr.counts())], fr.forces.reshape(-1)] +
+                                ([fr.stress * fr.get_volume()] if fr.stress is not None else [])) for fr in self.data]
+            return self.engine.data_solve(np.concatenate(Y), with_energies=with_energies, noise=noise)
         e, f, v = self.targets()
         if with_energies:
             K, Y = self.K, np.concatenate([e, f, v])
         else:
             K, Y = np.concatenate([self.Kf, self.Kv]), np.concatenate([f, v])
-        noise = _sigmoid(self._noise["all"] if x is None else x)
         return self.engine.solve(K, Y, noise=noise)
 
     def make_munu(self, algo=2, noise_f=None):
         """gppotential.py:548-605.  algo 2: plain regression; algo 3: with the hyper-parameter
         search of _regression(optimize=True) (:1265-1335) — noise such that the force-fit MAE
         meets `noise_f`, then the per-species mean offsets."""
-        if self.engine.m == 0 or self.Ke.shape[0] + self.Kf.shape[0] == 0:
+        if self.engine.m == 0 or (not self.data if self.resident else self._Ke.shape[0] + self._Kf.shape[0] == 0):
             return
         self.mean.set_data(self.data)
         if algo == 3:
@@ -341,7 +427,7 @@ class PosteriorPotential:
             x = float(np.clip(x, -14.0, 14.0))
             if x not in cache:
                 mu = self.engine.resolve(noise=_sigmoid(x))
-                cache[x] = float((np.abs(self.Kf @ mu - f).mean() - noise_f) ** 2)
+                cache[x] = float((np.abs(self._matvec(mu)[1] - f).mean() - noise_f) ** 2)
             return cache[x]
 
         x0 = float(self._noise["all"])
@@ -362,7 +448,7 @@ class PosteriorPotential:
         keys = sorted(self.mean.weights)
         nat = np.array([fr.natoms for fr in self.data], float)
         A = np.array([[fr.counts().get(z, 0) for z in keys] for fr in self.data], float) / nat[:, None]
-        b = (np.array([fr.energy for fr in self.data]) - self.Ke @ mu) / nat
+        b = (np.array([fr.energy for fr in self.data]) - self._matvec(mu)[0]) / nat
         w0 = np.array([self.mean.weights[z] for z in keys])
         w = w0 + np.linalg.lstsq(A, b - A @ w0, rcond=None)[0]
         for z, val in zip(keys, w):
@@ -373,7 +459,7 @@ class PosteriorPotential:
         n = len(self.data)
         e, f, v = self.targets()
         y = np.concatenate([e, f, v])
-        yy = self.K @ self.engine.mu
+        yy = np.concatenate(self._matvec(self.engine.mu))
         diff = yy - y
         nat = np.array([fr.natoms for fr in self.data], float)
         self._ediff = diff[:n] / nat
@@ -463,20 +549,30 @@ class PosteriorPotential:
         if len(self.data) == 0:
             if len(self.X) > 0:
                 self.add_data([fr])
+            elif self.resident:
+                self.add_data([fr], remake=False)  # stored without columns until the first inducing LCE
             else:
                 self.data.append(fr)
             return 1, inf, inf
         use_forces = fdiff < inf
-        rows = self._rows(fr)
         mu1 = self.engine.mu.copy()
-        self.add_data([fr], rows=[rows])
-        mu2 = self.engine.mu
-        e1, e2 = float(rows[0][0] @ mu1), float(rows[0][0] @ mu2)
+        if self.resident:
+            # the frame's rows never leave the device: its k·mu before and after the refit are two products
+            self.add_data([fr])
+            mu2 = self.engine.mu
+            n3 = 3 * fr.natoms
+            y1, y2 = (self.engine.data_matvec(w)[-(1 + n3 + fr.nv):] for w in (mu1, mu2))
+            e1, e2, dfr = float(y1[0]), float(y2[0]), y2[1:1 + n3] - y1[1:1 + n3]
+        else:
+            rows = self._rows(fr)
+            self.add_data([fr], rows=[rows])
+            mu2 = self.engine.mu
+            e1, e2, dfr = float(rows[0][0] @ mu1), float(rows[0][0] @ mu2), None
         de, df = abs(e1 - e2), 0.0
         if not use_forces:
             reject = de < ediff
         else:
-            d = rows[1] @ (mu2 - mu1)
+            d = dfr if dfr is not None else rows[1] @ (mu2 - mu1)
             df = float(np.abs(d).mean())
             # Normal(0, fdiff).log_prob(d).mean() > log_prob(fdiff)  <=>  mean(d^2) < fdiff^2
             reject = float((d * d).mean()) < fdiff * fdiff and float(np.abs(d).max()) < 3 * fdiff

@@ -131,6 +131,36 @@ int sgpr_kernel_columns(sgpr_model *h, int N, const int32_t *numbers, const doub
                         double *Kf, double *Kv);
 
 /*
+ * Resident training set: the regression's design matrix K = [K_e; K_f; K_v] of the stored data frames, kept in
+ * device memory for the life of the model (the reference keeps it as torch tensors next to the model:
+ * PosteriorPotential.set_data / add_data / pop_1data / popfirst_1data, regression/gppotential.py:484-509,
+ * :730-743, :793-813).  Rows are frame-major: frame f owns 1 + 3N_f + nv_f consecutive rows (its energy row, its
+ * force rows in the caller's atom order, then nv = 0 or 6 virial rows in Voigt order); columns are the inducing LCEs
+ * in the caller's order.  The inducing-set entry points below keep the columns in step (sgpr_add_inducing computes
+ * ONE new column per stored frame on the device, gppotential.py:745-772; remove / select re-index; sgpr_set_inducing
+ * recomputes), so after any sequence of edits the matrix equals what sgpr_kernel_rows would return for every frame.
+ *
+ *   sgpr_data_push    append a frame (its rows are computed on the device and stay there)
+ *   sgpr_data_pop     drop frame `index` (-1 = last: pop_1data; 0: popfirst_1data)
+ *   sgpr_data_clear   drop all frames
+ *   sgpr_data_info    number of frames / rows
+ *   sgpr_data_matvec  out[rows] = K v   (v[m] in the caller's column order): fit residuals, k·mu of a stored frame
+ *   sgpr_data_get     K[rows][m] row-major (diagnostics and tests; the product path never needs it)
+ *   sgpr_data_solve   sgpr_solve on the resident matrix: Y[rows] in the same row order; with_energies = 0 drops
+ *                     the energy rows (the force-only fit of _regression(optimize=True), gppotential.py:1265-1300);
+ *                     sgpr_resolve re-solves it for another noise as after sgpr_solve.
+ */
+int sgpr_data_push(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
+                   const int32_t *pbc, int nv);
+int sgpr_data_pop(sgpr_model *h, int index);
+int sgpr_data_clear(sgpr_model *h);
+int sgpr_data_info(sgpr_model *h, int32_t *frames, int64_t *rows);
+int sgpr_data_matvec(sgpr_model *h, const double *v, double *out);
+int sgpr_data_get(sgpr_model *h, double *K);
+int sgpr_data_solve(sgpr_model *h, const double *Y, int with_energies, double noise, double *mu_out,
+                    double *choli_out, double *ridge_out, double *sigma_out);
+
+/*
  * Inducing-set edits (PosteriorPotential.add_inducing / pop_1inducing / popfirst_1inducing /
  * select_inducing, gppotential.py:745-842, :1037-1046).  The caller's order is kept: a new LCE is
  * appended as index m; `remove` deletes one index (-1 = last); `select` keeps `indices` in the

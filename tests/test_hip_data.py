@@ -1,0 +1,150 @@
+"""GPU: the resident training set (sgpr_data_*): the design matrix [K_e; K_f; K_v] of the stored frames
+kept in device memory and edited in step with the data (add_data / pop_1data / popfirst_1data,
+regression/gppotential.py:730-743, :793-813) and with the inducing set (add_inducing :745-772, pop /
+select :782-842, :1037-1046).  After ANY sequence of edits it must equal what sgpr_kernel_rows returns
+for every stored frame (itself pinned to the reference's rows and the oracle's in test_hip_rows.py), and
+its solve must be the solve of the same matrix handed over from the host."""
+import numpy as np
+import pytest
+
+import active_common as ac
+from test_hip_parity import load, model_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def systems():
+    """Three H/O/Zr frames of different sizes: two golden ones and a rattled, strained copy."""
+    a, b = load("g5_mixed64"), load("g5_bigtric36")
+    rng = np.random.default_rng(11)
+    c = (b["numbers"], b["positions"] @ (np.eye(3) + 0.02 * rng.normal(size=(3, 3))) + 0.05 * rng.normal(size=b["positions"].shape),
+         b["cell"], b["pbc"])
+    c = (c[0], c[1], c[2] @ (np.eye(3) + 0.02 * rng.normal(size=(3, 3))), c[3])
+    return [(a["numbers"], a["positions"], a["cell"], a["pbc"]), (b["numbers"], b["positions"], b["cell"], b["pbc"]), c]
+
+
+def expected(mdl, frames, nvs):
+    """[rows, m] in the store's order (frame-major: e, 3N f, nv v) from sgpr_kernel_rows."""
+    out = []
+    for fr, nv in zip(frames, nvs):
+        ke, kf, kv = mdl.kernel_rows(*fr)
+        out += [ke[None], kf, kv[:nv]]
+    return np.concatenate(out) if out else np.zeros((0, mdl.m))
+
+
+def test_store_follows_every_edit():
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    X = list(mdl.X)
+    frames = systems()
+    nvs = [6, 0, 6]
+    mdl.set_inducing(X[:6])
+    for fr, nv in zip(frames[:2], nvs[:2]):
+        mdl.data_push(*fr, nv)
+    assert mdl.data_info() == (2, sum(1 + 3 * len(f[0]) + nv for f, nv in zip(frames[:2], nvs[:2])))
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames[:2], nvs[:2]))
+    # one new column per stored frame, computed by the library
+    for x in X[6:9]:
+        mdl.add_inducing(x)
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames[:2], nvs[:2]))
+    # a frame pushed later gets all columns
+    mdl.data_push(*frames[2], nvs[2])
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames, nvs))
+    # pops of the inducing set: last (free), first (re-index), arbitrary selection
+    mdl.remove_inducing(-1)
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames, nvs))
+    mdl.remove_inducing(0)
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames, nvs))
+    mdl.select_inducing([4, 0, 2, 5])
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames, nvs))
+    mdl.add_inducing(X[9])
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames, nvs))
+    # pops of the data: first (rows move up), last
+    mdl.data_pop(0)
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames[1:], nvs[1:]))
+    mdl.data_pop(-1)
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames[1:2], nvs[1:2]))
+    # a whole new inducing set: everything is recomputed
+    mdl.set_inducing(X[2:12])
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, frames[1:2], nvs[1:2]))
+    # products
+    v = np.random.default_rng(0).normal(size=mdl.m)
+    K = mdl.data_get()
+    np.testing.assert_allclose(mdl.data_matvec(v), K @ v, rtol=0, atol=1e-12 * np.abs(K).max() * np.abs(v).sum())
+    # errors: bad index, a species outside the table; the store is untouched by a failed push
+    from autoforce_amd import SgprError
+    with pytest.raises(SgprError):
+        mdl.data_pop(3)
+    bad = (np.full(4, 99), np.random.default_rng(1).uniform(0, 4, (4, 3)), np.eye(3) * 8.0, [True] * 3)
+    with pytest.raises(SgprError):
+        mdl.data_push(*bad, 6)
+    assert mdl.data_info()[0] == 1
+    np.testing.assert_array_equal(mdl.data_get(), K)
+    mdl.data_clear()
+    assert mdl.data_info() == (0, 0)
+    mdl.close()
+
+
+def test_frames_stored_before_the_first_inducing_lce():
+    """add_1atoms_fast with an empty X stores the frame without rows; the first add_inducing gives them
+    (gppotential.py:757-764, the numel() == 0 branch)."""
+    g = load("g5_big40")
+    full = model_from_fixture(g)
+    X = list(full.X)
+    fr = (g["numbers"], g["positions"], g["cell"], g["pbc"])
+    mdl = full.scratch()
+    mdl.set_inducing([])
+    mdl.data_push(*fr, 6)
+    assert mdl.data_info() == (1, 1 + 3 * len(fr[0]) + 6)
+    mdl.add_inducing(X[0])
+    mdl.add_inducing(X[1])
+    np.testing.assert_array_equal(mdl.data_get(), expected(mdl, [fr], [6]))
+    mdl.close(); full.close()
+
+
+@pytest.mark.parametrize("with_energies", [True, False])
+def test_resident_solve_is_the_host_solve(with_energies):
+    mdl = model_from_fixture(load("g5_mixed64"))
+    frames = systems()[:2]
+    nvs = [6, 6]
+    for fr, nv in zip(frames, nvs):
+        mdl.data_push(*fr, nv)
+    K = mdl.data_get()
+    rng = np.random.default_rng(3)
+    Y = K @ rng.normal(size=mdl.m) + 1e-3 * rng.normal(size=len(K))
+    is_e = np.zeros(len(K), bool)
+    a = 0
+    for fr, nv in zip(frames, nvs):
+        is_e[a] = True
+        a += 1 + 3 * len(fr[0]) + nv
+    ref = mdl.scratch()
+    ref.set_inducing(mdl.X)
+    keep = np.ones(len(K), bool) if with_energies else ~is_e
+    mu_h = ref.solve(K[keep], Y[keep], noise=0.02)
+    mu_d = mdl.data_solve(Y, with_energies=with_energies, noise=0.02)
+    assert mdl.ridge == ref.ridge and abs(mdl.sigma - ref.sigma) <= 1e-15 * ref.sigma
+    np.testing.assert_allclose(mdl.choli, ref.choli, rtol=0, atol=1e-12 * np.abs(ref.choli).max())
+    pred_h, pred_d = K @ mu_h, K @ mu_d
+    assert np.abs(pred_h - pred_d).max() <= 1e-9 * np.abs(pred_h).max()
+    # the cached first stage serves other noise values
+    np.testing.assert_allclose(K @ mdl.resolve(noise=0.05), K @ ref.resolve(noise=0.05), rtol=0, atol=1e-9 * np.abs(pred_h).max())
+    mdl.close(); ref.close()
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_reference_edit_sequence_in_both_modes(resident):
+    """g8: the reference's own fitted states after a sequence of data / inducing edits, with the design matrix on
+    the device (default) and as host arrays (the mode every non-HIP engine uses)."""
+    from autoforce_amd import SGPRModel
+    g = load("g5_big40")
+    eng = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=g["species"].tolist())
+    eng.resident_data = resident
+    ac.check_g8_edit_sequence(eng)
+
+
+def test_acceptance_rules_host_mode():
+    from autoforce_amd import SGPRModel
+    g = load("g5_big40")
+    eng = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=g["species"].tolist())
+    eng.resident_data = False
+    ac.check_g11_acceptance(eng)
