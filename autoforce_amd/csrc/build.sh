@@ -7,12 +7,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-variable"
 mkdir -p build
 pids=()
-for f in api descriptor neighbor gemm linalg; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ sgpr_internal.h -nt build/$f.o ] || [ ../../include/sgpr_hip.h -nt build/$f.o ] || [ solve.inc -nt build/$f.o ]; then
+for f in api descriptor neighbor gemm linalg tsqr; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ sgpr_internal.h -nt build/$f.o ] || [ ../../include/sgpr_hip.h -nt build/$f.o ] || [ solve.inc -nt build/$f.o ] || [ data.inc -nt build/$f.o ]; then
     $HIPCC $FLAGS ${EXTRA_FLAGS} -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/api.o build/descriptor.o build/neighbor.o build/gemm.o build/linalg.o -L/opt/rocm/lib -lrccl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/api.o build/descriptor.o build/neighbor.o build/gemm.o build/linalg.o build/tsqr.o -L/opt/rocm/lib -lrccl
 echo "built $(realpath $OUT)"

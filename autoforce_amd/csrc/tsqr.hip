@@ -1,0 +1,474 @@
+// tsqr.hip — Householder QR least squares for the regression of the SGPR model (regression/gppotential.py:
+// 1245-1263: mu = lstsq([K; sigma L^T], [Y; 0]) through torch.linalg.qr), communication-avoiding form for gfx950.
+//
+// The design matrix of the first stage is tall and skinny (10^5 rows of forces against m <= 2048 inducing columns).
+// A column-by-column panel factorisation of such a matrix is a chain of global reductions: two launches per column
+// over all rows (the round-1/2 kernels spent 64 ms there at 98k x 1024 for 5 ms worth of flops).  Here a 32-column
+// panel is factored by a TREE of independent workgroups instead (TSQR, Demmel et al. 2012):
+//
+//   level 0   every 256-row chunk of the panel is Householder-factored in LDS by one workgroup (no global
+//             synchronisation at all): chunk = Q_i [R_i; 0]
+//   level l   the R_i (32 rows each) are stacked, 8 to a chunk, and factored the same way ... until one R is left.
+//
+// The orthogonal factor is never formed.  Each chunk keeps its reflectors V_i and the triangular T_i of the compact
+// WY form, and the trailing matrix (the other columns and the targets) is updated chunk by chunk, level by level,
+//             A_i <- (I - V_i T_i^T V_i^T) A_i,
+// by ONE kernel per level that holds V_i (64 KB) and a 256 x 32 tile of A (64 KB) in LDS and runs both products on
+// v_mfma_f64_16x16x4_f64: the tile is read once and written once, nothing is reduced across workgroups, no atomics —
+// the result is bit-reproducible.  A panel costs 2 launches per level (4 levels at 10^5 rows) instead of 64.
+//
+// Storage: At[c][r] = A[r][c] (column c is contiguous over the rows, leading dimension ldr), as the callers build it.
+// On return the upper triangle (At[c][r], r <= c) holds R and At[cols][0:cols] holds (Q^T y)[0:cols].
+//
+// band > 0: column c is known to be zero below row band (c + 1) (the stacked triangular system of the second solve
+// stage with its rows interleaved: band = 2); a panel then only touches the rows above band (k0 + nb).
+#include <algorithm>
+#include <vector>
+
+#include "sgpr_internal.h"
+
+#define TNB 32    // panel width
+#define TCH 256   // rows per chunk (= threads per workgroup)
+#define TLD 260   // LDS leading dimension of a chunk column (doubles): 2-way bank spread for the MFMA operand reads
+#define TSB (TCH / TNB)  // R blocks per chunk of the upper levels
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct TsqrLeaf {
+    const double *src;  // element (c, i) of chunk b: src[b * chunk_stride + c * ld + i]
+    size_t chunk_stride;
+    int ld;
+    int n, nb;          // logical rows of this level, panel columns
+    double *V;          // [chunk][TNB][TCH]   reflectors (unnormalised: Q_j = I - scal_j v_j v_j^T), zero above the diagonal
+    double *T;          // [chunk][TNB][TNB]   compact WY: Q = I - V T V^T
+    double *Rnext;      // next level's chunks [chunk'][TNB][TCH] (R blocks stacked), or null at the top
+    double *Rfinal;     // top: At + k0 * ldr + k0 (column-major, ldr)
+    int ldr;
+};
+
+// wave64 sum on the DPP network (no LDS round trips): quads, half rows, rows, then the four row sums through
+// scalar registers; the result is wave-uniform
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum64(double v)
+{
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror
+    return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
+}
+
+// One chunk (<= 256 rows x <= 32 columns) factored by one workgroup with the chunk IN REGISTERS: thread (c, g) =
+// (tid & 31, tid >> 5) owns rows 32 g .. 32 g + 31 of column c for the whole factorisation.  A column step:
+//   the owner of column j has published it (v_j, zero above row j) and its norm in LDS          [barrier]
+//   every thread: 32 products of its rows with v_j -> partial sums in LDS                          [barrier]
+//   every thread: g_c = 8 partials, rank-1 update of its 32 rows; the owner of column j + 1 publishes it.
+// No cross-lane reductions at all.  V^T V (for T) is one MFMA product at the end; row t of T only depends on
+// itself, so lane t builds it alone.
+__global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
+{
+    extern __shared__ double lds[];
+    double *sm = lds;                     // [TNB][TLD]  V (masked) for the Gram product at the end
+    double *G = lds + TNB * TLD;          // [TNB][TNB + 1]:  V^T V
+    double *Ts = G + TNB * (TNB + 1);     // [TNB][TNB + 1]
+    __shared__ double vbuf[2][TCH], part[8][TNB + 1], pn[2][8], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = tid & 31, rg = tid >> 5, r0 = rg * 32;
+    const int chunk = blockIdx.x;
+    const int nr = min(TCH, q.n - chunk * TCH);
+    double a[32];
+    {
+        const double *src = q.src + chunk * q.chunk_stride + (size_t)c * q.ld + r0;
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            double2 v = make_double2(0.0, 0.0);
+            if (c < q.nb) {
+                if (r0 + k + 1 < nr) v = *(const double2 *)(src + k);
+                else if (r0 + k < nr) v.x = src[k];
+            }
+            a[k] = v.x; a[k + 1] = v.y;
+        }
+    }
+    for (int e = tid; e < TNB * (TNB + 1); e += TCH) Ts[e] = 0.0;
+    if (tid < TNB) { s_alpha[tid] = 0.0; s_scal[tid] = 0.0; s_vjj[tid] = 0.0; }
+    if (c == 0) {  // column 0 and its norm
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) { vbuf[0][r0 + k] = a[k]; s += a[k] * a[k]; }
+        pn[0][rg] = s;
+    }
+    __syncthreads();
+    for (int j = 0; j < q.nb; j++) {
+        const int jb = j & 1;
+        double s2 = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; g++) s2 += pn[jb][g];
+        const double akk = vbuf[jb][j];
+        const double nrm = sqrt(s2);
+        const double alpha = akk > 0.0 ? -nrm : nrm;
+        const double vjj = akk - alpha;
+        const double vv = s2 - akk * akk + vjj * vjj;
+        const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
+        if (tid == 0) { s_alpha[j] = alpha; s_scal[j] = sc; s_vjj[j] = vjj; }
+        const bool below = r0 + 31 >= j;  // (half-wave uniform) this row group meets the reflector
+        double vj[32], t = 0.0;
+        if (below) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                vj[k] = vbuf[jb][r0 + k];
+                if (r0 + k == j) vj[k] = vjj;
+                t += vj[k] * a[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 32; k++) vj[k] = 0.0;
+        }
+        part[rg][c] = t;
+        __syncthreads();
+        double g = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) g += part[u][c];
+        const double f = c > j ? sc * g : 0.0;
+        if (below) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) a[k] -= f * vj[k];
+        }
+        if (c == j + 1) {  // publish the next pivot column (zero above its diagonal) and its norm
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; k++) {
+                const double x = r0 + k > j ? a[k] : 0.0;
+                vbuf[jb ^ 1][r0 + k] = x;
+                s += x * x;
+            }
+            pn[jb ^ 1][rg] = s;
+        }
+        __syncthreads();
+    }
+    // V (zero above the diagonal, v_jj on it) -> LDS for the Gram product, -> global for the trailing update
+    double *V = q.V + (size_t)chunk * TNB * TCH + c * TCH + r0;
+    {
+        const double d = s_vjj[c];
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            double2 v;
+            v.x = (c < q.nb && r0 + k >= c) ? (r0 + k == c ? d : a[k]) : 0.0;
+            v.y = (c < q.nb && r0 + k + 1 >= c) ? (r0 + k + 1 == c ? d : a[k + 1]) : 0.0;
+            *(double2 *)&sm[c * TLD + r0 + k] = v;
+            *(double2 *)(V + k) = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const double *pa = sm + ((wave >> 1) * 16 + l15) * TLD + l4, *pb = sm + ((wave & 1) * 16 + l15) * TLD + l4;
+        v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 4
+        for (int k = 0; k < TCH; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k + 4 * u], pb[k + 4 * u], acc[u], 0, 0, 0);
+        }
+        const v4d w = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) G[((wave >> 1) * 16 + l4 + 4 * reg) * (TNB + 1) + (wave & 1) * 16 + l15] = w[reg];
+    }
+    __syncthreads();
+    // T[t][t] = scal_t,  T[t][j] = -scal_j sum_{l = t}^{j-1} T[t][l] (v_l . v_j):  lane t keeps row t in registers
+    // (fully unrolled: 496 multiply-adds on four interleaved chains per column, G read as LDS broadcasts)
+    if (tid < TNB) {
+        const int t = tid;
+        double Tr[TNB];
+#pragma unroll
+        for (int l = 0; l < TNB; l++) Tr[l] = l == t ? s_scal[t] : 0.0;
+#pragma unroll
+        for (int j = 1; j < TNB; j++) {
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int l = 0; l < j; l++) s4[l & 3] += Tr[l] * G[j * (TNB + 1) + l];
+            const double v = -s_scal[j] * ((s4[0] + s4[1]) + (s4[2] + s4[3]));
+            if (j > t) Tr[j] = v;
+        }
+#pragma unroll
+        for (int l = 0; l < TNB; l++) Ts[t * (TNB + 1) + l] = Tr[l];
+    }
+    __syncthreads();
+    double *T = q.T + (size_t)chunk * TNB * TNB;
+    for (int e = tid; e < TNB * TNB; e += TCH) T[e] = Ts[(e / TNB) * (TNB + 1) + e % TNB];
+    // R_i (upper triangular, alpha on the diagonal): rows 0..31 live in row group 0
+    if (rg == 0) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const double val = c < q.nb ? (k < c ? a[k] : (k == c ? s_alpha[c] : 0.0)) : 0.0;
+            if (q.Rnext) {
+                const int rho = chunk * TNB + k;
+                q.Rnext[(size_t)(rho / TCH) * TNB * TCH + c * TCH + rho % TCH] = val;
+            } else if (c < q.nb && k <= c) {
+                q.Rfinal[(size_t)c * q.ldr + k] = val;
+            }
+        }
+    }
+}
+
+struct TsqrApply {
+    double *A;        // trailing columns: A[c * ldr + physical row]
+    int ldr, ntrail;
+    int row0, row_end;  // physical rows of the panel: [row0, row_end)
+    int n;            // logical rows of this level
+    int stride;       // physical rows between consecutive 32-row blocks of the logical numbering (32: contiguous)
+    int tpw;          // column tiles per workgroup
+    const double *V;  // [chunk][TNB][TCH]
+    const double *T;  // [chunk][TNB][TNB]
+};
+
+// A_i <- A_i - V_i (T_i^T (V_i^T A_i)) for one chunk and a run of `tpw` tiles of 32 trailing columns: V_i and T_i are
+// loaded once, the next tile of A is in flight (registers) while the current one is worked on in LDS.
+// W = V^T A: four 16 x 16 blocks, one per wave, the 256-deep contraction on four interleaved accumulators;
+// Z = T^T W: one 16 x 16 block per wave; A -= V Z: 16 row blocks x 2 column blocks, four row blocks per wave.
+__global__ __launch_bounds__(TCH) void tsqr_apply_kernel(TsqrApply q)
+{
+    extern __shared__ double lds[];
+    double *Vs = lds;                    // [TNB][TLD]   Vs[i][r] = V[r][i]
+    double *As = lds + TNB * TLD;        // [TNB][TLD]   As[c][r] = A[r][c]
+    double *Ts = As + TNB * TLD;         // [TNB][TNB + 1]
+    double *Ws = Ts + TNB * (TNB + 1);   // [TNB][TNB + 1]
+    double *Zs = Ws + TNB * (TNB + 1);   // [TNB][TNB + 1]  (-Z)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int chunk = blockIdx.y;
+    const int tile0 = blockIdx.x * q.tpw, tile1 = min(tile0 + q.tpw, (q.ntrail + TNB - 1) / TNB);
+    // rows (2p, 2p + 1) of the chunk x 16 columns per thread; logical row -> physical row of the matrix
+    const int p = tid & 127, h = tid >> 7;
+    const int rho = chunk * TCH + 2 * p;
+    const int phys = q.row0 + (rho >> 5) * q.stride + (rho & 31);
+    const bool live0 = rho < q.n && phys < q.row_end, live1 = rho + 1 < q.n && phys + 1 < q.row_end;
+    const double *V = q.V + (size_t)chunk * TNB * TCH;
+    double2 aa[16];
+    auto fetch = [&](int tile) {
+        const int c0 = tile * TNB, nc = min(TNB, q.ntrail - c0);
+        const double *A = q.A + (size_t)c0 * q.ldr + phys;
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int c = 16 * h + u;
+            const double *a = A + (size_t)c * q.ldr;
+            aa[u] = make_double2(0.0, 0.0);
+            if (c < nc) {
+                if (live1) aa[u] = *(const double2 *)a;
+                else if (live0) aa[u].x = a[0];
+            }
+        }
+    };
+    fetch(tile0);
+    {
+        double2 vv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) vv[u] = *(const double2 *)&V[(16 * h + u) * TCH + 2 * p];
+#pragma unroll
+        for (int u = 0; u < 16; u++) *(double2 *)&Vs[(16 * h + u) * TLD + 2 * p] = vv[u];
+    }
+    for (int e = tid; e < TNB * TNB; e += TCH) Ts[(e / TNB) * (TNB + 1) + e % TNB] = q.T[(size_t)chunk * TNB * TNB + e];
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int i0 = (wave >> 1) * 16, cc0 = (wave & 1) * 16;
+    for (int tile = tile0; tile < tile1; tile++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) *(double2 *)&As[(16 * h + u) * TLD + 2 * p] = aa[u];
+        __syncthreads();
+        if (tile + 1 < tile1) fetch(tile + 1);
+        {
+            // W[i][c] = sum_r V[r][i] A[r][c]:  A operand (row i, k = r), B operand (k = r, col c)
+            v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const double *va = Vs + (i0 + l15) * TLD + l4;
+            const double *ab = As + (cc0 + l15) * TLD + l4;
+#pragma unroll 4
+            for (int k = 0; k < TCH; k += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[k + 4 * u], ab[k + 4 * u], acc[u], 0, 0, 0);
+            }
+            const v4d w = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Ws[(i0 + l4 + 4 * reg) * (TNB + 1) + cc0 + l15] = w[reg];
+        }
+        __syncthreads();
+        {
+            // -Z[i][c] = -sum_l T[l][i] W[l][c]:  A operand (row i, k = l) = T[l][i], B operand (k = l, col c) = W[l][c]
+            v4d acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int k = 0; k < TNB; k += 8) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[(k + l4) * (TNB + 1) + i0 + l15], Ws[(k + l4) * (TNB + 1) + cc0 + l15], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[(k + 4 + l4) * (TNB + 1) + i0 + l15], Ws[(k + 4 + l4) * (TNB + 1) + cc0 + l15], acc[1], 0, 0, 0);
+            }
+            const v4d z = acc[0] + acc[1];
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) Zs[(i0 + l4 + 4 * reg) * (TNB + 1) + cc0 + l15] = -z[reg];
+        }
+        __syncthreads();
+        {
+            // A[r][c] += sum_i V[r][i] (-Z)[i][c]:  A operand (row r, k = i), B operand (k = i, col c); C/D: col = lane & 15,
+            // row = (lane >> 4) + 4 reg
+            const int r0 = wave * 64;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+                v4d acc[4];
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) acc[rb][reg] = As[(16 * cb + l15) * TLD + r0 + 16 * rb + l4 + 4 * reg];
+#pragma unroll
+                for (int k = 0; k < TNB; k += 4) {
+                    const double zb = Zs[(k + l4) * (TNB + 1) + 16 * cb + l15];
+#pragma unroll
+                    for (int rb = 0; rb < 4; rb++)
+                        acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[(k + l4) * TLD + r0 + 16 * rb + l15], zb, acc[rb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) As[(16 * cb + l15) * TLD + r0 + 16 * rb + l4 + 4 * reg] = acc[rb][reg];
+            }
+        }
+        __syncthreads();
+        {
+            const int c0 = tile * TNB, nc = min(TNB, q.ntrail - c0);
+            double *A = q.A + (size_t)c0 * q.ldr + phys;
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int c = 16 * h + u;
+                if (c < nc) {
+                    const double2 v = *(const double2 *)&As[c * TLD + 2 * p];
+                    double *a = A + (size_t)c * q.ldr;
+                    if (live1) *(double2 *)a = v;
+                    else if (live0) a[0] = v.x;
+                }
+            }
+        }
+        __syncthreads();  // As is overwritten by the next tile
+    }
+}
+
+__global__ void qr_gather_r_kernel(int cols, const double *At, int ldr, double *Rm /*[cols][cols]*/, double *z)
+{
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cols && j < cols) Rm[(size_t)i * cols + j] = j >= i ? At[(size_t)j * ldr + i] : 0.0;
+    if (i < cols && j == 0) z[i] = At[(size_t)cols * ldr + i];
+}
+
+// back substitution R x = z, R row-major [cols][cols]: one workgroup, x kept in LDS
+__global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const double *A, const double *y, double *x)
+{
+    __shared__ double red[16];
+    __shared__ double xs[2048];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int k = cols - 1; k >= 0; k--) {
+        double s = 0.0;
+        for (int j = k + 1 + tid; j < cols; j += 1024) s += A[(size_t)k * cols + j] * xs[j];
+        s = wave_sum64(s);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) t += red[w];
+            xs[k] = (y[k] - t) / A[(size_t)k * cols + k];
+            x[k] = xs[k];
+        }
+        __syncthreads();
+    }
+}
+
+// chunks of every level of the tree over n rows (level 0 first)
+static void tsqr_levels(int n, std::vector<int> &chunks)
+{
+    chunks.clear();
+    for (;;) {
+        const int c = (n + TCH - 1) / TCH;
+        chunks.push_back(c);
+        if (c == 1) break;
+        n = c * TNB;
+    }
+}
+
+size_t lstsq_qr_blocked_work_doubles(int rows, int cols)
+{
+    std::vector<int> ch;
+    tsqr_levels(std::max(rows, 1), ch);
+    size_t total = 0;
+    for (int c : ch) total += (size_t)c * (2 * TNB * TCH + TNB * TNB);  // V, stacked R of the level above, T
+    return total + (size_t)cols * cols + cols + 64;
+}
+
+int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band)
+{
+    if (cols > 2048 || rows < cols || ldr < rows) return -1;
+    static bool attr_done = false;
+    const size_t lds_leaf = sizeof(double) * (TNB * TLD + 2 * TNB * (TNB + 1));
+    const size_t lds_apply = sizeof(double) * (2 * TNB * TLD + 3 * TNB * (TNB + 1));
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)tsqr_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf);
+        (void)hipFuncSetAttribute((const void *)tsqr_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply);
+        attr_done = true;
+    }
+    std::vector<int> ch;
+    tsqr_levels(rows, ch);
+    // per-level work arrays, sized for the first (tallest) panel
+    std::vector<double *> Vl(ch.size()), Tl(ch.size()), Sl(ch.size());
+    double *w = work;
+    for (size_t l = 0; l < ch.size(); l++) {
+        Vl[l] = w; w += (size_t)ch[l] * TNB * TCH;
+        Sl[l] = w; w += (size_t)ch[l] * TNB * TCH;  // input of level l (unused at level 0)
+        Tl[l] = w; w += (size_t)ch[l] * TNB * TNB;
+    }
+    double *Rm = w; w += (size_t)cols * cols;
+    double *z = w; w += cols;
+    for (int k0 = 0; k0 < cols; k0 += TNB) {
+        const int nb = std::min(TNB, cols - k0);
+        const int row_end = band > 0 ? std::min(rows, band * (k0 + nb)) : rows;
+        const int ntrail = cols + 1 - (k0 + nb);
+        int n = row_end - k0, stride = TNB;
+        for (int l = 0;; l++) {
+            const int chunks = (n + TCH - 1) / TCH;
+            const bool top = chunks == 1;
+            TsqrLeaf lf = {};
+            if (l == 0) { lf.src = At + (size_t)k0 * ldr + k0; lf.chunk_stride = TCH; lf.ld = ldr; }
+            else { lf.src = Sl[l]; lf.chunk_stride = (size_t)TNB * TCH; lf.ld = TCH; }
+            lf.n = n; lf.nb = nb;
+            lf.V = Vl[l]; lf.T = Tl[l];
+            lf.Rnext = top ? nullptr : Sl[l + 1];
+            lf.Rfinal = At + (size_t)k0 * ldr + k0;
+            lf.ldr = ldr;
+            hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks), dim3(TCH), lds_leaf, st, lf);
+            if (ntrail > 0) {
+                TsqrApply ap = {};
+                ap.A = At + (size_t)(k0 + nb) * ldr;
+                ap.ldr = ldr; ap.ntrail = ntrail;
+                ap.row0 = k0; ap.row_end = row_end;
+                ap.n = n; ap.stride = stride;
+                ap.V = Vl[l]; ap.T = Tl[l];
+                // enough workgroups to fill the chip several times over, else as many tiles per workgroup as possible
+                const int ntiles = (ntrail + TNB - 1) / TNB;
+                ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * chunks / 1024)));
+                hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, chunks), dim3(TCH), lds_apply, st, ap);
+            }
+            if (top) break;
+            n = chunks * TNB;
+            stride = l == 0 ? TCH : stride * TSB;
+        }
+    }
+    if (x) {
+        hipLaunchKernelGGL(qr_gather_r_kernel, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rm, z);
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rm, z, x);
+    }
+    return 0;
+}
+
+void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st)
+{
+    hipLaunchKernelGGL(qr_gather_r_kernel, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rm, z);
+}

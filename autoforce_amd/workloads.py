@@ -28,10 +28,11 @@ def _rattled_lattice(shape, spacing, sigma, rng, dmin=1.6):
 def lips(n_side=16, seed=0, sigma=0.15):
     """C3/C4: "LiPS" 16^3 = 4096 simple-cubic sites, 2.72 A, 1536 Li / 512 P / 2048 S."""
     rng = np.random.default_rng(seed)
-    N = n_side**3
+    dims = tuple(n_side) if np.ndim(n_side) else (n_side,) * 3  # (32, 32, 16): the 16384 atoms of config 5
+    N = int(np.prod(dims))
     nLi, nP = 3 * N // 8, N // 8
     numbers = rng.permutation(np.array([3] * nLi + [15] * nP + [16] * (N - nLi - nP))).astype(np.int32)
-    pos, cell = _rattled_lattice((n_side,) * 3, 2.72, sigma, rng)
+    pos, cell = _rattled_lattice(dims, 2.72, sigma, rng)
     return numbers, pos, cell, np.array([True, True, True])
 
 
