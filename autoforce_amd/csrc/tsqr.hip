@@ -68,43 +68,48 @@ __device__ __forceinline__ double wave_sum64(double v)
     return (lane_f64(v, 0) + lane_f64(v, 16)) + (lane_f64(v, 32) + lane_f64(v, 48));
 }
 
-// One chunk (<= 256 rows x <= 32 columns) factored by one workgroup with the chunk IN REGISTERS: thread (c, g) =
-// (tid & 31, tid >> 5) owns rows 32 g .. 32 g + 31 of column c for the whole factorisation.  A column step:
+// One chunk (<= 256 rows x <= 32 columns) factored by one workgroup of 512 threads with the chunk IN REGISTERS:
+// thread (c, g) = (tid & 31, tid >> 5) owns rows 16 g .. 16 g + 15 of column c for the whole factorisation.
+// A column step:
 //   the owner of column j has published it (v_j, zero above row j) and its norm in LDS          [barrier]
-//   every thread: 32 products of its rows with v_j -> partial sums in LDS                          [barrier]
-//   every thread: g_c = 8 partials, rank-1 update of its 32 rows; the owner of column j + 1 publishes it.
-// No cross-lane reductions at all.  V^T V (for T) is one MFMA product at the end; row t of T only depends on
-// itself, so lane t builds it alone.
-__global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
+//   every thread: 16 products of its rows with v_j -> partial sums in LDS                          [barrier]
+//   every thread: g_c = 16 partials, rank-1 update of its 16 rows; the owner of column j + 1 publishes it.
+// No cross-lane reductions.  Pivots only ever sit in rows 0..31 (wave 0): every other wave runs without a single
+// mask.  Two waves per SIMD hide each other's latencies (the step is a chain of dependent short operations).
+// V^T V (for T) is one MFMA product at the end; T is built in 16 x 16 blocks.
+#define TLT 512  // threads of the leaf kernel
+#define TRG 16   // rows per thread
+__global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
 {
     extern __shared__ double lds[];
     double *sm = lds;                     // [TNB][TLD]  V (masked) for the Gram product at the end
     double *G = lds + TNB * TLD;          // [TNB][TNB + 1]:  V^T V
     double *Ts = G + TNB * (TNB + 1);     // [TNB][TNB + 1]
-    __shared__ double vbuf[2][TCH], part[8][TNB + 1], pn[2][8], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
+    __shared__ __attribute__((aligned(16))) double vbuf[2][TCH], pn[2][16];
+    __shared__ double part[16][TNB + 1], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int c = tid & 31, rg = tid >> 5, r0 = rg * 32;
+    const int c = tid & 31, rg = tid >> 5, r0 = rg * TRG;
     const int chunk = blockIdx.x;
     const int nr = min(TCH, q.n - chunk * TCH);
-    double a[32];
+    double a[TRG];
     {
-        const double *src = q.src + chunk * q.chunk_stride + (size_t)c * q.ld + r0;
+        // (branch-free: a dead pair reads the chunk's first element instead; a pair cut by the end of the matrix reads
+        // one element of padding — ldr is a multiple of 64 — and drops it)
+        const double *col = q.src + chunk * q.chunk_stride + (size_t)(c < q.nb ? c : 0) * q.ld;
 #pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-            double2 v = make_double2(0.0, 0.0);
-            if (c < q.nb) {
-                if (r0 + k + 1 < nr) v = *(const double2 *)(src + k);
-                else if (r0 + k < nr) v.x = src[k];
-            }
-            a[k] = v.x; a[k + 1] = v.y;
+        for (int k = 0; k < TRG; k += 2) {
+            const bool ok0 = c < q.nb && r0 + k < nr, ok1 = c < q.nb && r0 + k + 1 < nr;
+            const double2 v = *(const double2 *)(col + (ok0 ? r0 + k : 0));
+            a[k] = ok0 ? v.x : 0.0;
+            a[k + 1] = ok1 ? v.y : 0.0;
         }
     }
-    for (int e = tid; e < TNB * (TNB + 1); e += TCH) Ts[e] = 0.0;
+    for (int e = tid; e < TNB * (TNB + 1); e += TLT) Ts[e] = 0.0;
     if (tid < TNB) { s_alpha[tid] = 0.0; s_scal[tid] = 0.0; s_vjj[tid] = 0.0; }
     if (c == 0) {  // column 0 and its norm
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < 32; k++) { vbuf[0][r0 + k] = a[k]; s += a[k] * a[k]; }
+        for (int k = 0; k < TRG; k++) { vbuf[0][r0 + k] = a[k]; s += a[k] * a[k]; }
         pn[0][rg] = s;
     }
     __syncthreads();
@@ -112,7 +117,10 @@ __global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
         const int jb = j & 1;
         double s2 = 0.0;
 #pragma unroll
-        for (int g = 0; g < 8; g++) s2 += pn[jb][g];
+        for (int g = 0; g < 16; g += 2) {
+            const double2 x = *(const double2 *)&pn[jb][g];
+            s2 += x.x + x.y;
+        }
         const double akk = vbuf[jb][j];
         const double nrm = sqrt(s2);
         const double alpha = akk > 0.0 ? -nrm : nrm;
@@ -120,38 +128,55 @@ __global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
         const double vv = s2 - akk * akk + vjj * vjj;
         const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
         if (tid == 0) { s_alpha[j] = alpha; s_scal[j] = sc; s_vjj[j] = vjj; }
-        const bool below = r0 + 31 >= j;  // (half-wave uniform) this row group meets the reflector
-        double vj[32], t = 0.0;
-        if (below) {
+        // pivot row relative to this row group (uniform over a half wave): < 0: every row of the group is below the
+        // pivot (no masks anywhere), 0..15: the pivot group, >= 16: the group is done (rows of R) and sits the step out
+        const int jj = j - r0;
+        double vj[TRG], t4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (jj < TRG) {
 #pragma unroll
-            for (int k = 0; k < 32; k++) {
-                vj[k] = vbuf[jb][r0 + k];
-                if (r0 + k == j) vj[k] = vjj;
-                t += vj[k] * a[k];
+            for (int k = 0; k < TRG; k += 2) {
+                const double2 x = *(const double2 *)&vbuf[jb][r0 + k];
+                vj[k] = x.x; vj[k + 1] = x.y;
             }
-        } else {
+            if (jj >= 0) {
 #pragma unroll
-            for (int k = 0; k < 32; k++) vj[k] = 0.0;
+                for (int k = 0; k < TRG; k++)
+                    if (k == jj) vj[k] = vjj;
+            }
+#pragma unroll
+            for (int k = 0; k < TRG; k++) t4[k & 3] += vj[k] * a[k];
         }
-        part[rg][c] = t;
+        part[rg][c] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
         __syncthreads();
-        double g = 0.0;
+        double g4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 8; u++) g += part[u][c];
-        const double f = c > j ? sc * g : 0.0;
-        if (below) {
+        for (int u = 0; u < 16; u++) g4[u & 3] += part[u][c];
+        const double f = c > j ? sc * ((g4[0] + g4[1]) + (g4[2] + g4[3])) : 0.0;
+        if (jj < TRG) {
 #pragma unroll
-            for (int k = 0; k < 32; k++) a[k] -= f * vj[k];
+            for (int k = 0; k < TRG; k++) a[k] -= f * vj[k];
         }
         if (c == j + 1) {  // publish the next pivot column (zero above its diagonal) and its norm
-            double s = 0.0;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (jj < 0) {
 #pragma unroll
-            for (int k = 0; k < 32; k++) {
-                const double x = r0 + k > j ? a[k] : 0.0;
-                vbuf[jb ^ 1][r0 + k] = x;
-                s += x * x;
+                for (int k = 0; k < TRG; k += 2) {
+                    *(double2 *)&vbuf[jb ^ 1][r0 + k] = make_double2(a[k], a[k + 1]);
+                    s4[k & 3] += a[k] * a[k];
+                    s4[(k + 1) & 3] += a[k + 1] * a[k + 1];
+                }
+            } else if (jj >= TRG - 1) {
+#pragma unroll
+                for (int k = 0; k < TRG; k += 2) *(double2 *)&vbuf[jb ^ 1][r0 + k] = make_double2(0.0, 0.0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < TRG; k++) {
+                    const double x = k > jj ? a[k] : 0.0;
+                    vbuf[jb ^ 1][r0 + k] = x;
+                    s4[k & 3] += x * x;
+                }
             }
-            pn[jb ^ 1][rg] = s;
+            pn[jb ^ 1][rg] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         }
         __syncthreads();
     }
@@ -160,7 +185,7 @@ __global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
     {
         const double d = s_vjj[c];
 #pragma unroll
-        for (int k = 0; k < 32; k += 2) {
+        for (int k = 0; k < TRG; k += 2) {
             double2 v;
             v.x = (c < q.nb && r0 + k >= c) ? (r0 + k == c ? d : a[k]) : 0.0;
             v.y = (c < q.nb && r0 + k + 1 >= c) ? (r0 + k + 1 == c ? d : a[k + 1]) : 0.0;
@@ -169,7 +194,7 @@ __global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
         }
     }
     __syncthreads();
-    {
+    if (wave < 4) {
         const int l15 = lane & 15, l4 = lane >> 4;
         const double *pa = sm + ((wave >> 1) * 16 + l15) * TLD + l4, *pb = sm + ((wave & 1) * 16 + l15) * TLD + l4;
         v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -183,37 +208,57 @@ __global__ __launch_bounds__(TCH) void tsqr_leaf_kernel(TsqrLeaf q)
         for (int reg = 0; reg < 4; reg++) G[((wave >> 1) * 16 + l4 + 4 * reg) * (TNB + 1) + (wave & 1) * 16 + l15] = w[reg];
     }
     __syncthreads();
-    // T[t][t] = scal_t,  T[t][j] = -scal_j sum_{l = t}^{j-1} T[t][l] (v_l . v_j):  lane t keeps row t in registers
-    // (fully unrolled: 496 multiply-adds on four interleaved chains per column, G read as LDS broadcasts)
+    // T = [T11 T12; 0 T22] in 16 x 16 blocks.  Diagonal blocks: T[t][t] = scal_t, T[t][j] = -scal_j sum_{l=t}^{j-1}
+    // T[t][l] (v_l . v_j) — row t only depends on itself: lane t of each half keeps it in registers (120 multiply-adds,
+    // unrolled).  Then T12 = -T11 (V1^T V2) T22 by 256 threads.
     if (tid < TNB) {
-        const int t = tid;
-        double Tr[TNB];
+        const int t = tid & 15, base = tid & 16;
+        double Tr[16];
 #pragma unroll
-        for (int l = 0; l < TNB; l++) Tr[l] = l == t ? s_scal[t] : 0.0;
+        for (int l = 0; l < 16; l++) Tr[l] = l == t ? s_scal[base + t] : 0.0;
 #pragma unroll
-        for (int j = 1; j < TNB; j++) {
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = 1; j < 16; j++) {
+            double s2[2] = {0.0, 0.0};
 #pragma unroll
-            for (int l = 0; l < j; l++) s4[l & 3] += Tr[l] * G[j * (TNB + 1) + l];
-            const double v = -s_scal[j] * ((s4[0] + s4[1]) + (s4[2] + s4[3]));
+            for (int l = 0; l < j; l++) s2[l & 1] += Tr[l] * G[(base + j) * (TNB + 1) + base + l];
+            const double v = -s_scal[base + j] * (s2[0] + s2[1]);
             if (j > t) Tr[j] = v;
         }
 #pragma unroll
-        for (int l = 0; l < TNB; l++) Ts[t * (TNB + 1) + l] = Tr[l];
+        for (int l = 0; l < 16; l++) Ts[(base + t) * (TNB + 1) + base + l] = Tr[l];
+    }
+    __syncthreads();
+    {
+        double *Xs = &part[0][0];  // [16][16]: (V1^T V2) T22
+        const int ia = (tid >> 4) & 15, ib = tid & 15;
+        if (tid < 256) {
+            double x = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) x += G[ia * (TNB + 1) + 16 + l] * Ts[(16 + l) * (TNB + 1) + 16 + ib];
+            Xs[ia * 16 + ib] = x;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            double y = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) y += Ts[ia * (TNB + 1) + l] * Xs[l * 16 + ib];
+            Ts[ia * (TNB + 1) + 16 + ib] = -y;
+        }
     }
     __syncthreads();
     double *T = q.T + (size_t)chunk * TNB * TNB;
-    for (int e = tid; e < TNB * TNB; e += TCH) T[e] = Ts[(e / TNB) * (TNB + 1) + e % TNB];
-    // R_i (upper triangular, alpha on the diagonal): rows 0..31 live in row group 0
-    if (rg == 0) {
+    for (int e = tid; e < TNB * TNB; e += TLT) T[e] = Ts[(e / TNB) * (TNB + 1) + e % TNB];
+    // R_i (upper triangular, alpha on the diagonal): rows 0..31 live in row groups 0 and 1
+    if (rg < 2) {
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
-            const double val = c < q.nb ? (k < c ? a[k] : (k == c ? s_alpha[c] : 0.0)) : 0.0;
+        for (int k = 0; k < TRG; k++) {
+            const int r = r0 + k;
+            const double val = c < q.nb ? (r < c ? a[k] : (r == c ? s_alpha[c] : 0.0)) : 0.0;
             if (q.Rnext) {
-                const int rho = chunk * TNB + k;
+                const int rho = chunk * TNB + r;
                 q.Rnext[(size_t)(rho / TCH) * TNB * TCH + c * TCH + rho % TCH] = val;
-            } else if (c < q.nb && k <= c) {
-                q.Rfinal[(size_t)c * q.ldr + k] = val;
+            } else if (c < q.nb && r <= c) {
+                q.Rfinal[(size_t)c * q.ldr + r] = val;
             }
         }
     }
@@ -443,7 +488,7 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
             lf.Rnext = top ? nullptr : Sl[l + 1];
             lf.Rfinal = At + (size_t)k0 * ldr + k0;
             lf.ldr = ldr;
-            hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks), dim3(TCH), lds_leaf, st, lf);
+            hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks), dim3(TLT), lds_leaf, st, lf);
             if (ntrail > 0) {
                 TsqrApply ap = {};
                 ap.A = At + (size_t)(k0 + nb) * ldr;
