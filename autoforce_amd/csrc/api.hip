@@ -141,6 +141,14 @@ struct sgpr_model {
     DevBuf<double> d_design, d_qr_A, d_qr_work;
     int64_t design_rcap = 0, design_ccap = 0, design_rows = 0;
     bool design_hold = false;  // an edit entry point is re-indexing the columns itself
+    // identity of the matrix: one id per stored frame and per inducing column (a pop returns to the earlier lists),
+    // and the first-stage factors of the last few (matrix, targets) pairs: a rejected trial (add, refit, pop, refit:
+    // gppotential.py:898-982) finds its second refit here
+    std::vector<int64_t> frame_ids, col_ids;
+    int64_t next_id = 1;
+    struct R1Entry { uint64_t key[2] = {0, 0}; int m = 0; DevBuf<double> r1; uint64_t age = 0; };
+    R1Entry r1_cache[4];
+    uint64_t r1_clock = 0;
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
     DevBuf<double> d_edit_tmp;  // scratch of the incremental inducing-set edits
@@ -483,6 +491,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                             &h->d_rows_bG, &h->d_rows_bF, &h->d_rows_bV, &h->d_design, &h->d_qr_A, &h->d_qr_work};
     for (auto b : db) b->release();
     h->d_rows_cols.release();
+    for (auto &e : h->r1_cache) e.r1.release();
     h->d_pack.release();
     h->d_T.release();
     h->d_hm.release();
@@ -601,6 +610,7 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
 static int alloc_work(sgpr_model *h);
 static int design_after_set(sgpr_model *h);   // data.inc: the resident design matrix follows the inducing set
 static int design_after_add(sgpr_model *h);
+static void design_after_pop_last(sgpr_model *h);
 static int design_select(sgpr_model *h, int count, const int32_t *idx);
 
 extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const int64_t *nbr_ptr,

@@ -232,11 +232,11 @@ class SGPRModel:
     def resolve(self, noise=0.01):
         """The same regression for another noise, re-using the factored [K | Y] of the last `solve`
         (the evaluations of _regression(optimize=True), gppotential.py:1265-1300)."""
-        mu, choli = np.zeros(self.m), np.zeros((self.m, self.m))
+        mu = np.zeros(self.m)
         ridge, sigma = C.c_double(0), C.c_double(0)
-        check(_lib.load().sgpr_resolve(self._h, float(noise), ptr(mu), ptr(choli), C.addressof(ridge),
-                                       C.addressof(sigma)))
-        self.mu, self.choli, self.ridge, self.sigma = mu, choli, ridge.value, sigma.value
+        # (choli = L^-1 and the ridge do not depend on the noise: they stay what the last solve returned)
+        check(_lib.load().sgpr_resolve(self._h, float(noise), ptr(mu), None, C.addressof(ridge), C.addressof(sigma)))
+        self.mu, self.ridge, self.sigma = mu, ridge.value, sigma.value
         return mu
 
     def kernel_rows(self, numbers, positions, cell, pbc):

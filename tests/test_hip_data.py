@@ -148,3 +148,47 @@ def test_acceptance_rules_host_mode():
     eng = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=g["species"].tolist())
     eng.resident_data = False
     ac.check_g11_acceptance(eng)
+
+
+def test_refit_after_a_rejected_trial():
+    """add_1inducing / add_1atoms_fast (gppotential.py:898-982) try an edit, refit, and on rejection pop it and refit
+    again: the second refit must reproduce the fit before the trial exactly (the library may serve its first
+    stage from the factors it kept), and different targets must not."""
+    mdl = model_from_fixture(load("g5_mixed64"))
+    X = list(mdl.X)
+    frames = systems()
+    mdl.set_inducing(X[:20])
+    for fr in frames[:2]:
+        mdl.data_push(*fr, 6)
+    rng = np.random.default_rng(9)
+    Y = rng.normal(size=mdl.data_info()[1])
+    mu0 = mdl.data_solve(Y, noise=0.02).copy()
+    # inducing trial
+    mdl.add_inducing(X[20])
+    mu1 = mdl.data_solve(Y, noise=0.02).copy()
+    assert len(mu1) == 21
+    mdl.remove_inducing(-1)
+    np.testing.assert_array_equal(mdl.data_solve(Y, noise=0.02), mu0)
+    # data trial
+    mdl.data_push(*frames[2], 6)
+    Y3 = np.concatenate([Y, rng.normal(size=mdl.data_info()[1] - len(Y))])
+    mu3 = mdl.data_solve(Y3, noise=0.02).copy()
+    mdl.data_pop(-1)
+    np.testing.assert_array_equal(mdl.data_solve(Y, noise=0.02), mu0)
+    # other targets, other noise, force-only fit: each its own answer, equal to a model that never cached anything
+    ref = mdl.scratch()
+    ref.set_inducing(mdl.X)
+    K = mdl.data_get()
+    Y2 = Y.copy(); Y2[5] += 1.0
+    for args, kw in (((Y2,), dict(noise=0.02)), ((Y,), dict(noise=0.05)), ((Y,), dict(noise=0.02, with_energies=False))):
+        got = mdl.data_solve(*args, **kw)
+        keep = np.ones(len(K), bool)
+        if not kw.get("with_energies", True):
+            a = 0
+            for fr in frames[:2]:
+                keep[a] = False
+                a += 1 + 3 * len(fr[0]) + 6
+        want = ref.solve(K[keep], args[0][keep], noise=kw["noise"])
+        assert np.abs(K @ got - K @ want).max() <= 1e-9 * np.abs(K @ want).max()
+    assert np.abs(mu3).max() > 0 and np.abs(mu1).max() > 0
+    mdl.close(); ref.close()

@@ -46,3 +46,7 @@ tm("pop_1data (+ refit)", post.pop_1data)
 tm("add_1atoms_fast trial (push, refit, 2 products, [pop, refit])", lambda: post.add_1atoms_fast(frames[nfr], 1e9, 1e9))
 tm("make_munu(algo=3) (noise search: 1 force-only factor + ~15 resolves)", lambda: post.make_munu(algo=3, noise_f=0.05))
 os.environ["SGPR_SOLVE_TIMING"] = "1"
+if os.environ.get("SGPR_PROFILE_OPT"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); post.make_munu(algo=3, noise_f=0.05); post.add_1inducing(X[m], 1e9); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
