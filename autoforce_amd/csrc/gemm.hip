@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         if (rt >= g.row_tiles) return;
     }
     const int row0 = rt * BMT, col0 = ct * BN;
-    const bool skip = (EPI == EPI_SUBLOWER && col0 > row0);  // symmetric update: lower tiles only (EPI_SUB: all)
+    const bool skip = (EPI == EPI_SUBLOWER && col0 > row0);  // symmetric update: lower tiles only
 
     v4d acc[TM][2];
 #pragma unroll
@@ -198,10 +198,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                     const double v = acc[tm][tn][r];
                     if (EPI == EPI_STORE || (EPI == EPI_WCOV && !second)) {
                         if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = v;
-                    } else if (EPI == EPI_SUBLOWER || EPI == EPI_SUB) {
+                    } else if (EPI == EPI_SUBLOWER) {
                         if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] -= v;
-                    } else if (EPI == EPI_ATOMIC) {
-                        if (row < p.M && col < p.N && v != 0.0) unsafeAtomicAdd(&p.C[(size_t)row * p.ldc + col], v);
                     } else if (EPI == EPI_KERNEL) {
                         // branch-free: per-row / per-column metadata was fetched before the main
                         // loop (a load inside a data-dependent branch cost one L2 round trip per
@@ -287,7 +285,5 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
     else if (epi == EPI_KERNEL && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_KERNEL, 1>), grid, block, 0, st, g);
     else if (epi == EPI_KERNEL) hipLaunchKernelGGL(gemm_nt_kernel<EPI_KERNEL>, grid, block, 0, st, g);
     else if (epi == EPI_SUBLOWER) hipLaunchKernelGGL(gemm_nt_kernel<EPI_SUBLOWER>, grid, block, 0, st, g);
-    else if (epi == EPI_SUB) hipLaunchKernelGGL(gemm_nt_kernel<EPI_SUB>, grid, block, 0, st, g);
-    else if (epi == EPI_ATOMIC) hipLaunchKernelGGL((gemm_nt_kernel<EPI_ATOMIC, 1>), grid, block, 0, st, g);
     else hipLaunchKernelGGL(gemm_nt_kernel<EPI_ROWSQ>, grid, block, 0, st, g);
 }

@@ -147,8 +147,7 @@ void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpa
                                const double *Pp, double *Pdense, hipStream_t st);
 
 // ---- fp64 MFMA GEMM family (C = A * B^T, both operands row-major with K contiguous) --------
-enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4,
-                    EPI_SUB = 5 /*C -= A.B^T*/, EPI_ATOMIC = 6 /*C += A.B^T by fp64 atomics: split-K tiles*/ };
+enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4 };
 
 struct GemmParams {
     int M, N, K;          // C is M x N, reduction K
