@@ -156,6 +156,7 @@ struct sgpr_model {
     double chol_ridge = 0.0, chol_dmean = 0.0;
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
+    int csq_slots = 1;
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
@@ -203,7 +204,7 @@ __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, d
 // block reduces a slice, release fence, ticket, last arriver combines — spent most of its 8 us in that
 // dependent chain.)
 struct FinArgs {
-    int N, cnt, first, stride, maxnn, t_stride, has_beta, nE, nV, bin_cap, t_check;
+    int N, cnt, first, stride, maxnn, t_stride, has_beta, nE, nV, bin_cap, t_check, csq_slots;
     const int *perm, *slot, *nn, *nbr_j, *aux, *nn_raw;
     const unsigned short *T;
     const double *G;            // gather form: [N][maxnn][4]
@@ -275,7 +276,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
         double bt = 0.0;
         const int il = (i - f.first) / f.stride;
         if (f.has_beta && i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt) {
-            const double v = 1.0 - f.csq[il];
+            double cs = 0.0;  // |choli k_i|^2: the tile partials in their fixed order
+            for (int k = 0; k < f.csq_slots; k++) cs += f.csq[(size_t)il * f.csq_slots + k];
+            const double v = 1.0 - cs;
             bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
         }
         packed[3 * f.N + c] = bt;
@@ -298,7 +301,14 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     double fs = lane < 3 ? f.Fself[by * f.f_stride + 3 * (size_t)i + lane] : 0.0;
     double *packed = f.packed + by * f.p_stride;
     const int c = f.perm[i];
-    const double cs = f.has_beta ? f.csq[i] : 1.0;
+    double cs = 1.0;
+    if (f.has_beta) {  // |choli k_i|^2: the tile partials, summed by a fixed tree
+        double x = 0.0;
+        for (int k = lane; k < f.csq_slots; k += 64) x += f.csq[(size_t)i * f.csq_slots + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        cs = x;
+    }
     const double vs = f.has_beta ? f.vs_sqrt[f.slot[i]] : 0.0;
     double fx = 0.0, fy = 0.0, fz = 0.0;
     for (int t0 = 0; t0 < n; t0 += 64) {
@@ -805,7 +815,8 @@ static int alloc_work(sgpr_model *h)
     bad |= h->d_C.alloc((size_t)std::max(h->cnt, 1) * h->CS);
     bad |= h->d_shear.alloc(cr);
     bad |= h->d_W.alloc((size_t)cr * h->Dpad);
-    bad |= h->d_csq.alloc(cr);
+    h->csq_slots = 2 * ((std::max(h->m_pad, 1) + 63) / 64);  // covloss partials: one per (64-column tile, wave column)
+    bad |= h->d_csq.alloc((size_t)cr * h->csq_slots);
     bad |= h->d_F.alloc((size_t)6 * h->N);
     h->virpart_len = (h->cnt + 3) / 4;  // one partial per desc_bwd workgroup
     bad |= h->d_virpart.alloc((size_t)std::max(h->virpart_len, 1) * 9);
@@ -974,7 +985,7 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
     f.t_check = (h->world == 1 && h->gather_ok) ? 1 : 0;
     f.perm = h->d_perm.p; f.slot = h->d_slot.p; f.nn = h->d_nn.p; f.nbr_j = h->d_nbr_j.p; f.aux = h->d_aux.p;
     f.nn_raw = h->d_nn_raw.p; f.T = h->d_T.p; f.G = h->d_G.p; f.Fnbr = h->d_F.p; f.Fself = h->d_F.p + 3 * (size_t)N;
-    f.csq = h->d_csq.p; f.vs_sqrt = h->d_vs_sqrt.p; f.Epart = h->d_Epart.p; f.virpart = h->d_virpart.p;
+    f.csq = h->d_csq.p; f.csq_slots = h->csq_slots; f.vs_sqrt = h->d_vs_sqrt.p; f.Epart = h->d_Epart.p; f.virpart = h->d_virpart.p;
     f.mean_energy = mean_energy; f.packed = packed_dev; f.stat = h->d_stat.p; f.bin_count = h->d_bin_count.p;
     f.flag = h->step_flag ? h->step_flag : h->d_flag.p; f.pos = h->d_pos.p; f.pos0 = h->d_pos0.p;
     f.rebuilds = h->d_flag.p + 2;
@@ -1022,7 +1033,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     sc.skin = skin; sc.pos0 = h->d_pos0.p; sc.cell0 = h->d_cell0.p; sc.ncand = h->d_ncand.p; sc.cand_j = h->d_cand_j.p;
     sc.cand_code = h->d_cand_code.p; sc.cidx = h->d_cidx.p; sc.hm = h->d_hm.p; sc.hmw = h->hmw;
     h->step_flag = h->d_flag.p + sc.parity;
-    launch_neighbor_bin(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc + skin, sc, h->d_F.p, 3 * N, h->d_csq.p, cnt,
+    launch_neighbor_bin(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc + skin, sc, h->d_F.p, 3 * N, h->d_csq.p, cnt * h->csq_slots,
                         st);
     stamp(h, "neighbor_bin", st);
     DescParams dp = {};
@@ -1054,7 +1065,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     gc.lda = h->m_pad; gc.ldb = h->m_pad; gc.ldc = 0;
     gc.A = h->d_K.p; gc.B = h->d_choli.p; gc.C = nullptr;
     gc.tiles = h->t_cov.p; gc.ntiles = (int)h->t_cov.n; gc.bm = h->gemm_bm_w;
-    gc.rowsq = h->d_csq.p;
+    gc.rowsq = h->d_csq.p; gc.rowsq_ld = h->csq_slots;
     // "overlap" option: the covloss product (MFMA-bound) runs on a side stream next to the reverse pass
     // (VALU/latency-bound) instead of being grouped with the W product
     bool forked = false;

@@ -1030,9 +1030,12 @@ static int rev_region_doubles(int Dpad)
     return (r + 1) & ~1;
 }
 
-template <int LMAX, int NMAX, int ST, bool GATHER>
+// ROWS: the training-rows form (a batch of inducing columns over blockIdx.y, the seed formed from Aw and P^m);
+// compiled apart so that the predict path carries none of its bookkeeping
+template <int LMAX, int NMAX, int ST, bool GATHER, bool ROWS>
 __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
 {
+    const double *const rows_aw = ROWS ? a.rows_aw : nullptr;
     using RD = RevDims<LMAX, NMAX>;
     constexpr int N1 = RD::N1, L1 = RD::L1, LL = RD::LL, NSLOT = RD::NSLOT;
     constexpr int KS = RD::KS, CB = RD::CB, CH = RD::CH, RB = RD::RB, SP = RD::SP, FS = RD::FS;
@@ -1051,12 +1054,15 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
     const int gi = a.first + (active ? ia : 0) * a.stride;
     const int nn = active ? a.nn[gi] : 0;
     // batch entry (training rows): column, seed scale and output bases
-    const int bq = a.rows_aw ? a.rows_cols[blockIdx.y] : 0;
-    const double aw_q = (a.rows_aw && active) ? a.rows_aw[(size_t)ia * a.rows_ld + bq] : 1.0;
-    double *Gb = a.G ? a.G + blockIdx.y * a.g_stride : nullptr;
-    double *Fnbr_b = a.Fnbr ? a.Fnbr + blockIdx.y * a.f_stride : nullptr;
-    double *Fself_b = a.Fself ? a.Fself + blockIdx.y * a.f_stride : nullptr;
-    double *vir_b = a.vir_part + blockIdx.y * a.v_stride;
+    const int bq = ROWS ? a.rows_cols[blockIdx.y] : 0;
+    const double aw_q = (ROWS && active) ? rows_aw[(size_t)ia * a.rows_ld + bq] : 1.0;
+    double *Gb = a.G, *Fnbr_b = a.Fnbr, *Fself_b = a.Fself, *vir_b = a.vir_part;
+    if constexpr (ROWS) {
+        if (Gb) Gb += blockIdx.y * a.g_stride;
+        if (Fnbr_b) Fnbr_b += blockIdx.y * a.f_stride;
+        if (Fself_b) Fself_b += blockIdx.y * a.f_stride;
+        vir_b += blockIdx.y * a.v_stride;
+    }
     double tot = 0.0;  // lanes < 48 with (lane & 3) == 0: running sum of virial component / force component lane >> 2
     bool zero_dc = false;  // dE/dp^ of this atom is identically zero (training rows: the column belongs to another
                            // species): every pair gradient is zero, only the hand-over slots have to be cleared
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
     if (nn > 0) {
         // ---------------------------------------------------------------- phase A: dE/dc -> dcl
         const double nrm = a.norm[ia];
-        if (!(nrm > 0.0) || (a.rows_aw && aw_q == 0.0)) {  // (aw_q: wave-uniform; 0 for atoms of other species)
+        if (!(nrm > 0.0) || (ROWS && aw_q == 0.0)) {  // (aw_q: wave-uniform; 0 for atoms of other species)
             for (int k = lane; k < ST * NSLOT; k += 64) dcl[k] = 0.0;
             zero_dc = true;
         } else {
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             double *gl = R + ST * NSLOT;    // EXPAND: [UT][UT][L1] else [Dpad]:  dE/dp~ * coef * (1 or 2)
             const double sden = nrm + SGPR_EPS;
             constexpr int MAXE = ((UT * (UT + 1)) / 2 * L1 + 63) / 64;
-            const double *Wi = a.rows_aw ? a.rows_pm + (size_t)bq * a.Dpad : a.W + (size_t)ia * a.Dpad;
+            const double *Wi = ROWS ? a.rows_pm + (size_t)bq * a.Dpad : a.W + (size_t)ia * a.Dpad;
             const double *Pi = a.Pn + (size_t)ia * a.Dpad;
             if constexpr (MAXE <= 10) {
                 // all global reads of this atom are issued up front (W, p^, pack entries, c)
@@ -1100,7 +1106,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                         if (SPL * 64 == NSLOT || slot < NSLOT)
                             cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
                     }
-                {
+                if constexpr (ROWS) {
                     bool nz = false;
 #pragma unroll
                     for (int k = 0; k < MAXE; k++) nz |= wv[k] != 0.0;
@@ -1406,20 +1412,21 @@ static int run_bwd(DescArgs a, hipStream_t st)
     using RD = RevDims<LMAX, NMAX>;
     a.rsz = rev_region_doubles<LMAX, NMAX, ST>(a.Dpad);
     const size_t lds = sizeof(double) * 4 * (size_t)(ST * RD::NSLOT + a.rsz + RD::CH / 2);
-    static size_t attr_set[2] = {0, 0};
-    const bool gather = a.G != nullptr;
-    if (attr_set[gather] < lds) {
-        if (gather)
-            (void)hipFuncSetAttribute((const void *)desc_rev_kernel<LMAX, NMAX, ST, true>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else
-            (void)hipFuncSetAttribute((const void *)desc_rev_kernel<LMAX, NMAX, ST, false>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[gather] = lds;
+    static size_t attr_set[4] = {0, 0, 0, 0};
+    const bool gather = a.G != nullptr, rows = a.rows_aw != nullptr;
+    const void *fn = gather ? (rows ? (const void *)desc_rev_kernel<LMAX, NMAX, ST, true, true>
+                                    : (const void *)desc_rev_kernel<LMAX, NMAX, ST, true, false>)
+                            : (rows ? (const void *)desc_rev_kernel<LMAX, NMAX, ST, false, true>
+                                    : (const void *)desc_rev_kernel<LMAX, NMAX, ST, false, false>);
+    if (attr_set[2 * gather + rows] < lds) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set[2 * gather + rows] = lds;
     }
-    const dim3 grid((a.N + 3) / 4, a.rows_aw ? a.batch : 1);
-    if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false>), grid, dim3(256), lds, st, a);
+    const dim3 grid((a.N + 3) / 4, rows ? a.batch : 1);
+    if (gather && rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, true>), grid, dim3(256), lds, st, a);
+    else if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false>), grid, dim3(256), lds, st, a);
+    else if (rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false>), grid, dim3(256), lds, st, a);
     return 0;
 }
 

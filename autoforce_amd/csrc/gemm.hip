@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                     s += __shfl_xor(s, 4, 64);
                     s += __shfl_xor(s, 8, 64);
                     const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
-                    if ((lane & 15) == 0 && row < p.M && s != 0.0) unsafeAtomicAdd(&p.rowsq[row], s);
+                    if ((lane & 15) == 0 && row < p.M && s != 0.0) p.rowsq[(size_t)row * p.rowsq_ld + 2 * ct + wc] = s;
                 }
             }
         }

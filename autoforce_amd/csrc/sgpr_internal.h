@@ -170,7 +170,8 @@ struct GemmParams {
     const int *row_slot;  // [M] species slot per row (EPI_KERNEL)
     const int *col_slot;  // [N] species slot per column
     // EPI_ROWSQ extras
-    double *rowsq;        // [M] accumulators (atomicAdd)
+    double *rowsq;        // [M][rowsq_ld] partial sums, slot 2 * column tile + wave column (plain stores: a fixed
+    int rowsq_ld;         //   summation order downstream)
     long long *stamps;    // diagnostic only
 };
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st);

@@ -109,6 +109,19 @@ def _lips_model(n_side, m, seed=1):
     return mdl, numbers, pos, cell, pbc
 
 
+def test_full_size_step_is_bit_reproducible():
+    """4096 / 512: energy, forces, stress AND covloss repeat bit for bit (the covloss row sums go through per-tile
+    partials in a fixed order, the forces through the gather-form reverse pass: no floating-point atomics)."""
+    mdl, numbers, pos, cell, pbc = _lips_model(16, 512)
+    ref = mdl.predict(numbers, pos, cell, pbc)
+    assert np.isfinite(ref["beta"]).all() and ref["beta"].max() > 0
+    for _ in range(4):
+        out = mdl.predict(numbers, pos, cell, pbc)
+        for k in ("energy", "forces", "stress", "beta"):
+            np.testing.assert_array_equal(np.asarray(out[k]), np.asarray(ref[k]))
+    mdl.close()
+
+
 def test_full_size_lips4096_against_oracle():
     """BASELINE configs[2] sizes: 4096 atoms, 3 species, 512 inducing.  north_star tolerance:
     forces within 1e-6 relative of the CPU path; held to 1e-8 here."""
