@@ -125,6 +125,7 @@ struct sgpr_model {
     DevBuf<double> d_gpart;
     DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
     DevBuf<double> d_rows_bG, d_rows_bF, d_rows_bV;     // (batch of columns: G, [Fnbr | Fself], virial partials)
+    DevBuf<double> d_rows_kepart;                       // (K_e: per-chunk column sums)
     DevBuf<int> d_rows_cols;
     std::vector<int> rows_cols;
     // resident training set (data.inc): the design matrix [K_e; K_f; K_v] of the stored frames, column-major in the
@@ -149,6 +150,27 @@ struct sgpr_model {
     struct R1Entry { uint64_t key[2] = {0, 0}; int m = 0; DevBuf<double> r1; uint64_t age = 0; };
     R1Entry r1_cache[4];
     uint64_t r1_clock = 0;
+    // the first-stage factorisation itself, kept with its reflectors (data.inc): a new inducing LCE is one more
+    // column pushed through them, a popped one is dropped.  Two of them: a data trial (push a frame, refit, pop it)
+    // comes back to the one it left; the force-only fit of the noise search keeps its own.
+    struct QrKeep {
+        bool valid = false;
+        int with_energies = 1;             // 0: the force-only fit of the noise search (energy rows zeroed)
+        DevBuf<int64_t> erows;             // the energy rows of the stored frames
+        int n_erows = 0;
+        int rows = 0, R = 0, ldr = 0;      // design rows; rows / leading dimension of the factored work array
+        int ncols = 0, ccap = 0;           // current columns, capacity of Rc
+        std::vector<int64_t> frame_ids, col_ids;
+        uint64_t ykey[2] = {0, 0};
+        DevBuf<double> store, Rc, yt, yraw, ysnap, vec;
+        size_t store_used = 0;
+        std::vector<TsqrPanel> panels;     // the panels of the full factorisation, then one per appended column
+        std::vector<int> app_k0;           // appended panels: their column,
+        std::vector<size_t> app_doubles;   //   their share of `store`,
+        std::vector<char> app_snap;        //   whether ysnap holds Q^T Y from before them
+        uint64_t age = 0;
+    };
+    QrKeep qr_keep[4];
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
     DevBuf<double> d_edit_tmp;  // scratch of the incremental inducing-set edits
@@ -498,10 +520,11 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                             &h->d_vs_sqrt, &h->d_gpart, &h->d_pos_in, &h->d_cell_in, &h->d_pos, &h->d_Pn, &h->d_norm, &h->d_C, &h->d_prec, &h->d_G,
                             &h->d_K, &h->d_Aw, &h->d_W, &h->d_F, &h->d_virpart, &h->d_Epart, &h->d_csq, &h->d_packed,
                             &h->d_rows_ones, &h->d_rows_out, &h->d_rows_ke, &h->d_L, &h->d_R1, &h->d_edit_tmp,
-                            &h->d_rows_bG, &h->d_rows_bF, &h->d_rows_bV, &h->d_design, &h->d_qr_A, &h->d_qr_work};
+                            &h->d_rows_bG, &h->d_rows_bF, &h->d_rows_bV, &h->d_rows_kepart, &h->d_design, &h->d_qr_A, &h->d_qr_work};
     for (auto b : db) b->release();
     h->d_rows_cols.release();
     for (auto &e : h->r1_cache) e.r1.release();
+    for (auto &k : h->qr_keep) { k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
     h->d_T.release();
     h->d_hm.release();

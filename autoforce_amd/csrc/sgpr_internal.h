@@ -189,10 +189,17 @@ void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, 
 // [A | y] is the contiguous row c of At; rows padded with zeros to ldr, a multiple of 64):
 // panels of 32 reflectors, compact-WY trailing updates on the MFMA GEMM.  At is overwritten.
 size_t lstsq_qr_blocked_work_doubles(int rows, int cols);
+// a kept panel of the factorisation (tsqr.hip): reflectors V and compact-WY T of every level of its tree
+struct TsqrLevel { double *V, *T; int n, chunks, stride; };
+struct TsqrPanel { int k0, nb, row_end, nlev; TsqrLevel lv[8]; };
+size_t tsqr_panel_doubles(int n);                       // V + T doubles of one panel over n rows
+size_t tsqr_keep_doubles(int rows, int cols, int band); // ... of every panel of a rows x cols factorisation
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /*[cols] or NULL: factor only*/,
-                            double *work, hipStream_t st, int band = 0 /*> 0: column c is zero below row band (c + 1)*/);
-// R (row-major [cols][cols], upper) and z = (Q^T y)[0:cols] out of a factored At
-void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st);
+                            double *work, hipStream_t st, int band = 0, double *keep = nullptr,
+                            std::vector<TsqrPanel> *panels = nullptr);
+void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st);
+void tsqr_append_column(double *vec, int rows, int k0, double *keep, TsqrPanel *rec, double *work, hipStream_t st);
+void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rc, int ldc, double *z, hipStream_t st);
 
 void host_build_harm_coef(HarmCoef *hc);
 void upload_harm_coef(const HarmCoef &hc);

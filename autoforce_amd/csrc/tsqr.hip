@@ -69,43 +69,47 @@ __device__ __forceinline__ double wave_sum64(double v)
 }
 
 // One chunk (<= 256 rows x <= 32 columns) factored by one workgroup of 512 threads with the chunk IN REGISTERS:
-// thread (c, g) = (tid & 31, tid >> 5) owns rows 16 g .. 16 g + 15 of column c for the whole factorisation.
+// thread (c, g) = (tid & 31, tid >> 5) owns the 16 rows g, g + 16, g + 32, ... of column c for the whole
+// factorisation.  The interleaved ownership puts the rows that can hold a pivot (0..31) at register slots 0 and 1 of
+// EVERY thread: two cheap masks per thread instead of a wave that masks all of its rows while seven others wait.
 // A column step:
 //   the owner of column j has published it (v_j, zero above row j) and its norm in LDS          [barrier]
 //   every thread: 16 products of its rows with v_j -> partial sums in LDS                          [barrier]
 //   every thread: g_c = 16 partials, rank-1 update of its 16 rows; the owner of column j + 1 publishes it.
-// No cross-lane reductions.  Pivots only ever sit in rows 0..31 (wave 0): every other wave runs without a single
-// mask.  Two waves per SIMD hide each other's latencies (the step is a chain of dependent short operations).
-// V^T V (for T) is one MFMA product at the end; T is built in 16 x 16 blocks.
+// No cross-lane reductions.  Two waves per SIMD hide each other's latencies (the step is a chain of dependent short
+// operations).  V^T V (for T) is one MFMA product at the end; T is built in 16 x 16 blocks.
 #define TLT 512  // threads of the leaf kernel
-#define TRG 16   // rows per thread
+#define TRG 16   // rows per thread (= row groups)
 __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
 {
     extern __shared__ double lds[];
-    double *sm = lds;                     // [TNB][TLD]  V (masked) for the Gram product at the end
+    double *sm = lds;                     // [TNB][TLD]  the chunk on its way in, V (masked) on its way out
     double *G = lds + TNB * TLD;          // [TNB][TNB + 1]:  V^T V
     double *Ts = G + TNB * (TNB + 1);     // [TNB][TNB + 1]
-    __shared__ __attribute__((aligned(16))) double vbuf[2][TCH], pn[2][16];
+    __shared__ __attribute__((aligned(16))) double vbuf[2][TCH], pn[2][16];   // vbuf[.][16 g + k] = row g + 16 k
     __shared__ double part[16][TNB + 1], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = tid & 31, rg = tid >> 5, r0 = rg * TRG;
     const int chunk = blockIdx.x;
     const int nr = min(TCH, q.n - chunk * TCH);
-    double a[TRG];
     {
-        // (branch-free: a dead pair reads the chunk's first element instead; a pair cut by the end of the matrix reads
-        // one element of padding — ldr is a multiple of 64 — and drops it)
+        // coalesced in (thread: 16 consecutive rows of its column), interleaved out.  Branch-free: a dead pair reads
+        // the chunk's first element instead; a pair cut by the end of the matrix reads one element of padding — ldr
+        // is a multiple of 64 — and drops it.
         const double *col = q.src + chunk * q.chunk_stride + (size_t)(c < q.nb ? c : 0) * q.ld;
 #pragma unroll
         for (int k = 0; k < TRG; k += 2) {
             const bool ok0 = c < q.nb && r0 + k < nr, ok1 = c < q.nb && r0 + k + 1 < nr;
             const double2 v = *(const double2 *)(col + (ok0 ? r0 + k : 0));
-            a[k] = ok0 ? v.x : 0.0;
-            a[k + 1] = ok1 ? v.y : 0.0;
+            *(double2 *)&sm[c * TLD + r0 + k] = make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
         }
     }
     for (int e = tid; e < TNB * (TNB + 1); e += TLT) Ts[e] = 0.0;
     if (tid < TNB) { s_alpha[tid] = 0.0; s_scal[tid] = 0.0; s_vjj[tid] = 0.0; }
+    __syncthreads();
+    double a[TRG];
+#pragma unroll
+    for (int k = 0; k < TRG; k++) a[k] = sm[c * TLD + rg + TRG * k];
     if (c == 0) {  // column 0 and its norm
         double s = 0.0;
 #pragma unroll
@@ -121,79 +125,64 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
             const double2 x = *(const double2 *)&pn[jb][g];
             s2 += x.x + x.y;
         }
-        const double akk = vbuf[jb][j];
+        const double akk = vbuf[jb][(j & 15) * TRG + (j >> 4)];
         const double nrm = sqrt(s2);
         const double alpha = akk > 0.0 ? -nrm : nrm;
         const double vjj = akk - alpha;
         const double vv = s2 - akk * akk + vjj * vjj;
         const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
         if (tid == 0) { s_alpha[j] = alpha; s_scal[j] = sc; s_vjj[j] = vjj; }
-        // pivot row relative to this row group (uniform over a half wave): < 0: every row of the group is below the
-        // pivot (no masks anywhere), 0..15: the pivot group, >= 16: the group is done (rows of R) and sits the step out
-        const int jj = j - r0;
         double vj[TRG], t4[4] = {0.0, 0.0, 0.0, 0.0};
-        if (jj < TRG) {
 #pragma unroll
-            for (int k = 0; k < TRG; k += 2) {
-                const double2 x = *(const double2 *)&vbuf[jb][r0 + k];
-                vj[k] = x.x; vj[k + 1] = x.y;
-            }
-            if (jj >= 0) {
-#pragma unroll
-                for (int k = 0; k < TRG; k++)
-                    if (k == jj) vj[k] = vjj;
-            }
-#pragma unroll
-            for (int k = 0; k < TRG; k++) t4[k & 3] += vj[k] * a[k];
+        for (int k = 0; k < TRG; k += 2) {
+            const double2 x = *(const double2 *)&vbuf[jb][r0 + k];
+            vj[k] = x.x; vj[k + 1] = x.y;
         }
+        if (rg == (j & 15)) {  // this group holds the pivot row, at slot 0 or 1
+            if (j < 16) vj[0] = vjj;
+            else vj[1] = vjj;
+        }
+#pragma unroll
+        for (int k = 0; k < TRG; k++) t4[k & 3] += vj[k] * a[k];
         part[rg][c] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
         __syncthreads();
         double g4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < 16; u++) g4[u & 3] += part[u][c];
         const double f = c > j ? sc * ((g4[0] + g4[1]) + (g4[2] + g4[3])) : 0.0;
-        if (jj < TRG) {
 #pragma unroll
-            for (int k = 0; k < TRG; k++) a[k] -= f * vj[k];
-        }
-        if (c == j + 1) {  // publish the next pivot column (zero above its diagonal) and its norm
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            if (jj < 0) {
+        for (int k = 0; k < TRG; k++) a[k] -= f * vj[k];
+        if (c == j + 1) {  // publish the next pivot column (zero above its diagonal: rows <= j) and its norm
+            double x[TRG], s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int k = 0; k < TRG; k += 2) {
-                    *(double2 *)&vbuf[jb ^ 1][r0 + k] = make_double2(a[k], a[k + 1]);
-                    s4[k & 3] += a[k] * a[k];
-                    s4[(k + 1) & 3] += a[k + 1] * a[k + 1];
-                }
-            } else if (jj >= TRG - 1) {
+            for (int k = 0; k < TRG; k++) x[k] = a[k];
+            if (rg <= j) x[0] = 0.0;
+            if (rg + 16 <= j) x[1] = 0.0;
 #pragma unroll
-                for (int k = 0; k < TRG; k += 2) *(double2 *)&vbuf[jb ^ 1][r0 + k] = make_double2(0.0, 0.0);
-            } else {
-#pragma unroll
-                for (int k = 0; k < TRG; k++) {
-                    const double x = k > jj ? a[k] : 0.0;
-                    vbuf[jb ^ 1][r0 + k] = x;
-                    s4[k & 3] += x * x;
-                }
+            for (int k = 0; k < TRG; k += 2) {
+                *(double2 *)&vbuf[jb ^ 1][r0 + k] = make_double2(x[k], x[k + 1]);
+                s4[k & 3] += x[k] * x[k];
+                s4[(k + 1) & 3] += x[k + 1] * x[k + 1];
             }
             pn[jb ^ 1][rg] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         }
         __syncthreads();
     }
-    // V (zero above the diagonal, v_jj on it) -> LDS for the Gram product, -> global for the trailing update
-    double *V = q.V + (size_t)chunk * TNB * TCH + c * TCH + r0;
+    // V (zero above the diagonal, v_jj on it) -> LDS: for the Gram product, and for the coalesced way out
     {
         const double d = s_vjj[c];
 #pragma unroll
-        for (int k = 0; k < TRG; k += 2) {
-            double2 v;
-            v.x = (c < q.nb && r0 + k >= c) ? (r0 + k == c ? d : a[k]) : 0.0;
-            v.y = (c < q.nb && r0 + k + 1 >= c) ? (r0 + k + 1 == c ? d : a[k + 1]) : 0.0;
-            *(double2 *)&sm[c * TLD + r0 + k] = v;
-            *(double2 *)(V + k) = v;
+        for (int k = 0; k < TRG; k++) {
+            const int r = rg + TRG * k;
+            sm[c * TLD + r] = (c < q.nb && r >= c) ? (r == c ? d : a[k]) : 0.0;
         }
     }
     __syncthreads();
+    {
+        double *V = q.V + (size_t)chunk * TNB * TCH + c * TCH + r0;
+#pragma unroll
+        for (int k = 0; k < TRG; k += 2) *(double2 *)(V + k) = *(const double2 *)&sm[c * TLD + r0 + k];
+    }
     if (wave < 4) {
         const int l15 = lane & 15, l4 = lane >> 4;
         const double *pa = sm + ((wave >> 1) * 16 + l15) * TLD + l4, *pb = sm + ((wave & 1) * 16 + l15) * TLD + l4;
@@ -248,18 +237,16 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
     __syncthreads();
     double *T = q.T + (size_t)chunk * TNB * TNB;
     for (int e = tid; e < TNB * TNB; e += TLT) T[e] = Ts[(e / TNB) * (TNB + 1) + e % TNB];
-    // R_i (upper triangular, alpha on the diagonal): rows 0..31 live in row groups 0 and 1
-    if (rg < 2) {
+    // R_i (upper triangular, alpha on the diagonal): row g is slot 0 of group g, row g + 16 its slot 1
 #pragma unroll
-        for (int k = 0; k < TRG; k++) {
-            const int r = r0 + k;
-            const double val = c < q.nb ? (r < c ? a[k] : (r == c ? s_alpha[c] : 0.0)) : 0.0;
-            if (q.Rnext) {
-                const int rho = chunk * TNB + r;
-                q.Rnext[(size_t)(rho / TCH) * TNB * TCH + c * TCH + rho % TCH] = val;
-            } else if (c < q.nb && r <= c) {
-                q.Rfinal[(size_t)c * q.ldr + r] = val;
-            }
+    for (int k = 0; k < 2; k++) {
+        const int r = rg + TRG * k;
+        const double val = c < q.nb ? (r < c ? a[k] : (r == c ? s_alpha[c] : 0.0)) : 0.0;
+        if (q.Rnext) {
+            const int rho = chunk * TNB + r;
+            q.Rnext[(size_t)(rho / TCH) * TNB * TCH + c * TCH + rho % TCH] = val;
+        } else if (c < q.nb && r <= c) {
+            q.Rfinal[(size_t)c * q.ldr + r] = val;
         }
     }
 }
@@ -398,32 +385,59 @@ __global__ __launch_bounds__(TCH) void tsqr_apply_kernel(TsqrApply q)
     }
 }
 
-__global__ void qr_gather_r_kernel(int cols, const double *At, int ldr, double *Rm /*[cols][cols]*/, double *z)
+// R (upper triangle of the factored work array), column-major Rc[c * ldc + i] (i <= c) or row-major Rc[i * ldc + c],
+// and z
+template <bool ROWMAJOR>
+__global__ void qr_gather_r_kernel(int cols, const double *At, int ldr, double *Rc, int ldc, double *z)
 {
-    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cols && j < cols) Rm[(size_t)i * cols + j] = j >= i ? At[(size_t)j * ldr + i] : 0.0;
-    if (i < cols && j == 0) z[i] = At[(size_t)cols * ldr + i];
+    if (ROWMAJOR) {
+        const int i = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < cols && c < cols) Rc[(size_t)i * ldc + c] = c >= i ? At[(size_t)c * ldr + i] : 0.0;
+        if (i < cols && c == 0) z[i] = At[(size_t)cols * ldr + i];
+    } else {
+        const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (c < cols && i < cols) Rc[(size_t)c * ldc + i] = i <= c ? At[(size_t)c * ldr + i] : 0.0;
+        if (c == 0 && i < cols) z[i] = At[(size_t)cols * ldr + i];
+    }
 }
 
-// back substitution R x = z, R row-major [cols][cols]: one workgroup, x kept in LDS
+// back substitution R x = z, R row-major [cols][cols], in blocks of 32 columns from the end: wave 0 solves the
+// 32 x 32 diagonal block (lane = row, its row of the block in registers, the pivots passed through readlane: no
+// barriers inside), then all 1024 threads take the block's contribution out of the rows above (one 32-term dot per
+// row).  Two workgroup barriers per 32 columns instead of two per column.
 __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const double *A, const double *y, double *x)
 {
-    __shared__ double red[16];
-    __shared__ double xs[2048];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int k = cols - 1; k >= 0; k--) {
-        double s = 0.0;
-        for (int j = k + 1 + tid; j < cols; j += 1024) s += A[(size_t)k * cols + j] * xs[j];
-        s = wave_sum64(s);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
+    __shared__ double zs[2048];
+    __shared__ double xb[32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < cols; i += 1024) zs[i] = y[i];
+    __syncthreads();
+    for (int b1 = cols; b1 > 0; b1 -= 32) {
+        const int b0 = max(b1 - 32, 0), nbk = b1 - b0;
+        if (tid < 64) {
+            const bool on = lane < nbk;
+            const int i = b0 + (on ? lane : 0);
+            double rr[32];
 #pragma unroll
-            for (int w = 0; w < 16; w++) t += red[w];
-            xs[k] = (y[k] - t) / A[(size_t)k * cols + k];
-            x[k] = xs[k];
+            for (int k = 0; k < 32; k++) rr[k] = (on && k < nbk) ? A[(size_t)i * cols + b0 + k] : (k == lane ? 1.0 : 0.0);
+            double zi = on ? zs[i] : 0.0;
+#pragma unroll
+            for (int k = 31; k >= 0; k--) {
+                if (k < nbk) {  // (uniform)
+                    const double xk = lane_f64(zi, k) / lane_f64(rr[k], k);
+                    if (lane < k) zi -= rr[k] * xk;
+                    if (lane == k) xb[k] = xk;
+                }
+            }
         }
+        __syncthreads();
+        for (int i = tid; i < b0; i += 1024) {
+            const double *r = A + (size_t)i * cols + b0;
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < nbk; k++) s4[k & 3] += r[k] * xb[k];
+            zs[i] -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+        if (tid < nbk) x[b0 + tid] = xb[tid];
         __syncthreads();
     }
 }
@@ -449,71 +463,157 @@ size_t lstsq_qr_blocked_work_doubles(int rows, int cols)
     return total + (size_t)cols * cols + cols + 64;
 }
 
-int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band)
+// doubles of V and T a kept panel over n rows needs (all levels)
+size_t tsqr_panel_doubles(int n)
 {
-    if (cols > 2048 || rows < cols || ldr < rows) return -1;
-    static bool attr_done = false;
-    const size_t lds_leaf = sizeof(double) * (TNB * TLD + 2 * TNB * (TNB + 1));
-    const size_t lds_apply = sizeof(double) * (2 * TNB * TLD + 3 * TNB * (TNB + 1));
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)tsqr_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf);
-        (void)hipFuncSetAttribute((const void *)tsqr_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply);
-        attr_done = true;
-    }
     std::vector<int> ch;
-    tsqr_levels(rows, ch);
-    // per-level work arrays, sized for the first (tallest) panel
+    tsqr_levels(std::max(n, 1), ch);
+    size_t total = 0;
+    for (int c : ch) total += (size_t)c * (TNB * TCH + TNB * TNB);
+    return total;
+}
+
+size_t tsqr_keep_doubles(int rows, int cols, int band)
+{
+    size_t total = 0;
+    for (int k0 = 0; k0 < cols; k0 += TNB) {
+        const int nb = std::min(TNB, cols - k0);
+        const int row_end = band > 0 ? std::min(rows, band * (k0 + nb)) : rows;
+        total += tsqr_panel_doubles(row_end - k0);
+    }
+    return total;
+}
+
+static size_t lds_leaf_bytes() { return sizeof(double) * (TNB * TLD + 2 * TNB * (TNB + 1)); }
+static size_t lds_apply_bytes() { return sizeof(double) * (2 * TNB * TLD + 3 * TNB * (TNB + 1)); }
+static void tsqr_attrs()
+{
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void *)tsqr_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_bytes());
+    (void)hipFuncSetAttribute((const void *)tsqr_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply_bytes());
+    done = true;
+}
+
+// One panel: factor columns [k0, k0 + nb) of the column-major matrix `panel_cols` (element (c, r) at
+// panel_cols[c * ld + r], r a physical row) over rows [k0, row_end), level by level, and update `ntrail` trailing
+// columns (trail[c * ld + r]) after every level.  V / T of every level go to `keep` (consecutive) when given — the
+// panel can then be applied again later (tsqr_apply_panels) — else to the per-level scratch in `work`.
+static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, double *trail, int ntrail, double *work,
+                       double *keep, TsqrPanel *rec, hipStream_t st)
+{
+    std::vector<int> ch;
+    tsqr_levels(std::max(row_end - k0, 1), ch);
+    // scratch layout of this panel: per level V | S (input of the level) | T
     std::vector<double *> Vl(ch.size()), Tl(ch.size()), Sl(ch.size());
     double *w = work;
     for (size_t l = 0; l < ch.size(); l++) {
         Vl[l] = w; w += (size_t)ch[l] * TNB * TCH;
-        Sl[l] = w; w += (size_t)ch[l] * TNB * TCH;  // input of level l (unused at level 0)
+        Sl[l] = w; w += (size_t)ch[l] * TNB * TCH;
         Tl[l] = w; w += (size_t)ch[l] * TNB * TNB;
     }
-    double *Rm = w; w += (size_t)cols * cols;
-    double *z = w; w += cols;
+    if (keep) {
+        double *kp = keep;
+        for (size_t l = 0; l < ch.size(); l++) {
+            Vl[l] = kp; kp += (size_t)ch[l] * TNB * TCH;
+            Tl[l] = kp; kp += (size_t)ch[l] * TNB * TNB;
+        }
+    }
+    if (rec) { rec->k0 = k0; rec->nb = nb; rec->row_end = row_end; rec->nlev = 0; }
+    int n = row_end - k0, stride = TNB;
+    for (int l = 0;; l++) {
+        const int chunks = (n + TCH - 1) / TCH;
+        const bool top = chunks == 1;
+        TsqrLeaf lf = {};
+        if (l == 0) { lf.src = panel_cols + k0; lf.chunk_stride = TCH; lf.ld = ld; }
+        else { lf.src = Sl[l]; lf.chunk_stride = (size_t)TNB * TCH; lf.ld = TCH; }
+        lf.n = n; lf.nb = nb;
+        lf.V = Vl[l]; lf.T = Tl[l];
+        lf.Rnext = top ? nullptr : Sl[l + 1];
+        lf.Rfinal = panel_cols + k0;
+        lf.ldr = ld;
+        hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks), dim3(TLT), lds_leaf_bytes(), st, lf);
+        if (rec && rec->nlev < 8) {
+            TsqrLevel &lv = rec->lv[rec->nlev++];
+            lv.V = Vl[l]; lv.T = Tl[l]; lv.n = n; lv.chunks = chunks; lv.stride = stride;
+        }
+        if (ntrail > 0) {
+            TsqrApply ap = {};
+            ap.A = trail;
+            ap.ldr = ld; ap.ntrail = ntrail;
+            ap.row0 = k0; ap.row_end = row_end;
+            ap.n = n; ap.stride = stride;
+            ap.V = Vl[l]; ap.T = Tl[l];
+            // enough workgroups to fill the chip several times over, else as many tiles per workgroup as possible
+            const int ntiles = (ntrail + TNB - 1) / TNB;
+            ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * chunks / 1024)));
+            hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, chunks), dim3(TCH), lds_apply_bytes(), st, ap);
+        }
+        if (top) break;
+        n = chunks * TNB;
+        stride = l == 0 ? TCH : stride * TSB;
+    }
+}
+
+int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band,
+                            double *keep, std::vector<TsqrPanel> *panels)
+{
+    if (cols > 2048 || rows < cols || ldr < rows) return -1;
+    tsqr_attrs();
+    size_t scratch = 0;
+    {
+        std::vector<int> ch;
+        tsqr_levels(rows, ch);
+        for (int c : ch) scratch += (size_t)c * (2 * TNB * TCH + TNB * TNB);
+    }
+    double *Rc = work + scratch, *z = Rc + (size_t)cols * cols;
+    if (panels) panels->clear();
     for (int k0 = 0; k0 < cols; k0 += TNB) {
         const int nb = std::min(TNB, cols - k0);
         const int row_end = band > 0 ? std::min(rows, band * (k0 + nb)) : rows;
         const int ntrail = cols + 1 - (k0 + nb);
-        int n = row_end - k0, stride = TNB;
-        for (int l = 0;; l++) {
-            const int chunks = (n + TCH - 1) / TCH;
-            const bool top = chunks == 1;
-            TsqrLeaf lf = {};
-            if (l == 0) { lf.src = At + (size_t)k0 * ldr + k0; lf.chunk_stride = TCH; lf.ld = ldr; }
-            else { lf.src = Sl[l]; lf.chunk_stride = (size_t)TNB * TCH; lf.ld = TCH; }
-            lf.n = n; lf.nb = nb;
-            lf.V = Vl[l]; lf.T = Tl[l];
-            lf.Rnext = top ? nullptr : Sl[l + 1];
-            lf.Rfinal = At + (size_t)k0 * ldr + k0;
-            lf.ldr = ldr;
-            hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks), dim3(TLT), lds_leaf, st, lf);
-            if (ntrail > 0) {
-                TsqrApply ap = {};
-                ap.A = At + (size_t)(k0 + nb) * ldr;
-                ap.ldr = ldr; ap.ntrail = ntrail;
-                ap.row0 = k0; ap.row_end = row_end;
-                ap.n = n; ap.stride = stride;
-                ap.V = Vl[l]; ap.T = Tl[l];
-                // enough workgroups to fill the chip several times over, else as many tiles per workgroup as possible
-                const int ntiles = (ntrail + TNB - 1) / TNB;
-                ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * chunks / 1024)));
-                hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, chunks), dim3(TCH), lds_apply, st, ap);
-            }
-            if (top) break;
-            n = chunks * TNB;
-            stride = l == 0 ? TCH : stride * TSB;
-        }
+        TsqrPanel rec;
+        tsqr_panel(At + (size_t)k0 * ldr, ldr, k0, nb, row_end, At + (size_t)(k0 + nb) * ldr, ntrail, work, keep,
+                   panels ? &rec : nullptr, st);
+        if (keep) keep += tsqr_panel_doubles(row_end - k0);
+        if (panels) panels->push_back(rec);
     }
     if (x) {
-        hipLaunchKernelGGL(qr_gather_r_kernel, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rm, z);
-        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rm, z, x);
+        hipLaunchKernelGGL(qr_gather_r_kernel<true>, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rc, cols, z);
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rc, z, x);
     }
     return 0;
 }
 
-void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rm, double *z, hipStream_t st)
+// vec <- Q_p^T vec for the kept panels p = first .. first + count - 1, in order (vec: one column over the physical rows)
+void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st)
 {
-    hipLaunchKernelGGL(qr_gather_r_kernel, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rm, z);
+    tsqr_attrs();
+    for (int p = 0; p < count; p++) {
+        const TsqrPanel &pn = panels[p];
+        for (int l = 0; l < pn.nlev; l++) {
+            TsqrApply ap = {};
+            ap.A = vec;
+            ap.ldr = 0; ap.ntrail = 1;
+            ap.row0 = pn.k0; ap.row_end = pn.row_end;
+            ap.n = pn.lv[l].n; ap.stride = pn.lv[l].stride;
+            ap.V = pn.lv[l].V; ap.T = pn.lv[l].T;
+            ap.tpw = 1;
+            hipLaunchKernelGGL(tsqr_apply_kernel, dim3(1, pn.lv[l].chunks), dim3(TCH), lds_apply_bytes(), st, ap);
+        }
+    }
+}
+
+// A new LAST column of an already factored matrix: `vec` (over the physical rows, every kept panel already applied)
+// gets its own one-column panel over rows [k0, rows): on return vec[0 .. k0] is the new column of R (its diagonal
+// at k0), the panel's reflectors are in `keep` (tsqr_panel_doubles(rows - k0) doubles), `rec` describes it.
+void tsqr_append_column(double *vec, int rows, int k0, double *keep, TsqrPanel *rec, double *work, hipStream_t st)
+{
+    tsqr_attrs();
+    tsqr_panel(vec, 0, k0, 1, rows, nullptr, 0, work, keep, rec, st);
+}
+
+void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rc, int ldc, double *z, hipStream_t st)
+{
+    hipLaunchKernelGGL(qr_gather_r_kernel<false>, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rc, ldc, z);
 }

@@ -106,6 +106,7 @@ def main():
         if os.path.exists(f):
             os.remove(f)
     rng = np.random.default_rng(1)
+    np.random.seed(1)  # sample_rand_lces draws from numpy's global generator (as the reference's does, active.py:656-690)
     mass = np.array([MASS[int(z)] for z in numbers])[:, None]
     kT = kB * args.temperature
     vel = rng.normal(size=(N, 3)) * np.sqrt(kT / mass)

@@ -192,3 +192,73 @@ def test_refit_after_a_rejected_trial():
         assert np.abs(K @ got - K @ want).max() <= 1e-9 * np.abs(K @ want).max()
     assert np.abs(mu3).max() > 0 and np.abs(mu1).max() > 0
     mdl.close(); ref.close()
+
+
+def test_columns_through_the_kept_reflectors():
+    """A long sequence of appended and popped inducing LCEs: every refit goes through the kept first-stage
+    factorisation (new column = Q^T k + its own one-column panel, popped column dropped) and must agree with a model
+    that factors the same matrix from scratch; targets change in between (Q^T Y is rebuilt)."""
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    X = list(mdl.X)
+    frames = systems()
+    mdl.set_inducing(X[:6])
+    for fr in frames:
+        mdl.data_push(*fr, 6)
+    rows = mdl.data_info()[1]
+    rng = np.random.default_rng(4)
+    Y = rng.normal(size=rows)
+
+    def check(Yv, noise=0.02, with_energies=True):
+        got = mdl.data_solve(Yv, noise=noise, with_energies=with_energies).copy()
+        ref = mdl.scratch()
+        ref.set_inducing(mdl.X)
+        K = mdl.data_get()
+        keep = np.ones(len(K), bool)
+        if not with_energies:
+            a = 0
+            for fr in frames[:mdl.data_info()[0]]:
+                keep[a] = False
+                a += 1 + 3 * len(fr[0]) + 6
+        want = ref.solve(K[keep], Yv[keep], noise=noise)
+        assert ref.ridge == mdl.ridge
+        scale = np.abs(K @ want).max()
+        assert np.abs(K @ got - K @ want).max() <= 1e-9 * scale, (len(mdl.X), np.abs(K @ got - K @ want).max() / scale)
+        ref.close()
+        return got
+
+    check(Y)                                   # full factorisation
+    for x in X[6:12]:                          # six appended columns
+        mdl.add_inducing(x)
+        check(Y)
+    check(Y, with_energies=False)              # the force-only fit keeps its own factorisation ...
+    mdl.remove_inducing(-1); check(Y)          # popped: an appended column
+    check(Y, with_energies=False)              # ... and follows the columns too
+    Y2 = Y + 0.1 * rng.normal(size=rows)
+    check(Y2)                                  # new targets through all kept panels
+    mdl.add_inducing(X[12]); check(Y2)
+    for _ in range(8):                         # pops reaching into the columns of the full factorisation
+        mdl.remove_inducing(-1)
+    mu_a = check(Y2)
+    mdl.add_inducing(X[13]); check(Y2)         # append below the original column count
+    mdl.remove_inducing(-1)
+    np.testing.assert_array_equal(check(Y2), mu_a)
+    # a data trial: the other slot, and back
+    mdl.data_pop(-1)
+    n3 = 1 + 3 * len(frames[2][0]) + 6
+    check(Y2[:-n3])
+    mdl.add_inducing(X[14]); check(Y2[:-n3])
+    mdl.data_push(*frames[2], 6)
+    check(Y2)                                  # rows of the pushed frame appended to the kept factor
+    check(Y2, with_energies=False)
+    Y3 = Y2.copy(); Y3[0] += 0.5; Y3[199] -= 0.25   # the energy targets of the old frames move with the mean
+    mdl.data_pop(-1); check(Y3[:-n3])
+    mdl.data_push(*frames[2], 6); check(Y3)
+    # more appended columns than the library keeps as one-column panels: it refactors on its own
+    mdl.set_inducing(X[:4])
+    check(Y)
+    for k in range(40):
+        mdl.add_inducing(X[4 + k % 20].__class__(X[4 + k % 20].number, X[4 + k % 20]._b, X[4 + k % 20]._r + 1e-3 * (k + 1)))
+        if k % 7 == 0 or k > 36:
+            check(Y)
+    mdl.close()

@@ -5,6 +5,7 @@ add_1atoms_fast = push + refit [+ pop + refit]).
 usage: python3 tools/update_bench.py [side=32 -> 32x32x16 = 16384 atoms, else side^3] [m=1024] [frames=2]"""
 import os, sys, time
 import numpy as np
+import scipy.optimize  # (the noise search imports it: keep that out of the timings)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autoforce_amd import SGPRModel
 from autoforce_amd.posterior import PosteriorPotential
