@@ -179,6 +179,8 @@ struct sgpr_model {
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
     int csq_slots = 1;
+    double *pin = nullptr;     // page-locked staging of sgpr_compute: [3N + 9] in | [4N + 11] out
+    size_t pin_doubles = 0;
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
@@ -523,6 +525,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                             &h->d_rows_bG, &h->d_rows_bF, &h->d_rows_bV, &h->d_rows_kepart, &h->d_design, &h->d_qr_A, &h->d_qr_work};
     for (auto b : db) b->release();
     h->d_rows_cols.release();
+    if (h->pin) (void)hipHostFree(h->pin);
     for (auto &e : h->r1_cache) e.r1.release();
     for (auto &k : h->qr_keep) { k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
@@ -1285,6 +1288,38 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         if (energy) *energy = 0.0;
         if (stress) memset(stress, 0, sizeof(double) * 6);
         return SGPR_OK;
+    }
+    // warm path (capacities already sized for this system by a checked pass): one page-locked staging buffer each
+    // way, ONE synchronisation; the step's own overflow word (packed[4N+10], finalize) says whether the capacities
+    // held — if not, or on the first call, the checked path below re-sizes and repeats
+    const size_t n_in = (size_t)3 * N + 9, n_out = (size_t)4 * N + 11;
+    if (h->pin_doubles < n_in + n_out) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr; h->pin_doubles = 0;
+        if (hipHostMalloc((void **)&h->pin, sizeof(double) * (n_in + n_out + 64), hipHostMallocDefault) == hipSuccess)
+            h->pin_doubles = n_in + n_out + 64;
+    }
+    if (h->warm && h->pin && !cov) {
+        double *pi = h->pin, *po = h->pin + n_in;
+        memcpy(pi, positions, sizeof(double) * 3 * N);
+        memcpy(pi + 3 * (size_t)N, cell, sizeof(double) * 9);
+        HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_cell_in.p, pi + 3 * (size_t)N, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
+        int rf = enqueue_step(h, h->d_pos_in.p, h->d_cell_in.p, h->d_packed.p, h->stream);
+        if (!rf) rf = reduce_packed(h, h->d_packed.p, h->stream);
+        if (rf) return rf;
+        HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        if (po[4 * (size_t)N + 10] == 0.0) {
+            if (forces) memcpy(forces, po, sizeof(double) * 3 * N);
+            if (beta) memcpy(beta, po + 3 * (size_t)N, sizeof(double) * N);
+            if (energy) *energy = po[4 * (size_t)N];
+            if (stress) sgpr_stress_from_virial(po + 4 * (size_t)N + 1, cell, stress);
+            return SGPR_OK;
+        }
+        h->warm = false;  // a capacity overflowed (or the cell is degenerate): the checked path sorts it out
+        h->lists_valid = false;
     }
     HIPCHK(hipMemcpyAsync(h->d_pos_in.p, positions, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_cell_in.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
