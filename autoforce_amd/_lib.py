@@ -35,6 +35,8 @@ SIGNATURES = {
     "sgpr_get_kmm": (C.c_int, [_vp, _vp]),
     "sgpr_get_inducing_descriptors": (C.c_int, [_vp, _vp]),
     "sgpr_set_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sgpr_set_mean": (C.c_int, [_vp, _vp, _vp]),
+    "sgpr_get_choli": (C.c_int, [_vp, _vp]),
     "sgpr_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_resolve": (C.c_int, [_vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_make_vscale": (C.c_int, [_vp, _vp]),

@@ -830,6 +830,44 @@ extern "C" int sgpr_set_weights(sgpr_model *h, const double *mu, const double *m
     return SGPR_OK;
 }
 
+// The mean offsets and the per-species variance scale alone: mu and choli stay what the last sgpr_solve /
+// sgpr_data_solve / sgpr_resolve left on the device (make_munu ends by installing exactly those,
+// gppotential.py:548-605 — there is no reason to carry an m x m matrix over PCIe and back for it).
+extern "C" int sgpr_set_mean(sgpr_model *h, const double *mean_w, const double *vscale)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_set_mean: bad arguments");
+    if (h->m <= 0 || !h->has_mu) return fail(SGPR_E_NOMODEL, "sgpr_set_mean: no solved weights on the device");
+    HIPCHK(hipSetDevice(h->device));
+    for (int k = 0; k < h->S; k++) {
+        h->mean_w[k] = mean_w ? mean_w[k] : 0.0;
+        if (vscale) h->vscale[k] = vscale[k];
+    }
+    upload_vscale(h);
+    h->mean_energy = 0.0;
+    if (h->rank == 0)
+        for (int z : h->numbers) {
+            const int s = slot_of(h, z);
+            if (s >= 0) h->mean_energy += h->mean_w[s];
+        }
+    drop_graph(h);
+    return SGPR_OK;
+}
+
+// choli = L^-1 of the cached K_mm factor, [m][m] in the caller's order
+extern "C" int sgpr_get_choli(sgpr_model *h, double *choli)
+{
+    if (!h || !choli) return fail(SGPR_E_INVALID, "sgpr_get_choli: bad arguments");
+    if (h->m <= 0 || !h->has_choli) return fail(SGPR_E_NOMODEL, "sgpr_get_choli: no factor on the device");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int m = h->m, ld = h->m_pad;
+    std::vector<double> cs((size_t)h->m_rows * ld);
+    HIPCHK(hipMemcpy(cs.data(), h->d_choli.p, sizeof(double) * cs.size(), hipMemcpyDeviceToHost));
+    for (int a = 0; a < m; a++)
+        for (int b = 0; b < m; b++) choli[(size_t)h->ind_perm[a] * m + h->ind_perm[b]] = cs[(size_t)a * ld + b];
+    return SGPR_OK;
+}
+
 // ---------------------------------------------------------------------------- system binding
 static int alloc_work(sgpr_model *h)
 {

@@ -58,7 +58,7 @@ class SGPRModel:
             raise ValueError("unknown_species must be 'error' or 'ignore'")
         self.X = []
         self.mu = None
-        self.choli = None
+        self._choli, self._choli_on_device = None, False
         self.ridge = 0.0
         self.sigma = None
         self.mean = {z: 0.0 for z in self.species}  # AutoMean weights (gppotential.py:200-231)
@@ -141,6 +141,20 @@ class SGPRModel:
         self.mu = None
         self.choli = None
 
+    @property
+    def choli(self):
+        """L^-1 of the K_mm factor, [m, m].  A device solve leaves it on the device; it is downloaded when somebody
+        looks (leakage, model files), not at every refit."""
+        if self._choli is None and self._choli_on_device and self.m:
+            out = np.zeros((self.m, self.m))
+            check(_lib.load().sgpr_get_choli(self._h, ptr(out)))
+            self._choli = out
+        return self._choli
+
+    @choli.setter
+    def choli(self, value):
+        self._choli, self._choli_on_device = value, False
+
     def _weights_dropped(self):
         self.mu = None
         self.choli = None
@@ -211,21 +225,29 @@ class SGPRModel:
         self.choli = None if choli is None else f64(choli).copy()
         vs = f64([self._vscale.get(z, np.inf) for z in self.species]) if self._vscale else None
         check(_lib.load().sgpr_set_weights(self._h, ptr(self.mu), ptr(self._table(self.mean, 0.0)), ptr(vs),
-                                           ptr(self.choli)))
+                                           ptr(self._choli)))
+
+    def commit_weights(self, mean=None):
+        """The tail of make_munu after a device solve: mu and choli are already installed on the device, only the
+        AutoMean weights follow (_vscale is what make_vscale just computed)."""
+        if mean is not None:
+            self.mean.update({int(z): float(w) for z, w in mean.items()})
+        check(_lib.load().sgpr_set_mean(self._h, ptr(self._table(self.mean, 0.0)), None))
 
     def solve(self, K, Y, noise=0.01):
         """make_munu (gppotential.py:548-605 -> _regression :1204-1339, optimize=False) on the
         device: jitcholesky(M), choli = L^-1, mu = lstsq([K; sigma L^T], [Y; 0])."""
         K = f64(K).reshape(-1, self.m)
         Y = f64(Y).reshape(-1)
-        mu, choli = np.zeros(self.m), np.zeros((self.m, self.m))
+        mu = np.zeros(self.m)
         ridge, sigma = C.c_double(0), C.c_double(0)
-        code = _lib.load().sgpr_solve(self._h, len(K), ptr(K), ptr(Y), float(noise), ptr(mu), ptr(choli),
+        code = _lib.load().sgpr_solve(self._h, len(K), ptr(K), ptr(Y), float(noise), ptr(mu), None,
                                       C.addressof(ridge), C.addressof(sigma))
         if code == _lib.E_NOT_PD:
             raise RuntimeError("cholesky was not successful!")  # theforce/regression/algebra.py:45-46
         check(code)
-        self.mu, self.choli, self.ridge, self.sigma = mu, choli, ridge.value, sigma.value
+        self.mu, self.ridge, self.sigma = mu, ridge.value, sigma.value
+        self._choli, self._choli_on_device = None, True
         self.make_vscale()
         return mu
 
@@ -309,15 +331,16 @@ class SGPRModel:
         Y = f64(Y).reshape(-1)
         if len(Y) != self.data_info()[1]:
             raise ValueError(f"data_solve: {len(Y)} targets for {self.data_info()[1]} stored rows")
-        mu, choli = np.zeros(self.m), np.zeros((self.m, self.m))
+        mu = np.zeros(self.m)
         ridge, sigma = C.c_double(0), C.c_double(0)
         self.generation += 1
-        code = _lib.load().sgpr_data_solve(self._h, ptr(Y), int(bool(with_energies)), float(noise), ptr(mu), ptr(choli),
+        code = _lib.load().sgpr_data_solve(self._h, ptr(Y), int(bool(with_energies)), float(noise), ptr(mu), None,
                                            C.addressof(ridge), C.addressof(sigma))
         if code == _lib.E_NOT_PD:
             raise RuntimeError("cholesky was not successful!")  # theforce/regression/algebra.py:45-46
         check(code)
-        self.mu, self.choli, self.ridge, self.sigma = mu, choli, ridge.value, sigma.value
+        self.mu, self.ridge, self.sigma = mu, ridge.value, sigma.value
+        self._choli, self._choli_on_device = None, True
         self.make_vscale()
         return mu
 

@@ -400,7 +400,10 @@ class PosteriorPotential:
             for z, val in zip(sorted(self.mean.weights), w):
                 self.mean.weights[z] = float(val)
         # the engine evaluates with exactly these numbers from now on
-        self.engine.set_weights(self.engine.mu, mean=self.mean.weights, choli=self.engine.choli)
+        if self._sync is None and hasattr(self.engine, "commit_weights"):
+            self.engine.commit_weights(mean=self.mean.weights)  # (mu and choli are where the solve left them)
+        else:
+            self.engine.set_weights(self.engine.mu, mean=self.mean.weights, choli=self.engine.choli)
         self.make_stats()
 
     def _optimize(self, noise_f):

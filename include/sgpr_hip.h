@@ -94,6 +94,16 @@ int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, cons
                      const double *choli);
 
 /*
+ * After a device solve (sgpr_solve / sgpr_data_solve / sgpr_resolve) mu and choli are already where prediction
+ * reads them: sgpr_set_mean installs the remaining outputs of make_munu — the AutoMean weights
+ * (regression/gppotential.py:219-227) and, optionally, _vscale (NULL: keep the one sgpr_make_vscale computed) —
+ * without moving the m x m choli over PCIe and back.  sgpr_get_choli downloads choli[m][m] (caller's order) for the
+ * callers that still want it on the host (leakage, gppotential.py:706-713; model files).
+ */
+int sgpr_set_mean(sgpr_model *h, const double *mean_w, const double *vscale);
+int sgpr_get_choli(sgpr_model *h, double *choli);
+
+/*
  * Solve side on the device (regression/gppotential.py:1204-1339 _regression with
  * optimize=False; regression/algebra.py:29-47 jitcholesky):
  *   L, ridge = jitcholesky(K_mm); choli = L^-1; sigma = noise0*0.99*mean(diag K_mm);
