@@ -262,3 +262,27 @@ def test_columns_through_the_kept_reflectors():
         if k % 7 == 0 or k > 36:
             check(Y)
     mdl.close()
+
+
+def test_weights_stay_on_the_device_after_a_solve():
+    """make_munu's tail (gppotential.py:548-605): after a device solve, commit_weights (mean only) must leave the
+    evaluator in the state set_weights(mu, choli) builds from the downloaded arrays."""
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    fr = (g["numbers"], g["positions"], g["cell"], g["pbc"])
+    mdl.data_push(*fr, 6)
+    rng = np.random.default_rng(2)
+    Y = rng.normal(size=mdl.data_info()[1])
+    mu = mdl.data_solve(Y, noise=0.03)
+    mean = {int(z): float(w) for z, w in zip(mdl.species, rng.normal(size=len(mdl.species)))}
+    mdl.commit_weights(mean=mean)
+    a = mdl.predict(*fr)
+    choli = mdl.choli                       # downloaded on demand
+    assert choli.shape == (mdl.m, mdl.m) and np.allclose(choli @ mdl.M @ choli.T, np.eye(mdl.m), atol=1e-6)
+    ref = mdl.scratch()
+    ref.set_inducing(mdl.X)
+    ref.set_weights(mu, mean=mean, vscale=mdl._vscale, choli=choli)
+    b = ref.predict(*fr)
+    for k in ("energy", "forces", "stress", "beta"):
+        np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
+    mdl.close(); ref.close()
