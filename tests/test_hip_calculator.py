@@ -335,6 +335,35 @@ def test_baseline_config5_oxide16384_m1024():
     mdl.close()
 
 
+def test_large_cell_beyond_the_bin_grid_cap():
+    """110 592 atoms in a 130.6 A cube: the neighbour grid wants 20 bins per edge and gets its cap of 16 (wider bins,
+    more candidates per sweep, same pairs).  Pair set and E / F / stress / covloss against the oracle's own
+    linked-cell list and reverse pass."""
+    from oracle import oracle as orc
+    mdl, numbers, pos, cell, pbc = _lips_model(48, 64)
+    N = len(numbers)
+    assert N == 110592
+    out = mdl.predict(numbers, pos, cell, pbc, cov=False)
+    nl = orc.neighbors_cells(pos, cell, pbc, 6.0)
+    ptr, j, off = mdl.neighbors(N)
+    np.testing.assert_array_equal(ptr, nl[0])
+    # same pairs: both lists sorted per atom by (j, image)
+    def canon(p, jj, oo):
+        key = np.lexsort((oo[:, 2], oo[:, 1], oo[:, 0], jj, np.repeat(np.arange(len(p) - 1), np.diff(p))))
+        return jj[key], oo[key]
+    ja, oa = canon(ptr, np.asarray(j), np.asarray(off))
+    jb, ob = canon(nl[0], np.asarray(nl[1]), np.asarray(nl[2]))
+    np.testing.assert_array_equal(ja, jb)
+    np.testing.assert_array_equal(oa, ob)
+    ref = _oracle_frame(mdl, numbers, pos, cell, nl)
+    assert abs(out["energy"] - ref["energy"]) <= 1e-9 * abs(ref["energy"])
+    assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
+    assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
+    vs = np.sqrt([mdl._vscale[int(z)] for z in numbers])
+    np.testing.assert_allclose(out["beta"], ref["beta"] * vs, rtol=0, atol=5e-6 * vs.max())
+    mdl.close()
+
+
 def test_single_atom_lce_from_device():
     """sgpr_get_local == the LCE assembled on the host from the full neighbour list
     (descriptor/atoms.py:365-382), for periodic images and an empty environment."""
