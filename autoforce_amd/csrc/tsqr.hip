@@ -78,6 +78,16 @@ __device__ __forceinline__ double wave_sum64(double v)
 //   every thread: g_c = 16 partials, rank-1 update of its 16 rows; the owner of column j + 1 publishes it.
 // No cross-lane reductions.  Two waves per SIMD hide each other's latencies (the step is a chain of dependent short
 // operations).  V^T V (for T) is one MFMA product at the end; T is built in 16 x 16 blocks.
+// the value held by the lane 32 away (v_permlane32_swap: upper half of one operand <-> lower half of the other)
+__device__ __forceinline__ double half_swap(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    const bool low = (threadIdx.x & 32) == 0;
+    return __hiloint2double(low ? rh[1] : rh[0], low ? rl[1] : rl[0]);
+}
+
 #define TLT 512  // threads of the leaf kernel
 #define TRG 16   // rows per thread (= row groups)
 __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
@@ -86,8 +96,8 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
     double *sm = lds;                     // [TNB][TLD]  the chunk on its way in, V (masked) on its way out
     double *G = lds + TNB * TLD;          // [TNB][TNB + 1]:  V^T V
     double *Ts = G + TNB * (TNB + 1);     // [TNB][TNB + 1]
-    __shared__ __attribute__((aligned(16))) double vbuf[2][TCH], pn[2][16];   // vbuf[.][16 g + k] = row g + 16 k
-    __shared__ double part[16][TNB + 1], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
+    __shared__ __attribute__((aligned(16))) double vbuf[2][TCH], pn[2][8];   // vbuf[.][16 g + k] = row g + 16 k
+    __shared__ double part[16][TNB + 1], rowj[TNB], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = tid & 31, rg = tid >> 5, r0 = rg * TRG;
     const int chunk = blockIdx.x;
@@ -110,48 +120,70 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
     double a[TRG];
 #pragma unroll
     for (int k = 0; k < TRG; k++) a[k] = sm[c * TLD + rg + TRG * k];
-    if (c == 0) {  // column 0 and its norm
+    if (c == 0) {  // column 0 and its norm (per wave: both row groups)
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < TRG; k++) { vbuf[0][r0 + k] = a[k]; s += a[k] * a[k]; }
-        pn[0][rg] = s;
+        const double sp = s + half_swap(s);
+        if (lane < 32) pn[0][wave] = sp;
     }
     __syncthreads();
     for (int j = 0; j < q.nb; j++) {
         const int jb = j & 1;
+        // the scalar chain (norm -> alpha -> 2 / v.v) does not feed the products below: they run on the RAW column x
+        // (v_j = x - alpha e_j), and g_c = x . a_c - alpha a_c[j] is put together after the barrier — the chain's
+        // square root and division overlap with the LDS traffic
         double s2 = 0.0;
 #pragma unroll
-        for (int g = 0; g < 16; g += 2) {
+        for (int g = 0; g < 8; g += 2) {
             const double2 x = *(const double2 *)&pn[jb][g];
             s2 += x.x + x.y;
         }
         const double akk = vbuf[jb][(j & 15) * TRG + (j >> 4)];
-        const double nrm = sqrt(s2);
+        // |x| and 2 / (v.v) = 1 / (|x| (|x| + |x_j|)) from the hardware seeds + one Newton step each (every wave
+        // repeats this chain at every step: the IEEE sqrt / division sequences were a third of the step's instructions)
+        double nrm = 0.0, sc = 0.0;
+        if (s2 > 0.0) {
+            double rs = __builtin_amdgcn_rsq(s2);
+            rs = rs * (1.5 - 0.5 * s2 * rs * rs);
+            nrm = s2 * rs;
+            nrm = nrm + 0.5 * rs * (s2 - nrm * nrm);
+            const double d = nrm * (nrm + fabs(akk));
+            double rd = __builtin_amdgcn_rcp(d);
+            rd = rd * (2.0 - d * rd);
+            sc = rd * (2.0 - d * rd);
+        }
         const double alpha = akk > 0.0 ? -nrm : nrm;
         const double vjj = akk - alpha;
-        const double vv = s2 - akk * akk + vjj * vjj;
-        const double sc = vv > 0.0 ? 2.0 / vv : 0.0;
         if (tid == 0) { s_alpha[j] = alpha; s_scal[j] = sc; s_vjj[j] = vjj; }
-        double vj[TRG], t4[4] = {0.0, 0.0, 0.0, 0.0};
+        double xj[TRG], t4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < TRG; k += 2) {
             const double2 x = *(const double2 *)&vbuf[jb][r0 + k];
-            vj[k] = x.x; vj[k + 1] = x.y;
-        }
-        if (rg == (j & 15)) {  // this group holds the pivot row, at slot 0 or 1
-            if (j < 16) vj[0] = vjj;
-            else vj[1] = vjj;
+            xj[k] = x.x; xj[k + 1] = x.y;
         }
 #pragma unroll
-        for (int k = 0; k < TRG; k++) t4[k & 3] += vj[k] * a[k];
-        part[rg][c] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+        for (int k = 0; k < TRG; k++) t4[k & 3] += xj[k] * a[k];
+        {
+            // the two row groups of a wave are summed before they reach LDS (one v_permlane32_swap per half)
+            const double t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+            const double tp = t + half_swap(t);
+            if (lane < 32) part[wave][c] = tp;
+        }
+        const bool pivot_group = rg == (j & 15);
+        if (pivot_group) rowj[c] = j < 16 ? a[0] : a[1];  // row j of every column
         __syncthreads();
         double g4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 16; u++) g4[u & 3] += part[u][c];
-        const double f = c > j ? sc * ((g4[0] + g4[1]) + (g4[2] + g4[3])) : 0.0;
+        for (int u = 0; u < 8; u++) g4[u & 3] += part[u][c];
+        const double g = ((g4[0] + g4[1]) + (g4[2] + g4[3])) - alpha * rowj[c];
+        const double f = c > j ? sc * g : 0.0;
 #pragma unroll
-        for (int k = 0; k < TRG; k++) a[k] -= f * vj[k];
+        for (int k = 0; k < TRG; k++) a[k] -= f * xj[k];
+        if (pivot_group) {  // the pivot entry of v_j is x_j[j] - alpha
+            if (j < 16) a[0] += f * alpha;
+            else a[1] += f * alpha;
+        }
         if (c == j + 1) {  // publish the next pivot column (zero above its diagonal: rows <= j) and its norm
             double x[TRG], s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -164,7 +196,9 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
                 s4[k & 3] += x[k] * x[k];
                 s4[(k + 1) & 3] += x[k + 1] * x[k + 1];
             }
-            pn[jb ^ 1][rg] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            const double sn = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            const double sp = sn + half_swap(sn);
+            if (lane < 32) pn[jb ^ 1][wave] = sp;
         }
         __syncthreads();
     }
