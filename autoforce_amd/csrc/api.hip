@@ -171,6 +171,7 @@ struct sgpr_model {
         uint64_t age = 0;
     };
     QrKeep qr_keep[4];
+    int qr_keep_mode = 1;  // option "qr_keep" (environment SGPR_QR_KEEP at creation): 1 on, 0 off, 2 verify
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
     DevBuf<double> d_edit_tmp;  // scratch of the incremental inducing-set edits
@@ -461,6 +462,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds
     h->d_cell0.alloc(9);
     if (getenv("SGPR_STAMPS")) h->d_stamps.alloc(4 * 4096);
+    if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
     return SGPR_OK;
 }
@@ -1467,6 +1469,12 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "qr_keep")) {
+        if (value < 0 || value > 2) return fail(SGPR_E_INVALID, "sgpr_set_option: qr_keep is 0, 1 or 2");
+        h->qr_keep_mode = value;
+        for (auto &k : h->qr_keep) k.valid = false;
+        return SGPR_OK;
+    }
     if (!strcmp(name, "skin_milliangstrom")) {
         if (value < 0) return fail(SGPR_E_INVALID, "sgpr_set_option: negative skin");
         h->skin = 1e-3 * value;

@@ -256,6 +256,11 @@ int sgpr_sync_check(sgpr_model *h, void *stream);
 /* Options:
  *  "graph" = 0/1            replay sgpr_step_dev from a captured HIP graph (default 0: eager launches pipeline
  *                           well while a step is ~100 us of kernels and measured faster than replay)
+ *  "qr_keep" = 1/0/2        the first-stage factorisation of sgpr_data_solve is kept with its reflectors, so that
+ *                           an appended / popped inducing LCE and a pushed frame update it instead of refactoring
+ *                           (default 1; 0: every refit factors from scratch, as the reference does,
+ *                           gppotential.py:745-791; 2: both, the difference of mu printed on stderr).  The
+ *                           environment variable SGPR_QR_KEEP sets the initial value.
  *  "skin_milliangstrom"     Verlet skin of the neighbour candidates (default 500 = 0.5 A).  The reference asks ASE
  *                           for a list with skin 0 at every step (descriptor/atoms.py:349-355); here candidate
  *                           lists of |r| < rc + skin are kept and rebuilt ON THE DEVICE whenever an atom has moved

@@ -286,3 +286,42 @@ def test_weights_stay_on_the_device_after_a_solve():
     for k in ("energy", "forces", "stress", "beta"):
         np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
     mdl.close(); ref.close()
+
+
+def test_kept_and_from_scratch_factorisations_agree():
+    """Option "qr_keep": the same edit sequence with the kept factorisation (default) and with a factorisation from
+    scratch at every refit (what the reference does, gppotential.py:745-791)."""
+    from autoforce_amd import _lib
+    g = load("g5_mixed64")
+    X = list(model_from_fixture(g).X)
+    frames = systems()
+    rng = np.random.default_rng(8)
+    Y = None
+    res = {}
+    for mode in (1, 0):
+        mdl = model_from_fixture(g)
+        _lib.check(_lib.load().sgpr_set_option(mdl.handle, b"qr_keep", mode))
+        mdl.set_inducing(X[:8])
+        for fr in frames[:2]:
+            mdl.data_push(*fr, 6)
+        if Y is None:
+            Y = rng.normal(size=mdl.data_info()[1] + 1 + 3 * len(frames[2][0]) + 6)
+        out = []
+        n2 = mdl.data_info()[1]
+        out.append(mdl.data_solve(Y[:n2], noise=0.02).copy())
+        for x in X[8:12]:
+            mdl.add_inducing(x)
+            out.append(mdl.data_solve(Y[:n2], noise=0.02).copy())
+        mdl.remove_inducing(-1)
+        out.append(mdl.data_solve(Y[:n2], noise=0.02).copy())
+        out.append(mdl.data_solve(Y[:n2], noise=0.02, with_energies=False).copy())
+        mdl.data_push(*frames[2], 6)
+        out.append(mdl.data_solve(Y, noise=0.02).copy())
+        K = mdl.data_get()
+        res[mode] = (out, K)
+        mdl.close()
+    K = res[1][1]
+    np.testing.assert_array_equal(K, res[0][1])
+    for a, b in zip(res[1][0], res[0][0]):
+        Ka = K[:, :len(a)] if len(a) == K.shape[1] else None
+        assert np.abs(a - b).max() <= 1e-7 * np.abs(b).max()
