@@ -140,6 +140,13 @@ struct sgpr_model {
     };
     std::vector<DataFrame> frames;
     DevBuf<double> d_design, d_qr_A, d_qr_work;
+    // scratch of the update-path entry points, kept between calls (hipMalloc / hipFree per call cost more than the
+    // kernels they served: a refit makes a dozen such calls)
+    DevBuf<double> sc_s2A, sc_s2x, sc_s2work, sc_mv_v, sc_mv_o, sc_ra_y, sc_ra_t, sc_vs_t, sc_ai_er, sc_ai_p, sc_ai_norm,
+        sc_ai_krow, sc_ai_kself, sc_y;
+    DevBuf<int> sc_s2so, sc_ai_eslot, sc_ai_oslot, sc_ai_onn, sc_ai_info;
+    DevBuf<int64_t> sc_ai_ptr;
+    DevBuf<unsigned char> sc_ise;
     int64_t design_rcap = 0, design_ccap = 0, design_rows = 0;
     bool design_hold = false;  // an edit entry point is re-indexing the columns itself
     // identity of the matrix: one id per stored frame and per inducing column (a pop returns to the earlier lists),
@@ -528,6 +535,15 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     for (auto b : db) b->release();
     h->d_rows_cols.release();
     if (h->pin) (void)hipHostFree(h->pin);
+    {
+        DevBuf<double> *sd[] = {&h->sc_s2A, &h->sc_s2x, &h->sc_s2work, &h->sc_mv_v, &h->sc_mv_o, &h->sc_ra_y, &h->sc_ra_t, &h->sc_vs_t,
+                                &h->sc_ai_er, &h->sc_ai_p, &h->sc_ai_norm, &h->sc_ai_krow, &h->sc_ai_kself, &h->sc_y};
+        for (auto b : sd) b->release();
+        DevBuf<int> *si[] = {&h->sc_s2so, &h->sc_ai_eslot, &h->sc_ai_oslot, &h->sc_ai_onn, &h->sc_ai_info};
+        for (auto b : si) b->release();
+        h->sc_ai_ptr.release();
+        h->sc_ise.release();
+    }
     for (auto &e : h->r1_cache) e.r1.release();
     for (auto &k : h->qr_keep) { k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
