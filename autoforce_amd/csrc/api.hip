@@ -245,6 +245,8 @@ struct FinArgs {
     double mean_energy;
     double *packed;
     int *stat, *bin_count;
+    const int *row_cols, *row_colslot, *nbr_code;   // training rows: column of each batch entry, species slot of every
+                                                    // column, the lists' code words (neighbour species in bits 24..31)
     size_t g_stride, f_stride, v_stride, p_stride;  // batch (blockIdx.y, training rows): doubles between entries of
                                                     // G, [Fnbr | Fself], virpart, packed
     const int *flag;            // this step's rebuild flag: set -> the candidates were rebuilt from `pos`
@@ -343,9 +345,10 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     }
     const double vs = f.has_beta ? f.vs_sqrt[f.slot[i]] : 0.0;
     double fx = 0.0, fy = 0.0, fz = 0.0;
+    const int want = f.row_cols ? f.row_colslot[f.row_cols[by]] : -1;  // rows: only neighbours of the column's species wrote
     for (int t0 = 0; t0 < n; t0 += 64) {
         const int t = t0 + lane;
-        if (t < n) {
+        if (t < n && (want < 0 || ((f.nbr_code[(size_t)i * f.maxnn + t] >> 24) & 0xff) == want)) {
             const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + t) * 4);
             const double2 b0 = row[0], b1 = row[1];
             fx += b0.x; fy += b0.y; fz += b1.x;
@@ -1055,7 +1058,7 @@ static void stamp(sgpr_model *h, const char *name, hipStream_t st)
 
 // the step's last kernel.  gather: forces from the pair gradients G (reverse pass in gather form);
 // otherwise from the two force buffers of the scatter form (zero when no reverse pass ran).
-struct FinBatch { int batch; double *G, *F, *virpart; size_t g_stride, f_stride, v_stride, p_stride; };
+struct FinBatch { int batch; double *G, *F, *virpart; size_t g_stride, f_stride, v_stride, p_stride; const int *cols; };
 
 static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool beta, double mean_energy,
                             double *packed_dev, hipStream_t st, const FinBatch *fb = nullptr)
@@ -1076,6 +1079,7 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
         batch = fb->batch;
         f.G = fb->G; f.Fnbr = fb->F; f.Fself = fb->F + 3 * (size_t)N; f.virpart = fb->virpart;
         f.g_stride = fb->g_stride; f.f_stride = fb->f_stride; f.v_stride = fb->v_stride; f.p_stride = fb->p_stride;
+        f.row_cols = fb->cols; f.row_colslot = h->d_ind_slot.p; f.nbr_code = h->d_nbr_shift.p;
     }
     if (gather)
         hipLaunchKernelGGL(finalize_gather_kernel, dim3((std::max(N, 1) + 3) / 4 + 11, batch), dim3(256), 0, st, f);

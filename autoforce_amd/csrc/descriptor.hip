@@ -197,6 +197,7 @@ struct DescArgs {
     const double *rows_aw;  // [N][rows_ld] d k(i,q) / d(dot), or null (predict path: W below)
     const double *rows_pm;  // [m][Dpad]
     const int *rows_cols;   // [gridDim.y] species-sorted inducing index of each column of the batch
+    const int *rows_colslot; // [m] species slot of the inducing LCEs
     int rows_ld, batch;
     size_t g_stride, f_stride, v_stride;  // doubles between the batch entries of G, F (= [Fnbr | Fself]), vir_part
     const double *W;        // backward: [N][Dpad]
@@ -1191,8 +1192,15 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
         // ---------------------------------------------------------------- phase B: pair terms
         const double ang = a.shear[ia] ? SGPR_TINY_ANGLE : 0.0;
         double *stage = R;  // [CH][SP] one staged row set (hY, then gY); earlier in a tile: [CH][FS] radial rows
-        for (int t0 = 0; t0 < nn; t0 += CH) {
-            const int cnt = min(CH, nn - t0);
+        // training rows: an atom of another species than the column's has k(i,q) = 0 identically: no pair terms, and
+        // nothing to hand over — the finalize of a rows batch only adds the hand-overs of neighbours of the column's
+        // species (their species is in the list's code word), so the slots this atom would have cleared are never read
+        int nn_b = nn;
+        if constexpr (ROWS) {
+            if (a.slot[gi] != a.rows_colslot[bq]) nn_b = 0;
+        }
+        for (int t0 = 0; t0 < nn_b; t0 += CH) {
+            const int cnt = min(CH, nn_b - t0);
             const bool on = lane < cnt;
             const int t = t0 + lane;
             double r[3] = {1.0, 0.0, 0.0}, ex = 0.0;
@@ -1538,7 +1546,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
     a.Fself = F ? F + 3 * (size_t)p.Nall : nullptr;
     a.vir_part = virial;
     if (rows) {
-        a.rows_aw = rows->aw; a.rows_pm = rows->pm; a.rows_cols = rows->cols; a.rows_ld = rows->ld; a.batch = rows->batch;
+        a.rows_aw = rows->aw; a.rows_pm = rows->pm; a.rows_cols = rows->cols; a.rows_colslot = rows->col_slot; a.rows_ld = rows->ld; a.batch = rows->batch;
         a.g_stride = rows->g_stride; a.f_stride = rows->f_stride; a.v_stride = rows->v_stride;
     }
     DISPATCH_LNS(BWD, a, st);

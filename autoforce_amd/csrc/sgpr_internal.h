@@ -124,6 +124,8 @@ struct RowsBatch {
     const double *aw;   // [N][ld]
     const double *pm;   // [m][Dpad]
     const int *cols;    // [batch] species-sorted inducing index (device)
+    const int *col_slot; // [m] species slot of every (sorted) inducing LCE: an atom of another species has
+                        //     k(i,q) = 0 identically and sits the column out
     int ld, batch;
     size_t g_stride, f_stride, v_stride;  // doubles between batch entries of G, F, virial partials
 };
