@@ -39,6 +39,7 @@ SIGNATURES = {
     "sgpr_get_choli": (C.c_int, [_vp, _vp]),
     "sgpr_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_resolve": (C.c_int, [_vp, _dbl, _vp, _vp, _vp, _vp]),
+    "sgpr_resolve_batch": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sgpr_make_vscale": (C.c_int, [_vp, _vp]),
     "sgpr_kernel_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgpr_kernel_columns": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),

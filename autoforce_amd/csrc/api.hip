@@ -143,7 +143,7 @@ struct sgpr_model {
     // scratch of the update-path entry points, kept between calls (hipMalloc / hipFree per call cost more than the
     // kernels they served: a refit makes a dozen such calls)
     DevBuf<double> sc_s2A, sc_s2x, sc_s2work, sc_mv_v, sc_mv_o, sc_ra_y, sc_ra_t, sc_vs_t, sc_ai_er, sc_ai_p, sc_ai_norm,
-        sc_ai_krow, sc_ai_kself, sc_y;
+        sc_ai_krow, sc_ai_kself, sc_y, sc_bA, sc_bx, sc_bwork;
     DevBuf<int> sc_s2so, sc_ai_eslot, sc_ai_oslot, sc_ai_onn, sc_ai_info;
     DevBuf<int64_t> sc_ai_ptr;
     DevBuf<unsigned char> sc_ise;
@@ -540,7 +540,8 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     if (h->pin) (void)hipHostFree(h->pin);
     {
         DevBuf<double> *sd[] = {&h->sc_s2A, &h->sc_s2x, &h->sc_s2work, &h->sc_mv_v, &h->sc_mv_o, &h->sc_ra_y, &h->sc_ra_t, &h->sc_vs_t,
-                                &h->sc_ai_er, &h->sc_ai_p, &h->sc_ai_norm, &h->sc_ai_krow, &h->sc_ai_kself, &h->sc_y};
+                                &h->sc_ai_er, &h->sc_ai_p, &h->sc_ai_norm, &h->sc_ai_krow, &h->sc_ai_kself, &h->sc_y, &h->sc_bA, &h->sc_bx,
+                                &h->sc_bwork};
         for (auto b : sd) b->release();
         DevBuf<int> *si[] = {&h->sc_s2so, &h->sc_ai_eslot, &h->sc_ai_oslot, &h->sc_ai_onn, &h->sc_ai_info};
         for (auto b : si) b->release();

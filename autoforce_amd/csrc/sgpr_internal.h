@@ -199,6 +199,8 @@ size_t tsqr_keep_doubles(int rows, int cols, int band); // ... of every panel of
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /*[cols] or NULL: factor only*/,
                             double *work, hipStream_t st, int band = 0, double *keep = nullptr,
                             std::vector<TsqrPanel> *panels = nullptr);
+int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_mat, double *x, double *work, int batch,
+                            hipStream_t st, int band);
 void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st);
 void tsqr_append_column(double *vec, int rows, int k0, double *keep, TsqrPanel *rec, double *work, hipStream_t st);
 void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rc, int ldc, double *z, hipStream_t st);

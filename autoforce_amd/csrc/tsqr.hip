@@ -44,6 +44,9 @@ struct TsqrLeaf {
     double *Rnext;      // next level's chunks [chunk'][TNB][TCH] (R blocks stacked), or null at the top
     double *Rfinal;     // top: At + k0 * ldr + k0 (column-major, ldr)
     int ldr;
+    // a batch of independent problems of the same shape (blockIdx.y): doubles between their matrices / work arrays
+    size_t bs_mat, bs_work;
+    int src_in_work;    // level >= 1: src is the stacked R of the level below (work), else the matrix
 };
 
 // wave64 sum on the DPP network (no LDS round trips): quads, half rows, rows, then the four row sums through
@@ -102,6 +105,11 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
     const int c = tid & 31, rg = tid >> 5, r0 = rg * TRG;
     const int chunk = blockIdx.x;
     const int nr = min(TCH, q.n - chunk * TCH);
+    const size_t off_m = blockIdx.y * q.bs_mat, off_w = blockIdx.y * q.bs_work;
+    q.src += q.src_in_work ? off_w : off_m;
+    q.V += off_w; q.T += off_w;
+    if (q.Rnext) q.Rnext += off_w;
+    q.Rfinal += off_m;
     {
         // coalesced in (thread: 16 consecutive rows of its column), interleaved out.  Branch-free: a dead pair reads
         // the chunk's first element instead; a pair cut by the end of the matrix reads one element of padding — ldr
@@ -292,6 +300,7 @@ struct TsqrApply {
     int n;            // logical rows of this level
     int stride;       // physical rows between consecutive 32-row blocks of the logical numbering (32: contiguous)
     int tpw;          // column tiles per workgroup
+    size_t bs_mat, bs_work;  // batch of independent problems (blockIdx.z)
     const double *V;  // [chunk][TNB][TCH]
     const double *T;  // [chunk][TNB][TNB]
 };
@@ -310,6 +319,8 @@ __global__ __launch_bounds__(TCH) void tsqr_apply_kernel(TsqrApply q)
     double *Zs = Ws + TNB * (TNB + 1);   // [TNB][TNB + 1]  (-Z)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int chunk = blockIdx.y;
+    q.A += blockIdx.z * q.bs_mat;
+    q.V += blockIdx.z * q.bs_work; q.T += blockIdx.z * q.bs_work;
     const int tile0 = blockIdx.x * q.tpw, tile1 = min(tile0 + q.tpw, (q.ntrail + TNB - 1) / TNB);
     // rows (2p, 2p + 1) of the chunk x 16 columns per thread; logical row -> physical row of the matrix
     const int p = tid & 127, h = tid >> 7;
@@ -534,7 +545,7 @@ static void tsqr_attrs()
 // columns (trail[c * ld + r]) after every level.  V / T of every level go to `keep` (consecutive) when given — the
 // panel can then be applied again later (tsqr_apply_panels) — else to the per-level scratch in `work`.
 static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, double *trail, int ntrail, double *work,
-                       double *keep, TsqrPanel *rec, hipStream_t st)
+                       double *keep, TsqrPanel *rec, hipStream_t st, int batch = 1, size_t bs_mat = 0, size_t bs_work = 0)
 {
     std::vector<int> ch;
     tsqr_levels(std::max(row_end - k0, 1), ch);
@@ -566,7 +577,8 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
         lf.Rnext = top ? nullptr : Sl[l + 1];
         lf.Rfinal = panel_cols + k0;
         lf.ldr = ld;
-        hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks), dim3(TLT), lds_leaf_bytes(), st, lf);
+        lf.bs_mat = bs_mat; lf.bs_work = bs_work; lf.src_in_work = l > 0;
+        hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks, batch), dim3(TLT), lds_leaf_bytes(), st, lf);
         if (rec && rec->nlev < 8) {
             TsqrLevel &lv = rec->lv[rec->nlev++];
             lv.V = Vl[l]; lv.T = Tl[l]; lv.n = n; lv.chunks = chunks; lv.stride = stride;
@@ -580,8 +592,9 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
             ap.V = Vl[l]; ap.T = Tl[l];
             // enough workgroups to fill the chip several times over, else as many tiles per workgroup as possible
             const int ntiles = (ntrail + TNB - 1) / TNB;
-            ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * chunks / 1024)));
-            hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, chunks), dim3(TCH), lds_apply_bytes(), st, ap);
+            ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * chunks * batch / 1024)));
+            ap.bs_mat = bs_mat; ap.bs_work = bs_work;
+            hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, chunks, batch), dim3(TCH), lds_apply_bytes(), st, ap);
         }
         if (top) break;
         n = chunks * TNB;
@@ -615,6 +628,38 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
     if (x) {
         hipLaunchKernelGGL(qr_gather_r_kernel<true>, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rc, cols, z);
         hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rc, z, x);
+    }
+    return 0;
+}
+
+// `batch` independent least-squares problems of one shape in the same launches (grid dimension = problem): matrix b at
+// At + b * bs_mat, its solution at x + b * cols, its scratch at work + b * lstsq_qr_blocked_work_doubles(rows, cols).
+// The second stage of the regression for a dozen noise values at once: every launch of a single 2m x m band problem
+// occupies at most five of the 256 CUs.
+int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_mat, double *x, double *work, int batch,
+                            hipStream_t st, int band)
+{
+    if (cols > 2048 || rows < cols || ldr < rows || batch < 1) return -1;
+    tsqr_attrs();
+    const size_t bs_work = lstsq_qr_blocked_work_doubles(rows, cols);
+    size_t scratch = 0;
+    {
+        std::vector<int> ch;
+        tsqr_levels(rows, ch);
+        for (int c : ch) scratch += (size_t)c * (2 * TNB * TCH + TNB * TNB);
+    }
+    for (int k0 = 0; k0 < cols; k0 += TNB) {
+        const int nb = std::min(TNB, cols - k0);
+        const int row_end = band > 0 ? std::min(rows, band * (k0 + nb)) : rows;
+        const int ntrail = cols + 1 - (k0 + nb);
+        tsqr_panel(At + (size_t)k0 * ldr, ldr, k0, nb, row_end, At + (size_t)(k0 + nb) * ldr, ntrail, work, nullptr, nullptr, st,
+                   batch, bs_mat, bs_work);
+    }
+    for (int b = 0; b < batch; b++) {
+        double *Rc = work + b * bs_work + scratch, *z = Rc + (size_t)cols * cols;
+        hipLaunchKernelGGL(qr_gather_r_kernel<true>, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At + b * bs_mat, ldr, Rc,
+                           cols, z);
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rc, z, x + (size_t)b * cols);
     }
     return 0;
 }

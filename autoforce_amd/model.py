@@ -261,6 +261,17 @@ class SGPRModel:
         self.mu, self.ridge, self.sigma = mu, ridge.value, sigma.value
         return mu
 
+    def resolve_many(self, noises):
+        """mu for each of `noises` from the factored [K | Y] of the last solve, evaluated together on the device
+        (the grid scan of the noise search); the installed weights do not change.  Returns [len(noises), m]."""
+        noises = f64(noises).reshape(-1)
+        out = np.zeros((len(noises), self.m))
+        for a in range(0, len(noises), 64):
+            part = np.zeros((min(64, len(noises) - a), self.m))
+            check(_lib.load().sgpr_resolve_batch(self._h, len(part), ptr(f64(noises[a:a + 64])), ptr(part)))
+            out[a:a + len(part)] = part
+        return out
+
     def kernel_rows(self, numbers, positions, cell, pbc):
         """(Ke[m], Kf[3N,m], Kv[6,m]) of one data frame (gppotential.py:63-84, :495-497)."""
         numbers = i32(numbers)

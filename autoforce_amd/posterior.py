@@ -434,8 +434,13 @@ class PosteriorPotential:
             return cache[x]
 
         x0 = float(self._noise["all"])
-        f0 = objective(x0)
         grid = [x0 + d for d in (-6.0, -4.0, -3.0, -2.0, -1.0, -0.5, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0)]
+        if hasattr(self.engine, "resolve_many"):
+            # the scan is a batch of independent second-stage problems: one set of launches for all of them
+            xs = sorted({float(np.clip(x, -14.0, 14.0)) for x in grid + [x0]})
+            for x, mu in zip(xs, self.engine.resolve_many([_sigmoid(x) for x in xs])):
+                cache[x] = float((np.abs(self._matvec(mu)[1] - f).mean() - noise_f) ** 2)
+        f0 = objective(x0)
         vals = [objective(x) for x in grid]
         k = int(np.argmin(vals))
         if vals[k] < f0 * (1.0 - 1e-3):

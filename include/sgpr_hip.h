@@ -118,6 +118,10 @@ int sgpr_solve(sgpr_model *h, int rows, const double *K, const double *Y, double
  * the QR of [K | Y] is kept on the device (R, Q^T Y), the noise only enters a 2m x m second stage.
  * This is what _regression(optimize=True) evaluates repeatedly (gppotential.py:1265-1300). */
 int sgpr_resolve(sgpr_model *h, double noise0, double *mu, double *choli, double *ridge, double *sigma);
+/* The same for `count` (<= 64) noise values in one go, mu_out[count][m]: the grid scan of the noise search
+ * (gppotential.py:1283-1296 describes it) as ONE batch of independent second-stage problems sharing every kernel
+ * launch.  Evaluation only: the weights installed for prediction stay those of the last sgpr_solve / sgpr_resolve. */
+int sgpr_resolve_batch(sgpr_model *h, int count, const double *noise, double *mu_out);
 
 /*
  * Training rows of one data frame against the inducing set, on the device

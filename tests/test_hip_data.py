@@ -325,3 +325,25 @@ def test_kept_and_from_scratch_factorisations_agree():
     for a, b in zip(res[1][0], res[0][0]):
         Ka = K[:, :len(a)] if len(a) == K.shape[1] else None
         assert np.abs(a - b).max() <= 1e-7 * np.abs(b).max()
+
+
+def test_batched_resolve_equals_resolve():
+    """sgpr_resolve_batch: a dozen noise values in one set of launches give the weights of a dozen sgpr_resolve calls
+    (same arithmetic per problem: bit for bit), and leave the installed weights alone."""
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    for fr in systems()[:2]:
+        mdl.data_push(*fr, 6)
+    rng = np.random.default_rng(5)
+    Y = rng.normal(size=mdl.data_info()[1])
+    mu0 = mdl.data_solve(Y, noise=0.02).copy()
+    before = mdl.predict(*systems()[0])
+    noises = [1e-4, 3e-3, 0.02, 0.1, 0.3, 0.7, 0.02]
+    many = mdl.resolve_many(noises)
+    after = mdl.predict(*systems()[0])
+    np.testing.assert_array_equal(before["forces"], after["forces"])
+    np.testing.assert_array_equal(many[2], mu0)
+    np.testing.assert_array_equal(many[6], mu0)
+    for k, nz in enumerate(noises):
+        np.testing.assert_array_equal(many[k], mdl.resolve(noise=nz))
+    mdl.close()
