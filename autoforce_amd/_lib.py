@@ -37,6 +37,7 @@ SIGNATURES = {
     "sgpr_set_weights": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sgpr_set_mean": (C.c_int, [_vp, _vp, _vp]),
     "sgpr_get_choli": (C.c_int, [_vp, _vp]),
+    "sgpr_restore_weights": (C.c_int, [_vp, _vp]),
     "sgpr_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_resolve": (C.c_int, [_vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_resolve_batch": (C.c_int, [_vp, C.c_int, _vp, _vp]),

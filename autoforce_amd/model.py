@@ -234,6 +234,23 @@ class SGPRModel:
             self.mean.update({int(z): float(w) for z, w in mean.items()})
         check(_lib.load().sgpr_set_mean(self._h, ptr(self._table(self.mean, 0.0)), None))
 
+    def snapshot_weights(self):
+        """What a rejected trial has to put back (see restore_weights)."""
+        return dict(mu=None if self.mu is None else self.mu.copy(), ridge=self.ridge, sigma=self.sigma,
+                    vscale=dict(self._vscale), mean=dict(self.mean))
+
+    def restore_weights(self, snap):
+        """After the pop that ends a rejected trial: the weights saved before it, instead of a refit that would
+        reproduce them (gppotential.py:898-982)."""
+        check(_lib.load().sgpr_restore_weights(self._h, ptr(f64(snap["mu"]))))
+        self.mu = snap["mu"].copy()
+        self.ridge, self.sigma = snap["ridge"], snap["sigma"]
+        self._vscale = dict(snap["vscale"])
+        self.mean.update(snap["mean"])
+        self._choli, self._choli_on_device = None, True
+        vs = f64([self._vscale.get(z, np.inf) for z in self.species])
+        check(_lib.load().sgpr_set_mean(self._h, ptr(self._table(self.mean, 0.0)), ptr(vs)))
+
     def solve(self, K, Y, noise=0.01):
         """make_munu (gppotential.py:548-605 -> _regression :1204-1339, optimize=False) on the
         device: jitcholesky(M), choli = L^-1, mu = lstsq([K; sigma L^T], [Y; 0])."""

@@ -12,6 +12,8 @@ Y = [E − mean; F; V·stress], plus the σ Lᵀ regulariser rows added inside t
 """
 from collections import Counter
 
+import copy
+
 import numpy as np
 
 EPS = float(np.finfo(np.float64).eps)  # torch.finfo().eps with the reference's fp64 default
@@ -511,6 +513,27 @@ class PosteriorPotential:
         return np.array([self.leakage(x) for x in locs])
 
     # ------------------------------------------------------------------ acceptance rules
+    _SNAP = ("scaled_noise", "_stats", "_ediff", "_fdiff", "_force_r2", "_f_max", "indu_counts", "kern_diag_mean")
+
+    def _snapshot(self):
+        """The fitted state a trial may have to put back: a rejected trial pops its edit and the reference refits
+        (gppotential.py:898-982) — for exactly the model it had before.  Engines that can restore weights get them
+        back instead of solving for them again."""
+        if not hasattr(self.engine, "restore_weights") or self.engine.mu is None:
+            return None
+        snap = {k: copy.copy(getattr(self, k)) for k in self._SNAP if hasattr(self, k)}
+        snap["mean"] = dict(self.mean.weights)
+        snap["engine"] = self.engine.snapshot_weights()
+        return snap
+
+    def _restore(self, snap):
+        for k, v in snap.items():
+            if k not in ("mean", "engine"):
+                setattr(self, k, v)
+        self.mean.weights.clear()
+        self.mean.weights.update(snap["mean"])
+        self.engine.restore_weights(snap["engine"])
+
     def add_1inducing(self, loc, ediff):
         """gppotential.py:955-982: keep the LCE only if it moves its own energy by >= ediff."""
         if loc.number not in self.species:
@@ -519,12 +542,17 @@ class PosteriorPotential:
             self.add_inducing(loc)  # with no data yet there is nothing to border or refit
             return 1, inf
         e1 = self.energy_of(loc)
+        snap = self._snapshot()
         self.add_inducing(loc)
         e2 = self.energy_of(loc)
         de = abs(e1 - e2)
         blind = abs(e1) <= 1e-8 and abs(e2) <= 1e-8  # torch.allclose(..., zeros): atol 1e-8
         if (de < ediff and not blind) or self.ridge > 0.0:
-            self.pop_1inducing()
+            if snap is None:
+                self.pop_1inducing()
+            else:
+                self.pop_1inducing(remake=False)
+                self._restore(snap)
             return 0, de
         return 1, de
 
@@ -564,6 +592,7 @@ class PosteriorPotential:
             return 1, inf, inf
         use_forces = fdiff < inf
         mu1 = self.engine.mu.copy()
+        snap = self._snapshot()
         if self.resident:
             # the frame's rows never leave the device: its k·mu before and after the refit are two products
             self.add_data([fr])
@@ -586,7 +615,11 @@ class PosteriorPotential:
             reject = float((d * d).mean()) < fdiff * fdiff and float(np.abs(d).max()) < 3 * fdiff
         blind = abs(e1) <= 1e-8 and abs(e2) <= 1e-8
         if reject and not blind:
-            self.pop_1data()
+            if snap is None:
+                self.pop_1data()
+            else:
+                self.pop_1data(remake=False)
+                self._restore(snap)
             return 0, de, df
         return 1, de, df
 

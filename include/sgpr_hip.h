@@ -102,6 +102,11 @@ int sgpr_set_weights(sgpr_model *h, const double *mu, const double *mean_w, cons
  */
 int sgpr_set_mean(sgpr_model *h, const double *mean_w, const double *vscale);
 int sgpr_get_choli(sgpr_model *h, double *choli);
+/* The end of a rejected trial (add_1inducing / add_1atoms_fast, gppotential.py:898-982: edit, refit, measure, pop,
+ * refit): after the pop the model is the one the trial started from, so the caller hands back the mu it saved instead
+ * of asking for the same fit again.  The K_mm factor (hence choli) of the restored inducing set is the cached one or
+ * is recomputed here; follow with sgpr_set_mean for the mean / _vscale. */
+int sgpr_restore_weights(sgpr_model *h, const double *mu);
 
 /*
  * Solve side on the device (regression/gppotential.py:1204-1339 _regression with

@@ -135,6 +135,17 @@ class OracleModel:
             self._vscale = {int(z): float(v) for z, v in vscale.items()}
         self.choli = None if choli is None else np.asarray(choli, float).copy()
 
+    def snapshot_weights(self):
+        return dict(mu=None if self.mu is None else self.mu.copy(), choli=None if self.choli is None else self.choli.copy(),
+                    ridge=self.ridge, sigma=self.sigma, vscale=dict(self._vscale), mean=dict(self.mean))
+
+    def restore_weights(self, snap):
+        """The end of a rejected trial: the state saved before it (SGPRModel.restore_weights)."""
+        self.mu, self.choli = snap["mu"].copy(), snap["choli"].copy()
+        self.ridge, self.sigma = snap["ridge"], snap["sigma"]
+        self._vscale = dict(snap["vscale"])
+        self.mean.update(snap["mean"])
+
     # ---- evaluation
     def predict(self, numbers, positions, cell, pbc, rank=0, world=1, cov=False, beta=True):
         self.calls += 1
