@@ -354,6 +354,17 @@ class SGPRModel:
             check(_lib.load().sgpr_data_get(self._h, ptr(out)))
         return out
 
+    def data_factor(self, Y, with_energies=True):
+        """The first stage of data_solve alone: [R1, z] of the resident [K | Y] for resolve / resolve_many."""
+        Y = f64(Y).reshape(-1)
+        if len(Y) != self.data_info()[1]:
+            raise ValueError(f"data_factor: {len(Y)} targets for {self.data_info()[1]} stored rows")
+        self.generation += 1
+        code = _lib.load().sgpr_data_factor(self._h, ptr(Y), int(bool(with_energies)))
+        if code == _lib.E_NOT_PD:
+            raise RuntimeError("cholesky was not successful!")
+        check(code)
+
     def data_solve(self, Y, with_energies=True, noise=0.01):
         """`solve` on the resident matrix (Y in its row order)."""
         Y = f64(Y).reshape(-1)

@@ -368,12 +368,15 @@ class PosteriorPotential:
         return ch1, ch2
 
     # ------------------------------------------------------------------ regression
-    def _solve(self, with_energies, x=None):
-        """One make_mu of _regression (gppotential.py:1245-1263) on the device."""
+    def _solve(self, with_energies, x=None, factor_only=False):
+        """One make_mu of _regression (gppotential.py:1245-1263) on the device.  factor_only: the first stage alone
+        (what the noise search re-solves from), where the engine offers it."""
         noise = _sigmoid(self._noise["all"] if x is None else x)
         if self.resident:
             Y = [np.concatenate([[fr.energy - self.mean(fr.counts())], fr.forces.reshape(-1)] +
                                 ([fr.stress * fr.get_volume()] if fr.stress is not None else [])) for fr in self.data]
+            if factor_only and hasattr(self.engine, "data_factor") and hasattr(self.engine, "resolve_many"):
+                return self.engine.data_factor(np.concatenate(Y), with_energies=with_energies)
             return self.engine.data_solve(np.concatenate(Y), with_energies=with_energies, noise=noise)
         e, f, v = self.targets()
         if with_energies:
@@ -425,7 +428,7 @@ class PosteriorPotential:
         point the reference's second BFGS converges to)."""
         from scipy.optimize import minimize_scalar
         _, f, _ = self.targets()
-        self._solve(with_energies=False)  # factors [Kf; Kv | F; V] once; the search only re-solves
+        self._solve(with_energies=False, factor_only=True)  # factors [Kf; Kv | F; V] once; the search only re-solves
         cache = {}
 
         def objective(x):

@@ -168,6 +168,8 @@ int sgpr_kernel_columns(sgpr_model *h, int N, const int32_t *numbers, const doub
  *   sgpr_data_solve   sgpr_solve on the resident matrix: Y[rows] in the same row order; with_energies = 0 drops
  *                     the energy rows (the force-only fit of _regression(optimize=True), gppotential.py:1265-1300);
  *                     sgpr_resolve re-solves it for another noise as after sgpr_solve.
+ *   sgpr_data_factor  the first stage of sgpr_data_solve alone (K_mm factor, R1 and z kept on the device for
+ *                     sgpr_resolve / sgpr_resolve_batch); no weights are produced or installed.
  */
 int sgpr_data_push(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
                    const int32_t *pbc, int nv);
@@ -178,6 +180,7 @@ int sgpr_data_matvec(sgpr_model *h, const double *v, double *out);
 int sgpr_data_get(sgpr_model *h, double *K);
 int sgpr_data_solve(sgpr_model *h, const double *Y, int with_energies, double noise, double *mu_out,
                     double *choli_out, double *ridge_out, double *sigma_out);
+int sgpr_data_factor(sgpr_model *h, const double *Y, int with_energies);
 
 /*
  * Inducing-set edits (PosteriorPotential.add_inducing / pop_1inducing / popfirst_1inducing /
