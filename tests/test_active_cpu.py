@@ -193,6 +193,41 @@ def test_acceptance_rules():
     assert abs(p.leakage(locs[0])) < 1e-6 and p.leakage(locs[13]) > 1e-4
 
 
+def test_rejected_trials_restore_what_a_refit_would_give():
+    """A rejected add_1inducing / add_1atoms_fast hands back the fitted state saved before the trial; the reference
+    refits instead (gppotential.py:898-982) — for exactly the same model.  Both must leave the same posterior."""
+    frames = _frames(3)
+    locs = _locals(frames[0], range(18))
+
+    class NoRestore:  # the same engine without the shortcut: PosteriorPotential falls back to pop + refit
+        def __init__(self, eng):
+            self._e = eng
+
+        def __getattr__(self, name):
+            if name in ("restore_weights", "snapshot_weights"):
+                raise AttributeError(name)
+            return getattr(self._e, name)
+
+    posts = []
+    for wrap in (lambda e: e, NoRestore):
+        p = PosteriorPotential(wrap(engine()))
+        p.set_data(frames[:2], locs[:6])
+        assert p.add_1inducing(locs[9], 1e3)[0] == 0          # rejected inducing trial
+        assert p.add_1atoms_fast(frames[2], 1e3, 1e3)[0] == 0  # rejected data trial
+        posts.append(p)
+    a, b = posts
+    assert len(a.X) == len(b.X) == 6 and a.ndata == b.ndata == 2
+    np.testing.assert_allclose(a.mu, b.mu, rtol=0, atol=1e-9 * np.abs(b.mu).max())
+    np.testing.assert_allclose(a.choli, b.choli, rtol=0, atol=1e-9 * np.abs(b.choli).max())
+    np.testing.assert_allclose(a._stats, b._stats, rtol=1e-8, atol=1e-12)
+    assert a.mean.weights.keys() == b.mean.weights.keys()
+    for z in a.mean.weights:
+        assert abs(a.mean.weights[z] - b.mean.weights[z]) < 1e-10
+    assert a.engine._vscale.keys() == b.engine._vscale.keys()
+    for z in a.engine._vscale:
+        assert abs(a.engine._vscale[z] - b.engine._vscale[z]) <= 1e-9 * abs(b.engine._vscale[z])
+
+
 def test_hpo_meets_noise_target():
     """make_munu(algo=3): after the noise search the force-fit MAE of the forces-only fit sits at
     noise_f (gppotential.py:1265-1300), and the mean offsets solve their least-squares problem."""
