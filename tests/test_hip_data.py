@@ -347,3 +347,88 @@ def test_batched_resolve_equals_resolve():
     for k, nz in enumerate(noises):
         np.testing.assert_array_equal(many[k], mdl.resolve(noise=nz))
     mdl.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_edit_sequences(seed):
+    """Randomised differential test of the resident training set and the kept factorisation: a random walk over the
+    edits the learning loop makes (append / pop / select inducing LCEs, push / pop frames, new targets, force-only
+    fits, re-solves), the fit checked after every step against a model that is set up and factored from scratch."""
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    pool = list(mdl.X)
+    frames_pool = systems()
+    rng = np.random.default_rng(100 + seed)
+    X = [pool[i] for i in rng.permutation(len(pool))[:5]]
+    mdl.set_inducing(X)
+    frames, targets = [], []
+
+    def push():
+        fr = frames_pool[int(rng.integers(len(frames_pool)))]
+        # a rattled copy: every stored frame different
+        fr = (fr[0], fr[1] + 0.03 * rng.normal(size=fr[1].shape), fr[2], fr[3])
+        nv = int(rng.choice([0, 6]))
+        mdl.data_push(*fr, nv)
+        frames.append((fr, nv))
+        targets.append(rng.normal(size=1 + 3 * len(fr[0]) + nv))
+
+    push(); push()
+    fresh_id = [0]
+
+    def new_lce():
+        base = pool[int(rng.integers(len(pool)))]
+        fresh_id[0] += 1
+        return base.__class__(base.number, base._b, base._r + 0.02 * rng.normal(size=base._r.shape))
+
+    def check(with_energies=True, noise=0.02):
+        Y = np.concatenate(targets)
+        got = mdl.data_solve(Y, noise=noise, with_energies=with_energies).copy()
+        ref = mdl.scratch()
+        ref.set_inducing(mdl.X)
+        K = np.concatenate([np.concatenate([ke[None], kf, kv[:nv]]) for (fr, nv) in frames
+                            for ke, kf, kv in [ref.kernel_rows(*fr)]])
+        np.testing.assert_array_equal(mdl.data_get(), K)
+        keep = np.ones(len(K), bool)
+        if not with_energies:
+            a = 0
+            for fr, nv in frames:
+                keep[a] = False
+                a += 1 + 3 * len(fr[0]) + nv
+        want = ref.solve(K[keep], Y[keep], noise=noise)
+        scale = max(np.abs(K @ want).max(), 1e-300)
+        assert np.abs(K @ got - K @ want).max() <= 1e-8 * scale
+        ref.close()
+
+    check()
+    for step in range(36):
+        op = rng.choice(["add", "add", "add", "pop", "pop", "popfirst", "select", "push", "popdata", "popfirstdata",
+                         "targets", "force_only", "resolve"])
+        if op == "add":
+            mdl.add_inducing(new_lce())
+        elif op == "pop" and mdl.m > 3:
+            mdl.remove_inducing(-1)
+        elif op == "popfirst" and mdl.m > 3:
+            mdl.remove_inducing(0)
+        elif op == "select" and mdl.m > 4:
+            idx = rng.permutation(mdl.m)[:mdl.m - 1].tolist()
+            mdl.select_inducing(idx)
+        elif op == "push" and len(frames) < 4:
+            push()
+        elif op == "popdata" and len(frames) > 1:
+            mdl.data_pop(-1); frames.pop(); targets.pop()
+        elif op == "popfirstdata" and len(frames) > 1:
+            mdl.data_pop(0); frames.pop(0); targets.pop(0)
+        elif op == "targets":
+            k = int(rng.integers(len(targets)))
+            targets[k] = targets[k] + 0.1 * rng.normal(size=len(targets[k]))
+        elif op == "force_only":
+            check(with_energies=False)
+        elif op == "resolve":
+            check()
+            Y = np.concatenate(targets)
+            many = mdl.resolve_many([0.01, 0.05])
+            np.testing.assert_array_equal(many[0], mdl.resolve(noise=0.01))
+            np.testing.assert_array_equal(many[1], mdl.resolve(noise=0.05))
+            continue
+        check()
+    mdl.close()
