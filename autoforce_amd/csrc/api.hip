@@ -171,9 +171,10 @@ struct sgpr_model {
         uint64_t ykey[2] = {0, 0};
         DevBuf<double> store, Rc, yt, yraw, ysnap, vec;
         size_t store_used = 0;
-        std::vector<TsqrPanel> panels;     // the panels of the full factorisation, then one per appended column
-        std::vector<int> app_k0;           // appended panels: their column,
-        std::vector<size_t> app_doubles;   //   their share of `store`,
+        std::vector<TsqrPanel> panels;     // the panels of the full factorisation
+        size_t store_base = 0;             // where the appended columns' reflectors start in `store`: slot a holds
+                                           // v [ldr], sc, alpha
+        std::vector<int> app_k0;           // appended columns: their column index (one flat reflector each),
         std::vector<char> app_snap;        //   whether ysnap holds Q^T Y from before them
         uint64_t age = 0;
     };

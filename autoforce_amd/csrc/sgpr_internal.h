@@ -202,7 +202,10 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /
 int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_mat, double *x, double *work, int batch,
                             hipStream_t st, int band);
 void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st);
-void tsqr_append_column(double *vec, int rows, int k0, double *keep, TsqrPanel *rec, double *work, hipStream_t st);
+// one-column Householder reflectors over n elements (appended columns of a kept factorisation)
+size_t flat_part_doubles(int n);
+void flat_reflector_make(const double *x, int n, double *v, double *sc, double *alpha, double *part, hipStream_t st);
+void flat_reflector_apply(const double *v, const double *sc, int n, double *a, double *part, hipStream_t st);
 void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rc, int ldc, double *z, hipStream_t st);
 
 void host_build_harm_coef(HarmCoef *hc);

@@ -683,13 +683,82 @@ void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStrea
     }
 }
 
-// A new LAST column of an already factored matrix: `vec` (over the physical rows, every kept panel already applied)
-// gets its own one-column panel over rows [k0, rows): on return vec[0 .. k0] is the new column of R (its diagonal
-// at k0), the panel's reflectors are in `keep` (tsqr_panel_doubles(rows - k0) doubles), `rec` describes it.
-void tsqr_append_column(double *vec, int rows, int k0, double *keep, TsqrPanel *rec, double *work, hipStream_t st)
+// ---------------------------------------------------------------- one-column reflectors (appended columns)
+// A column appended to a kept factorisation gets a single Householder reflector over all remaining rows,
+// H = I - sc v v^T — no tree: the norm and the products with it are two-stage sums in a fixed order (per-chunk
+// partials, then every workgroup adds the partials itself), two launches per application.
+#define FCH 2048  // elements per workgroup
+
+__device__ __forceinline__ double block_sum256(double s, double *red)
 {
-    tsqr_attrs();
-    tsqr_panel(vec, 0, k0, 1, rows, nullptr, 0, work, keep, rec, st);
+    s = wave_sum64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(256) void flat_dot_kernel(int n, const double *x, const double *y, double *part)
+{
+    __shared__ double red[4];
+    const int i0 = blockIdx.x * FCH, i1 = min(n, i0 + FCH);
+    double s = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) s += x[i] * y[i];
+    s = block_sum256(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__device__ __forceinline__ double sum_parts(const double *part, int np, double *red)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+    return block_sum256(s, red);
+}
+
+// a <- a - sc (v . a) v, the dot product given as partials
+__global__ __launch_bounds__(256) void flat_apply_kernel(int n, int np, const double *part, const double *sc, const double *v,
+                                                         double *a)
+{
+    __shared__ double red[4];
+    const double f = sc[0] * sum_parts(part, np, red);
+    const int i0 = blockIdx.x * FCH, i1 = min(n, i0 + FCH);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) a[i] -= f * v[i];
+}
+
+// v = x - alpha e_0, sc = 2 / v.v, alpha = -sign(x_0) |x| (|x|^2 given as partials); x is left as it is
+__global__ __launch_bounds__(256) void flat_make_kernel(int n, int np, const double *part, const double *x, double *v,
+                                                        double *sc, double *alpha_out)
+{
+    __shared__ double red[4];
+    const double s2 = sum_parts(part, np, red);
+    const double akk = x[0];
+    const double nrm = sqrt(s2);
+    const double alpha = akk > 0.0 ? -nrm : nrm;
+    const double v0 = akk - alpha;
+    const double vv = s2 - akk * akk + v0 * v0;
+    const int i0 = blockIdx.x * FCH, i1 = min(n, i0 + FCH);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) v[i] = i == 0 ? v0 : x[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[0] = vv > 0.0 ? 2.0 / vv : 0.0;
+        alpha_out[0] = alpha;
+    }
+}
+
+size_t flat_part_doubles(int n) { return (size_t)(n + FCH - 1) / FCH + 8; }
+
+void flat_reflector_make(const double *x, int n, double *v, double *sc, double *alpha, double *part, hipStream_t st)
+{
+    const int np = (n + FCH - 1) / FCH;
+    hipLaunchKernelGGL(flat_dot_kernel, dim3(np), dim3(256), 0, st, n, x, x, part);
+    hipLaunchKernelGGL(flat_make_kernel, dim3(np), dim3(256), 0, st, n, np, part, x, v, sc, alpha);
+}
+
+void flat_reflector_apply(const double *v, const double *sc, int n, double *a, double *part, hipStream_t st)
+{
+    const int np = (n + FCH - 1) / FCH;
+    hipLaunchKernelGGL(flat_dot_kernel, dim3(np), dim3(256), 0, st, n, v, a, part);
+    hipLaunchKernelGGL(flat_apply_kernel, dim3(np), dim3(256), 0, st, n, np, part, sc, v, a);
 }
 
 void launch_qr_gather_r(int cols, const double *At, int ldr, double *Rc, int ldc, double *z, hipStream_t st)
