@@ -145,7 +145,7 @@ struct sgpr_model {
     DevBuf<double> sc_s2A, sc_s2x, sc_s2work, sc_mv_v, sc_mv_o, sc_ra_y, sc_ra_t, sc_vs_t, sc_ai_er, sc_ai_p, sc_ai_norm,
         sc_ai_krow, sc_ai_kself, sc_y, sc_bA, sc_bx, sc_bwork;
     DevBuf<int> sc_s2so, sc_ai_eslot, sc_ai_oslot, sc_ai_onn, sc_ai_info;
-    DevBuf<int64_t> sc_ai_ptr;
+    DevBuf<int64_t> sc_ai_ptr, sc_erow;
     DevBuf<unsigned char> sc_ise;
     int64_t design_rcap = 0, design_ccap = 0, design_rows = 0;
     bool design_hold = false;  // an edit entry point is re-indexing the columns itself
@@ -547,6 +547,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
         DevBuf<int> *si[] = {&h->sc_s2so, &h->sc_ai_eslot, &h->sc_ai_oslot, &h->sc_ai_onn, &h->sc_ai_info};
         for (auto b : si) b->release();
         h->sc_ai_ptr.release();
+        h->sc_erow.release();
         h->sc_ise.release();
     }
     for (auto &e : h->r1_cache) e.r1.release();
@@ -779,6 +780,19 @@ extern "C" int sgpr_get_kmm(sgpr_model *h, double *M)
     HIPCHK(hipMemcpy(buf.data(), h->d_M.p, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
     for (int a = 0; a < m; a++)
         for (int b = 0; b < m; b++) M[(size_t)h->ind_perm[a] * m + h->ind_perm[b]] = buf[(size_t)a * h->m_pad + b];
+    return SGPR_OK;
+}
+
+// diag(K_mm) alone, caller order (make_stats' kern_diag_mean, gppotential.py:644-649: no need for the m x m matrix)
+extern "C" int sgpr_get_kmm_diag(sgpr_model *h, double *diag)
+{
+    if (!h || !diag) return fail(SGPR_E_INVALID, "sgpr_get_kmm_diag: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int m = h->m;
+    if (m <= 0) return SGPR_OK;
+    std::vector<double> d(m);
+    HIPCHK(hipMemcpy2D(d.data(), sizeof(double), h->d_M.p, sizeof(double) * (h->m_pad + 1), sizeof(double), m, hipMemcpyDeviceToHost));
+    for (int a = 0; a < m; a++) diag[h->ind_perm[a]] = d[a];
     return SGPR_OK;
 }
 

@@ -199,6 +199,12 @@ class SGPRModel:
         return out
 
     @property
+    def M_diag(self):
+        out = np.zeros(self.m)
+        check(_lib.load().sgpr_get_kmm_diag(self._h, ptr(out)))
+        return out
+
+    @property
     def dims(self):
         out = np.zeros(8, np.int32)
         check(_lib.load().sgpr_get_dims(self._h, ptr(out)))
@@ -346,6 +352,18 @@ class SGPRModel:
         out = np.zeros(self.data_info()[1])
         check(_lib.load().sgpr_data_matvec(self._h, ptr(v), ptr(out)))
         return out
+
+    def data_fit_stats(self, v, Y):
+        """(e_pred[frames], stats[7]) of K v against the targets Y, reduced on the device: the energy rows of K v and
+        {sum d, sum |d|, sum d^2, sum y, sum y^2, max |y|, count} of d = K v - Y over the force / virial rows."""
+        v = f64(v).reshape(self.m)
+        Y = f64(Y).reshape(-1)
+        n, rows = self.data_info()
+        if len(Y) != rows:
+            raise ValueError(f"data_fit_stats: {len(Y)} targets for {rows} stored rows")
+        e, st = np.zeros(n), np.zeros(8)
+        check(_lib.load().sgpr_data_fit_stats(self._h, ptr(v), ptr(Y), ptr(e), ptr(st)))
+        return e, st[:7]
 
     def data_get(self):
         """The resident design matrix [rows, m] (diagnostics / tests)."""

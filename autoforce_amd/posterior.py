@@ -368,16 +368,21 @@ class PosteriorPotential:
         return ch1, ch2
 
     # ------------------------------------------------------------------ regression
+    def _store_targets(self):
+        """The targets in the row order of the engine's resident matrix (per frame: E - mean, forces, stress * V)."""
+        return np.concatenate([np.concatenate([[fr.energy - self.mean(fr.counts())], fr.forces.reshape(-1)] +
+                                              ([fr.stress * fr.get_volume()] if fr.stress is not None else []))
+                               for fr in self.data])
+
     def _solve(self, with_energies, x=None, factor_only=False):
         """One make_mu of _regression (gppotential.py:1245-1263) on the device.  factor_only: the first stage alone
         (what the noise search re-solves from), where the engine offers it."""
         noise = _sigmoid(self._noise["all"] if x is None else x)
         if self.resident:
-            Y = [np.concatenate([[fr.energy - self.mean(fr.counts())], fr.forces.reshape(-1)] +
-                                ([fr.stress * fr.get_volume()] if fr.stress is not None else [])) for fr in self.data]
+            Y = self._store_targets()
             if factor_only and hasattr(self.engine, "data_factor") and hasattr(self.engine, "resolve_many"):
-                return self.engine.data_factor(np.concatenate(Y), with_energies=with_energies)
-            return self.engine.data_solve(np.concatenate(Y), with_energies=with_energies, noise=noise)
+                return self.engine.data_factor(Y, with_energies=with_energies)
+            return self.engine.data_solve(Y, with_energies=with_energies, noise=noise)
         e, f, v = self.targets()
         if with_energies:
             K, Y = self.K, np.concatenate([e, f, v])
@@ -470,19 +475,34 @@ class PosteriorPotential:
     def make_stats(self):
         """gppotential.py:610-649."""
         n = len(self.data)
-        e, f, v = self.targets()
-        y = np.concatenate([e, f, v])
-        yy = np.concatenate(self._matvec(self.engine.mu))
-        diff = yy - y
         nat = np.array([fr.natoms for fr in self.data], float)
-        self._ediff = diff[:n] / nat
-        self._fdiff = diff[n:]
-        self._force_r2 = _r2(yy[n:], y[n:])
-        self._stats = [self._ediff.mean(), np.abs(self._ediff).mean(), self._fdiff.mean(), np.abs(self._fdiff).mean(),
-                       self._force_r2]
-        self._f_max = np.abs(y[n:]).max()
+        if self.resident and hasattr(self.engine, "data_fit_stats"):
+            # reduced on the device: one number per frame and seven sums come back, not 10^5..10^6 residuals
+            e_pred, (sd, sad, sd2, sy, sy2, ymax, cnt) = self.engine.data_fit_stats(self.engine.mu, self._store_targets())
+            e_t = np.array([fr.energy - self.mean(fr.counts()) for fr in self.data])
+            self._ediff = (e_pred - e_t) / nat
+            self._fdiff = None
+            if cnt >= 2:
+                var_d, var_y = (sd2 - sd * sd / cnt) / (cnt - 1), (sy2 - sy * sy / cnt) / (cnt - 1)
+                self._force_r2 = float(1.0 - var_d / var_y)
+            else:
+                self._force_r2 = float("nan")
+            self._stats = [self._ediff.mean(), np.abs(self._ediff).mean(), sd / max(cnt, 1.0), sad / max(cnt, 1.0),
+                           self._force_r2]
+            self._f_max = float(ymax)
+        else:
+            e, f, v = self.targets()
+            y = np.concatenate([e, f, v])
+            yy = np.concatenate(self._matvec(self.engine.mu))
+            diff = yy - y
+            self._ediff = diff[:n] / nat
+            self._fdiff = diff[n:]
+            self._force_r2 = _r2(yy[n:], y[n:])
+            self._stats = [self._ediff.mean(), np.abs(self._ediff).mean(), self._fdiff.mean(), np.abs(self._fdiff).mean(),
+                           self._force_r2]
+            self._f_max = np.abs(y[n:]).max()
         self.indu_counts = Counter(x.number for x in self.X)
-        diag = np.diag(self.M)
+        diag = self.engine.M_diag if hasattr(self.engine, "M_diag") else np.diag(self.M)
         self.kern_diag_mean = Counter()
         for x, d in zip(self.X, diag):
             self.kern_diag_mean[x.number] += float(d) / self.indu_counts[x.number]

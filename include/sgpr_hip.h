@@ -81,6 +81,8 @@ int sgpr_get_kmm(sgpr_model *h, double *M);
  * D=(nmax+1)^2(lmax+1), block [sb][sa] flattened [n][n'][l] (descriptor/sesoap.py:195-203,
  * :254-258 COO block (species[b], species[a])). Test/inspection export. */
 int sgpr_get_inducing_descriptors(sgpr_model *h, double *P);
+/* diag(K_mm)[m], caller order. */
+int sgpr_get_kmm_diag(sgpr_model *h, double *diag);
 
 /*
  * Set the regression state used by prediction.
@@ -164,6 +166,9 @@ int sgpr_kernel_columns(sgpr_model *h, int N, const int32_t *numbers, const doub
  *   sgpr_data_clear   drop all frames
  *   sgpr_data_info    number of frames / rows
  *   sgpr_data_matvec  out[rows] = K v   (v[m] in the caller's column order): fit residuals, k·mu of a stored frame
+ *   sgpr_data_fit_stats  make_stats (gppotential.py:610-649) without the residual vector: e_pred[frames] = the
+ *                     energy rows of K v, stats[7] = {sum d, sum |d|, sum d^2, sum y, sum y^2, max |y|, count} of
+ *                     d = K v - Y over the force and virial rows
  *   sgpr_data_get     K[rows][m] row-major (diagnostics and tests; the product path never needs it)
  *   sgpr_data_solve   sgpr_solve on the resident matrix: Y[rows] in the same row order; with_energies = 0 drops
  *                     the energy rows (the force-only fit of _regression(optimize=True), gppotential.py:1265-1300);
@@ -177,6 +182,7 @@ int sgpr_data_pop(sgpr_model *h, int index);
 int sgpr_data_clear(sgpr_model *h);
 int sgpr_data_info(sgpr_model *h, int32_t *frames, int64_t *rows);
 int sgpr_data_matvec(sgpr_model *h, const double *v, double *out);
+int sgpr_data_fit_stats(sgpr_model *h, const double *v, const double *Y, double *e_pred, double *stats);
 int sgpr_data_get(sgpr_model *h, double *K);
 int sgpr_data_solve(sgpr_model *h, const double *Y, int with_energies, double noise, double *mu_out,
                     double *choli_out, double *ridge_out, double *sigma_out);

@@ -432,3 +432,29 @@ def test_random_edit_sequences(seed):
             continue
         check()
     mdl.close()
+
+
+def test_fit_statistics_on_the_device():
+    """sgpr_data_fit_stats against numpy over the downloaded matrix (make_stats, gppotential.py:610-649)."""
+    mdl = model_from_fixture(load("g5_mixed64"))
+    frames = systems()
+    nvs = [6, 0, 6]
+    for fr, nv in zip(frames, nvs):
+        mdl.data_push(*fr, nv)
+    rng = np.random.default_rng(12)
+    K = mdl.data_get()
+    Y = rng.normal(size=len(K))
+    v = rng.normal(size=mdl.m)
+    e_pred, st = mdl.data_fit_stats(v, Y)
+    pred = K @ v
+    is_e = np.zeros(len(K), bool)
+    a = 0
+    for fr, nv in zip(frames, nvs):
+        is_e[a] = True
+        a += 1 + 3 * len(fr[0]) + nv
+    np.testing.assert_allclose(e_pred, pred[is_e], rtol=0, atol=1e-12 * np.abs(pred).max())
+    d, y = (pred - Y)[~is_e], Y[~is_e]
+    want = [d.sum(), np.abs(d).sum(), (d * d).sum(), y.sum(), (y * y).sum(), np.abs(y).max(), len(d)]
+    np.testing.assert_allclose(st, want, rtol=1e-12, atol=1e-10)
+    np.testing.assert_array_equal(mdl.M_diag, np.diag(mdl.M))
+    mdl.close()
