@@ -193,9 +193,11 @@ struct sgpr_model {
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
+    DevBuf<long long> d_stamps2; // the same for the grouped W + covloss launch
     DevBuf<long long> d_pstamps; // SGPR_STAMPS=1 + a -DSGPR_PHASE_STAMPS build: [2][N][8] phase stamps (forward | reverse)
     DevBuf<int4> t_knm, t_w, t_cov, t_kmm, t_wcov;  // working-tile tables of the GEMMs
     int gemm_bm_k = 64, gemm_bm_w = 64;  // rows per tile of t_knm  /  t_w, t_cov, t_wcov
+    int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
     std::vector<int4> h_t_w, h_t_cov;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -472,7 +474,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_cell_in.alloc(9);
     h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds
     h->d_cell0.alloc(9);
-    if (getenv("SGPR_STAMPS")) h->d_stamps.alloc(4 * 4096);
+    if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
     return SGPR_OK;
@@ -490,17 +492,30 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     if (h->d_stamps.p && h->t_knm.n) {
-        std::vector<long long> st(4 * h->t_knm.n);
+        std::vector<long long> st(8 * h->t_knm.n);
         (void)hipMemcpy(st.data(), h->d_stamps.p, sizeof(long long) * st.size(), hipMemcpyDeviceToHost);
         double pro = 0, loop = 0, epi = 0; int n = 0; long long t0 = 1LL << 62, t1 = 0;
         for (size_t b = 0; b < h->t_knm.n; b++) {
-            if (st[4 * b + 3] <= 0) continue;
-            loop += st[4 * b + 1] - st[4 * b]; epi += st[4 * b + 2] - st[4 * b + 1]; n++;
-            t0 = std::min(t0, st[4 * b]); t1 = std::max(t1, st[4 * b + 2]);
+            if (st[8 * b + 3] <= 0) continue;
+            loop += st[8 * b + 1] - st[8 * b]; epi += st[8 * b + 2] - st[8 * b + 1]; n++;
+            t0 = std::min(t0, st[8 * b]); t1 = std::max(t1, st[8 * b + 2]);
         }
         fprintf(stderr, "[sgpr stamps] K_nm gemm: %d tiles, start->loop end %.0f cyc, epilogue %.0f cyc, first start->last end %lld cyc\n",
                 n, loop / std::max(n, 1), epi / std::max(n, 1), t1 - t0);
         (void)pro;
+        if (const char *path = getenv("SGPR_STAMPS_FILE")) {  // every record, for tools/stamps_wcov.py
+            if (FILE *f = fopen(path, "w")) {
+                for (size_t b = 0; b < h->t_knm.n; b++)
+                    fprintf(f, "knm %zu %lld %lld %lld %lld %lld %lld\n", b, st[8 * b], st[8 * b + 1], st[8 * b + 2], st[8 * b + 3], st[8 * b + 4], st[8 * b + 5]);
+                std::vector<long long> s2(8 * std::min<size_t>(h->t_wcov.n, 8192));
+                if (h->d_stamps2.p && !s2.empty()) {
+                    (void)hipMemcpy(s2.data(), h->d_stamps2.p, sizeof(long long) * s2.size(), hipMemcpyDeviceToHost);
+                    for (size_t b = 0; b < s2.size() / 8; b++)
+                        fprintf(f, "wcov %zu %lld %lld %lld %lld %lld %lld\n", b, s2[8 * b], s2[8 * b + 1], s2[8 * b + 2], s2[8 * b + 3], s2[8 * b + 4], s2[8 * b + 5]);
+                }
+                fclose(f);
+            }
+        }
     }
     if (h->d_pstamps.p && h->N > 0) {
         const int N = h->N;
@@ -582,7 +597,15 @@ static int build_tiles(sgpr_model *h, int kind)
     // 32-row tiles when 64-row tiles would leave most of the 256 CUs without work (small shares)
     // measured at 4096 rows: K_nm 24.8 -> 22.3 us with 32-row tiles, the grouped W+covloss launch
     // 28.7 -> 31.2 us (it already has 582 tiles); small shares (ranks of a sharded frame) gain on both
-    const int bm = kind == 3 ? 64 : kind == 0 ? (h->cnt > 8192 ? 64 : 32) : (h->cnt > 2048 ? 64 : 32);
+    int bm = kind == 3 ? 64 : (h->cnt > 8192 ? 64 : 32);
+    if (const char *e = getenv("SGPR_GEMM_BM")) {  // experiment: "k,w" tile heights
+        int bk = 0, bw = 0;
+        if (sscanf(e, "%d,%d", &bk, &bw) == 2 && kind != 3) bm = kind == 0 ? bk : bw;
+    }
+    if (const char *e = getenv("SGPR_GEMM_KD")) {
+        int kk = 0, kw = 0;
+        if (sscanf(e, "%d,%d", &kk, &kw) == 2) { h->gemm_kd_k = kk == 16 ? 16 : 32; h->gemm_kd_w = kw == 16 ? 16 : 32; }
+    }
     if (kind == 0) h->gemm_bm_k = bm;
     if (kind == 1 || kind == 2) h->gemm_bm_w = bm;
     const int nrt = (nrows + bm - 1) / bm, nct = (ncols + 63) / 64;
@@ -661,6 +684,7 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
     g.A = A; g.B = h->d_Pm.p; g.C = Kout;
     g.tiles = tiles.p; g.ntiles = (int)tiles.n;
     g.bm = (&tiles == &h->t_kmm) ? 64 : h->gemm_bm_k;
+    g.kd = h->gemm_kd_k;
     g.eta = h->eta; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
     g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
@@ -1162,12 +1186,13 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     gw.M = cnt; gw.N = h->Dpad; gw.K = h->m_pad;
     gw.lda = h->m_pad; gw.ldb = h->m_pad; gw.ldc = h->Dpad;
     gw.A = h->d_Aw.p; gw.B = h->d_PmT.p; gw.C = h->d_W.p;
-    gw.tiles = h->t_w.p; gw.ntiles = (int)h->t_w.n; gw.bm = h->gemm_bm_w;
+    gw.tiles = h->t_w.p; gw.ntiles = (int)h->t_w.n; gw.bm = h->gemm_bm_w; gw.kd = h->gemm_kd_w;
     gc.M = cnt; gc.N = h->m; gc.K = h->m_pad;
     gc.lda = h->m_pad; gc.ldb = h->m_pad; gc.ldc = 0;
     gc.A = h->d_K.p; gc.B = h->d_choli.p; gc.C = nullptr;
-    gc.tiles = h->t_cov.p; gc.ntiles = (int)h->t_cov.n; gc.bm = h->gemm_bm_w;
+    gc.tiles = h->t_cov.p; gc.ntiles = (int)h->t_cov.n; gc.bm = h->gemm_bm_w; gc.kd = h->gemm_kd_w;
     gc.rowsq = h->d_csq.p; gc.rowsq_ld = h->csq_slots;
+    gw.stamps = (h->d_stamps2.p && h->t_wcov.n <= 8192) ? h->d_stamps2.p : nullptr;
     // "overlap" option: the covloss product (MFMA-bound) runs on a side stream next to the reverse pass
     // (VALU/latency-bound) instead of being grouped with the W product
     bool forked = false;

@@ -161,6 +161,7 @@ struct GemmParams {
     const int4 *tiles;
     int ntiles;
     int bm;               // rows per tile of the table: 64 (default when 0) or 32
+    int kd;               // 32-row tiles: depth of an LDS stage, 32 (default when 0) or 16 (four workgroups per CU)
     int tri;              // unused by the kernel (the tile table carries the trimmed k range)
     // EPI_KERNEL extras
     double eta;
