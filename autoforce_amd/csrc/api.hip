@@ -325,6 +325,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
 // gather form: one wave per atom i,  F_i = (sum_t g_it, kept by the reverse kernel) - sum_t' G[i][t']
 // where G[i][t'] is the gradient of the pair (j_t' -> i), stored at i's own list position by the
 // reverse kernel: one coalesced row per wave, fixed shuffle tree: reproducible.
+// wave64 sum on the DPP network (quads, half rows, rows) and four scalar row sums: the result is wave-uniform and
+// costs no LDS round trip (six ds_bpermute rounds per sum were a third of this kernel's dependent chain)
+template <int CTRL>
+__device__ __forceinline__ double fin_dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fin_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double fin_wave_sum(double v)
+{
+    v += fin_dpp<0xB1>(v);
+    v += fin_dpp<0x4E>(v);
+    v += fin_dpp<0x141>(v);
+    v += fin_dpp<0x140>(v);
+    return (fin_lane(v, 0) + fin_lane(v, 16)) + (fin_lane(v, 32) + fin_lane(v, 48));
+}
+
 __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
 {
     const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
@@ -333,8 +355,16 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = b * 4 + wave;
     if (i >= f.N) return;
-    const int n = f.nn[i];
     const size_t by = blockIdx.y;
+    // the first 64 pair gradients of the row are requested before the neighbour count is known (the row has maxnn
+    // slots; what lies beyond the count is masked after the load): one cold miss less on the chain
+    const bool spec = lane < f.maxnn;
+    double2 g0 = make_double2(0.0, 0.0), g1 = make_double2(0.0, 0.0);
+    if (spec) {
+        const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + lane) * 4);
+        g0 = row[0]; g1 = row[1];
+    }
+    const int n = f.nn[i];
     double fs = lane < 3 ? f.Fself[by * f.f_stride + 3 * (size_t)i + lane] : 0.0;
     double *packed = f.packed + by * f.p_stride;
     const int c = f.perm[i];
@@ -342,9 +372,7 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     if (f.has_beta) {  // |choli k_i|^2: the tile partials, summed by a fixed tree
         double x = 0.0;
         for (int k = lane; k < f.csq_slots; k += 64) x += f.csq[(size_t)i * f.csq_slots + k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        cs = x;
+        cs = fin_wave_sum(x);
     }
     const double vs = f.has_beta ? f.vs_sqrt[f.slot[i]] : 0.0;
     double fx = 0.0, fy = 0.0, fz = 0.0;
@@ -352,17 +380,15 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     for (int t0 = 0; t0 < n; t0 += 64) {
         const int t = t0 + lane;
         if (t < n && (want < 0 || ((f.nbr_code[(size_t)i * f.maxnn + t] >> 24) & 0xff) == want)) {
-            const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + t) * 4);
-            const double2 b0 = row[0], b1 = row[1];
+            double2 b0 = g0, b1 = g1;
+            if (t0 > 0) {
+                const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + t) * 4);
+                b0 = row[0]; b1 = row[1];
+            }
             fx += b0.x; fy += b0.y; fz += b1.x;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        fx += __shfl_xor(fx, o, 64);
-        fy += __shfl_xor(fy, o, 64);
-        fz += __shfl_xor(fz, o, 64);
-    }
+    fx = fin_wave_sum(fx); fy = fin_wave_sum(fy); fz = fin_wave_sum(fz);
     if (lane < 3) packed[3 * (size_t)c + lane] = fs - (lane == 0 ? fx : lane == 1 ? fy : fz);
     if (lane < 3 && *f.flag) f.pos0[3 * (size_t)i + lane] = f.pos[3 * (size_t)i + lane];
     if (lane == 3) {
@@ -594,10 +620,10 @@ static int build_tiles(sgpr_model *h, int kind)
     const std::vector<int> &roff = kind == 3 ? h->qoff : h->aoff;
     const int nrows = kind == 3 ? h->m : h->cnt;
     const int ncols = kind == 1 ? h->Dpad : h->m;
-    // 32-row tiles when 64-row tiles would leave most of the 256 CUs without work (small shares)
-    // measured at 4096 rows: K_nm 24.8 -> 22.3 us with 32-row tiles, the grouped W+covloss launch
-    // 28.7 -> 31.2 us (it already has 582 tiles); small shares (ranks of a sharded frame) gain on both
-    int bm = kind == 3 ? 64 : (h->cnt > 8192 ? 64 : 32);
+    // 32-row tiles with 16-deep stages (four workgroups per CU) for the three products of a step at every size
+    // measured (4096 / 512: K_nm 22.2 -> 18-20 us, W + covloss 24.9 -> 22.6 us; 32768 / 1024: 198 -> 184 and
+    // 313 -> 287 us against the 64-row tiles); K_mm keeps the 64-row form
+    int bm = kind == 3 ? 64 : 32;
     if (const char *e = getenv("SGPR_GEMM_BM")) {  // experiment: "k,w" tile heights
         int bk = 0, bw = 0;
         if (sscanf(e, "%d,%d", &bk, &bw) == 2 && kind != 3) bm = kind == 0 ? bk : bw;

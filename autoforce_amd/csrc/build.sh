@@ -9,8 +9,8 @@ mkdir -p build
 pids=()
 for f in api descriptor neighbor gemm linalg tsqr; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ sgpr_internal.h -nt build/$f.o ] || [ ../../include/sgpr_hip.h -nt build/$f.o ] || [ solve.inc -nt build/$f.o ] || [ data.inc -nt build/$f.o ]; then
-    # gemm: MFMA accumulators stay in VGPRs (the AGPR form copies them in and out around every trip of the stage loop)
-    X=""; [ $f = gemm ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"
+    # gemm, tsqr: MFMA accumulators stay in VGPRs (the AGPR form copies them in and out around every trip of a loop)
+    X=""; [ $f = gemm -o $f = tsqr ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"
     $HIPCC $FLAGS $X ${EXTRA_FLAGS} -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

@@ -155,12 +155,13 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     // this atom's position is requested before the barrier: the gather (perm -> pos_in) and the grid
     // set-up by thread 0 are independent latency chains
     const int i = gid;
-    double x = 0.0, y = 0.0, z = 0.0;
+    double x = 0.0, y = 0.0, z = 0.0, x0 = 0.0, y0 = 0.0, z0 = 0.0;
     int slot_i = 0;
     if (i < a.N) {
         const int c = a.perm ? a.perm[i] : i;
         x = a.pos_in[3 * c]; y = a.pos_in[3 * c + 1]; z = a.pos_in[3 * c + 2];
         slot_i = a.slot[i];
+        x0 = a.pos0[3 * i]; y0 = a.pos0[3 * i + 1]; z0 = a.pos0[3 * i + 2];  // cold miss, off the chain behind the barrier
     }
     for (int k = gid; k < a.n_zero_a; k += gsz) a.zero_a[k] = 0.0;
     for (int k = gid; k < a.n_zero_b; k += gsz) a.zero_b[k] = 0.0;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     if (i >= a.N) return;
     a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
     {   // rebuild decision, part 2: has this atom moved more than half the skin since the candidates were built?
-        const double dx = x - a.pos0[3 * i], dy = y - a.pos0[3 * i + 1], dz = z - a.pos0[3 * i + 2];
+        const double dx = x - x0, dy = y - y0, dz = z - z0;
         if (!(dx * dx + dy * dy + dz * dz <= a.half_skin2)) atomicMax(&a.flag[a.parity], 1);
     }
     int bidx[3], w[3];
