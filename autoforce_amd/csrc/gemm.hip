@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256, KD == 16 ? 4 : 2) void gemm_nt_kernel(GemmArgs
                         const bool same = e_rs[tm][r] == e_cs[tn];
                         const bool rl = e_rn[tm][r] == 0, cl = e_cn[tn] == 0;
                         double pm1;
-                        if (g.ieta >= 1) {
+                        if (g.ieta == 4)  // the reference's default exponent: no loop
+                            pm1 = v * v * v;
+                        else if (g.ieta >= 1) {
                             pm1 = 1.0;
                             for (int q = 1; q < g.ieta; q++) pm1 *= v;
                         } else
@@ -384,8 +386,18 @@ __global__ __launch_bounds__(256, KD == 16 ? 4 : 2) void gemm_nt_kernel(GemmArgs
     }
     if (EPI == EPI_KERNEL && g.Epart) {
         // one energy partial per WAVE (no workgroup barrier: the waves retire independently)
+        esum += row_dpp<0xB1>(esum);
+        esum += row_dpp<0x4E>(esum);
+        esum += row_dpp<0x141>(esum);
+        esum += row_dpp<0x140>(esum);  // every lane holds the sum of its row of 16; the four row sums through SGPRs
+        {
+            const int lo = __double2loint(esum), hi = __double2hiint(esum);
+            double r4[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) esum += __shfl_xor(esum, o, 64);
+            for (int q = 0; q < 4; q++)
+                r4[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
+            esum = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+        }
         if (lane == 0) g.Epart[(size_t)(g.p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct) * 4 + wave] = esum;
     }
     if (g.stamps && threadIdx.x == 0) {
