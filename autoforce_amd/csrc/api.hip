@@ -258,6 +258,28 @@ struct FinArgs {
     double *pos0;               // [N][3] positions the candidate lists were built at
 };
 
+// wave64 sum on the DPP network (quads, half rows, rows) and four scalar row sums: the result is wave-uniform and
+// costs no LDS round trip (six ds_bpermute rounds per sum were a third of this kernel's dependent chain)
+template <int CTRL>
+__device__ __forceinline__ double fin_dpp(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fin_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double fin_wave_sum(double v)
+{
+    v += fin_dpp<0xB1>(v);
+    v += fin_dpp<0x4E>(v);
+    v += fin_dpp<0x141>(v);
+    v += fin_dpp<0x140>(v);
+    return (fin_lane(v, 0) + fin_lane(v, 16)) + (fin_lane(v, 32) + fin_lane(v, 48));
+}
+
 // reducer workgroup q: E (0), the nine virial components (1..9), the largest neighbour count (10)
 __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
 {
@@ -266,17 +288,42 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
     const size_t by = blockIdx.y;
     double s = 0.0;
     if (q == 10) {
-        int mx = 0;
-        for (int k = tid; k < f.cnt; k += 256) mx = max(mx, f.nn_raw[k]);
+        // eight loads in flight per thread: one workgroup with one load per thread and trip moves 2 KB per memory
+        // round trip (32768 atoms: 60 us of reducers behind a 15 us gather)
+        int m8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int4 *src4 = (const int4 *)f.nn_raw;  // the array is padded to whole rows of 64: 16-B loads stay inside it
+        const int n4 = (f.cnt + 3) / 4;
+        for (int k0 = tid; k0 < n4; k0 += 2048) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 256 * u;
+                const int4 v = src4[min(k, n4 - 1)];
+                const int e = 4 * k;
+                int m = e < f.cnt ? v.x : 0;
+                m = max(m, e + 1 < f.cnt ? v.y : 0);
+                m = max(m, e + 2 < f.cnt ? v.z : 0);
+                m = max(m, e + 3 < f.cnt ? v.w : 0);
+                m8[u] = max(m8[u], m);
+            }
+        }
+        const int mx = max(max(max(m8[0], m8[1]), max(m8[2], m8[3])), max(max(m8[4], m8[5]), max(m8[6], m8[7])));
         s = (double)mx;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
     } else {
         const double *src = q == 0 ? f.Epart : f.virpart + by * f.v_stride + (size_t)(q - 1) * f.nV;
         const int n = q == 0 ? f.nE : f.nV;
-        for (int k = tid; k < n; k += 256) s += src[k];
+        double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // fixed assignment of terms to partial sums: same bits every run
+        for (int k0 = tid; k0 < n; k0 += 2048) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 256 * u;
+                const double v = src[min(k, n - 1)];
+                a8[u] += k < n ? v : 0.0;
+            }
+        }
+        s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        s = fin_wave_sum(s);
     }
     if (lane == 0) wsum[wave] = s;
     __syncthreads();
@@ -325,28 +372,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
 // gather form: one wave per atom i,  F_i = (sum_t g_it, kept by the reverse kernel) - sum_t' G[i][t']
 // where G[i][t'] is the gradient of the pair (j_t' -> i), stored at i's own list position by the
 // reverse kernel: one coalesced row per wave, fixed shuffle tree: reproducible.
-// wave64 sum on the DPP network (quads, half rows, rows) and four scalar row sums: the result is wave-uniform and
-// costs no LDS round trip (six ds_bpermute rounds per sum were a third of this kernel's dependent chain)
-template <int CTRL>
-__device__ __forceinline__ double fin_dpp(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double fin_lane(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-__device__ __forceinline__ double fin_wave_sum(double v)
-{
-    v += fin_dpp<0xB1>(v);
-    v += fin_dpp<0x4E>(v);
-    v += fin_dpp<0x141>(v);
-    v += fin_dpp<0x140>(v);
-    return (fin_lane(v, 0) + fin_lane(v, 16)) + (fin_lane(v, 32) + fin_lane(v, 48));
-}
-
 __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
 {
     const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
