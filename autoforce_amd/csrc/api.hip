@@ -100,6 +100,7 @@ struct sgpr_model {
     // neighbour list
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
+    bool spin_wait = true;   // sgpr_compute's warm path polls the stream instead of a blocking wait (option "spin_wait"; -16 us per call)
     DevBuf<char> d_grid;
     DevBuf<int> d_bin_of, d_bin_count, d_nn, d_nbr_j, d_nbr_shift, d_stat;
     int bin_cap = 0;  // slots per bin of the binned copies
@@ -525,6 +526,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_cell_in.alloc(9);
     h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds
     h->d_cell0.alloc(9);
+    if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
     if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
@@ -1099,7 +1101,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_aoff.alloc(h->S + 1, false);
     bad |= h->d_lslot.alloc(h->cnt_rows, false);
     bad |= h->d_lnn.alloc(h->cnt_rows, false);
-    bad |= h->d_pos_in.alloc((size_t)3 * std::max(N, 1));
+    bad |= h->d_pos_in.alloc((size_t)3 * std::max(N, 1) + 16);  // + the cell behind the positions (warm path: one copy)
     bad |= h->d_pos.alloc((size_t)3 * std::max(N, 1));
     bad |= h->d_bin_of.alloc(std::max(N, 1));
     bad |= h->d_kslot.alloc(std::max(N, 1));
@@ -1455,13 +1457,18 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         double *pi = h->pin, *po = h->pin + n_in;
         memcpy(pi, positions, sizeof(double) * 3 * N);
         memcpy(pi + 3 * (size_t)N, cell, sizeof(double) * 9);
-        HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->d_cell_in.p, pi + 3 * (size_t)N, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
-        int rf = enqueue_step(h, h->d_pos_in.p, h->d_cell_in.p, h->d_packed.p, h->stream);
+        // positions and cell travel as ONE copy (a second 72-byte copy is a whole DMA command of its own)
+        HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
+        int rf = enqueue_step(h, h->d_pos_in.p, h->d_pos_in.p + 3 * (size_t)N, h->d_packed.p, h->stream);
         if (!rf) rf = reduce_packed(h, h->d_packed.p, h->stream);
         if (rf) return rf;
         HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->spin_wait) {  // option "spin_wait": poll the stream instead of a blocking wait
+            hipError_t q;
+            while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
+            HIPCHK(q);
+        } else
+            HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
         if (po[4 * (size_t)N + 10] == 0.0) {
             if (forces) memcpy(forces, po, sizeof(double) * 3 * N);
@@ -1580,6 +1587,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
     if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
+    if (!strcmp(name, "spin_wait")) { h->spin_wait = value != 0; return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
     if (!strcmp(name, "qr_keep")) {
         if (value < 0 || value > 2) return fail(SGPR_E_INVALID, "sgpr_set_option: qr_keep is 0, 1 or 2");

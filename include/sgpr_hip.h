@@ -287,7 +287,10 @@ int sgpr_sync_check(sgpr_model *h, void *stream);
  *                           0 = rebuild every step
  *  "ignore_unknown_species" = 0/1  atoms and LCE neighbours outside the species table are invisible
  *                           (descriptor/sesoap.py:343-346) instead of SGPR_E_SPECIES
- *  "overlap" = 0/1          covloss product on a side stream (measured slower; default 0) */
+ *  "overlap" = 0/1          covloss product on a side stream (measured slower; default 0)
+ *  "spin_wait" = 1/0        sgpr_compute polls its stream for the end of a step instead of a blocking wait
+ *                           (default 1: one host thread spins for the ~0.1 ms of a step, 16 us less wall time per
+ *                           call on a 4096-atom frame; 0: hipStreamSynchronize).  Environment: SGPR_SPIN_WAIT */
 int sgpr_set_option(sgpr_model *h, const char *name, int value);
 /* How many times the neighbour candidates were rebuilt since sgpr_create (see "skin_milliangstrom"). */
 int sgpr_get_list_rebuilds(sgpr_model *h, int64_t *count);
