@@ -435,9 +435,9 @@ class SGPRModel:
         cell = f64(np.asarray(cell, float).reshape(3, 3))
         pbc = i32(np.asarray(pbc, bool).astype(np.int32))
         E = C.c_double(0)
-        F = np.zeros((N, 3))
+        F = np.empty((N, 3))  # every output is written by the call (a failure raises)
         stress = np.zeros(6)
-        b = np.zeros(N) if beta else None
+        b = np.empty(N) if beta else None
         K = np.zeros((N, self.m)) if cov else None
         self.generation += 1
         check(_lib.load().sgpr_compute(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), rank, world,
