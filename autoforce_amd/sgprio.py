@@ -100,9 +100,14 @@ def format_extxyz(fr):
         head.append('stress="{}"'.format(" ".join(repr(float(v)) for v in s.reshape(-1))))
     head.append('pbc="{}"'.format(" ".join("T" if b else "F" for b in fr.pbc)))
     lines = [f"{fr.natoms}\n", " ".join(head) + "\n"]
-    for k in range(fr.natoms):
-        vals = list(fr.positions[k]) + (list(fr.forces[k]) if fr.forces is not None else [])
-        lines.append("{:<2s} ".format(SYMBOLS[int(fr.numbers[k])]) + " ".join(f"{v:22.15e}" for v in vals) + "\n")
+    # one %-format per row over plain Python floats (the same text as f"{v:22.15e}" per value, a quarter of the time:
+    # a 16384-atom frame goes to the tape after every accepted teacher call)
+    cols = np.asarray(fr.positions, float).reshape(fr.natoms, 3)
+    if fr.forces is not None:
+        cols = np.hstack([cols, np.asarray(fr.forces, float).reshape(fr.natoms, 3)])
+    fmt = "%-2s " + " ".join(["%22.15e"] * cols.shape[1]) + "\n"
+    syms = [SYMBOLS[z] for z in np.asarray(fr.numbers, int).tolist()]
+    lines.extend(fmt % (sym, *row) for sym, row in zip(syms, cols.tolist()))
     return lines
 
 
