@@ -62,6 +62,9 @@ def test_golden_frames(name):
     want = g["covloss"]
     ok = np.isfinite(want)
     np.testing.assert_allclose(out["beta"][ok], want[ok], rtol=0, atol=5e-7 * max(1.0, np.abs(want[ok]).max()))
+    # ... which is the square root's doing: beta^2 = (1 - |choli k|^2) vscale, the quantity the device actually
+    # accumulates, agrees to rounding
+    np.testing.assert_allclose(out["beta"][ok] ** 2, want[ok] ** 2, rtol=1e-9, atol=1e-11 * max(1.0, np.abs(want[ok]).max() ** 2))
     mdl.close()
 
 
@@ -149,6 +152,7 @@ def test_against_oracle_512_atoms():
     assert np.abs(out["forces"] - ref["forces"]).max() <= 1e-8 * np.abs(ref["forces"]).max()
     assert np.abs(out["stress"] - ref["stress"]).max() <= 1e-8 * np.abs(ref["stress"]).max()
     np.testing.assert_allclose(out["beta"], ref["beta"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["beta"] ** 2, ref["beta"] ** 2, rtol=1e-9, atol=1e-11)  # see test_golden_frames
     # Newton's third law (the reference's own sanity check in the survey: sum F = 1e-16)
     assert np.abs(out["forces"].sum(0)).max() <= 1e-10 * np.abs(out["forces"]).max()
     mdl.close()
