@@ -520,7 +520,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     HarmCoef hc;
     host_build_harm_coef(&hc);
     upload_harm_coef(hc);
-    h->d_grid.alloc(256);
+    h->d_grid.alloc(1024);  // the step's grid (128 B) + two cached {grid, cell} records by step parity (256 B each from 256)
     h->d_stat.alloc(4);
     h->d_bin_count.alloc(4096);
     h->d_cell_in.alloc(9);

@@ -132,14 +132,28 @@ __device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGr
     g.nbins = g.nb[0] * g.nb[1] * g.nb[2];
 }
 
+static_assert(sizeof(NlGrid) <= 128, "the cached grid records of nl_bin_kernel are 128 B + the cell");
+
 __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
 {
     __shared__ NlGrid g;
     const int tid = threadIdx.x, wg = blockIdx.x;
     if (tid == 0) {
-        nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
+        // The grid of the previous step is kept with the cell it was made for (two records, by step parity: this
+        // launch reads the one the previous launch wrote and writes the other — nobody writes what somebody reads).
+        // An MD run at constant cell finds it there and skips the inversion, the three heights and their dozen
+        // fp64 divisions and square roots on ONE lane while 255 wait at the barrier.
+        char *cache = (char *)a.grid + 256;
+        const NlGrid *g_prev = (const NlGrid *)(cache + 256 * (a.parity ^ 1));
+        const double *c_prev = (const double *)(cache + 256 * (a.parity ^ 1) + 128);
+        bool same = a.force == 0;
+        for (int k = 0; k < 9; k++) same = same && a.cell[k] == c_prev[k];
+        if (same) g = *g_prev;
+        else nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
         if (wg == 0) {
             *a.grid = g;
+            *(NlGrid *)(cache + 256 * a.parity) = g;
+            for (int k = 0; k < 9; k++) ((double *)(cache + 256 * a.parity + 128))[k] = a.cell[k];
             // rebuild decision, part 1: forced, or the cell differs from the one the candidates were built in;
             // the other parity's flag is cleared for the next step (nobody reads it during this one)
             bool changed = a.force != 0;
