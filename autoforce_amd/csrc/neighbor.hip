@@ -146,9 +146,10 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         char *cache = (char *)a.grid + 256;
         const NlGrid *g_prev = (const NlGrid *)(cache + 256 * (a.parity ^ 1));
         const double *c_prev = (const double *)(cache + 256 * (a.parity ^ 1) + 128);
+        const NlGrid gp = *g_prev;  // requested together with the two cells, not behind their comparison
         bool same = a.force == 0;
         for (int k = 0; k < 9; k++) same = same && a.cell[k] == c_prev[k];
-        if (same) g = *g_prev;
+        if (same) g = gp;
         else nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
         if (wg == 0) {
             *a.grid = g;
