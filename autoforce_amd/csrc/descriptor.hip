@@ -1069,9 +1069,36 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                            // species): every pair gradient is zero, only the hand-over slots have to be cleared
 
     PHASE_STAMP(0);
+    // Everything phase A reads of this atom (norm, W, p^, pack table, c) is requested NOW, next to the neighbour count:
+    // the addresses depend on the atom index only, and behind `nn > 0` and `nrm > 0` they were the third cold miss
+    // of a chain of three (nn -> norm -> rows): 15k cycles for 36 FMAs per lane.
+    constexpr int MAXE_H = ((ST * RD::N1 * (ST * RD::N1 + 1)) / 2 * RD::L1 + 63) / 64;
+    constexpr bool HOIST = MAXE_H <= 10;
+    const double nrm_h = active ? a.norm[ia] : 0.0;
+    double wv_h[HOIST ? MAXE_H : 1], pv_h[HOIST ? MAXE_H : 1], cv_h[HOIST ? ST * SPL : 1];
+    PackEntry pe_h[HOIST ? MAXE_H : 1];
+    if constexpr (HOIST) {
+        const double *Wi = ROWS ? a.rows_pm + (size_t)bq * a.Dpad : a.W + (size_t)(active ? ia : 0) * a.Dpad;
+        const double *Pi = a.Pn + (size_t)(active ? ia : 0) * a.Dpad;
+#pragma unroll
+        for (int k = 0; k < MAXE_H; k++) {
+            const int e = lane + 64 * k;
+            const bool in = e < a.Dc && active;
+            wv_h[k] = in ? aw_q * Wi[e] : 0.0;
+            pv_h[k] = in ? Pi[e] : 0.0;
+            pe_h[k] = a.pack[in ? e : 0];
+        }
+#pragma unroll
+        for (int s = 0; s < ST; s++)
+#pragma unroll
+            for (int k = 0; k < SPL; k++) {
+                const int slot = lane + 64 * k;
+                cv_h[s * SPL + k] = (active && s < a.S && (SPL * 64 == NSLOT || slot < NSLOT)) ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+            }
+    }
     if (nn > 0) {
         // ---------------------------------------------------------------- phase A: dE/dc -> dcl
-        const double nrm = a.norm[ia];
+        const double nrm = nrm_h;
         if (!(nrm > 0.0) || (ROWS && aw_q == 0.0)) {  // (aw_q: wave-uniform; 0 for atoms of other species)
             for (int k = lane; k < ST * NSLOT; k += 64) dcl[k] = 0.0;
             zero_dc = true;
@@ -1088,24 +1115,16 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             const double *Wi = ROWS ? a.rows_pm + (size_t)bq * a.Dpad : a.W + (size_t)ia * a.Dpad;
             const double *Pi = a.Pn + (size_t)ia * a.Dpad;
             if constexpr (MAXE <= 10) {
-                // all global reads of this atom are issued up front (W, p^, pack entries, c)
-                double wv[MAXE], pv[MAXE];
-                PackEntry pe[MAXE];
-#pragma unroll
-                for (int k = 0; k < MAXE; k++) {
-                    const int e = lane + 64 * k;
-                    const bool in = e < a.Dc;
-                    wv[k] = in ? aw_q * Wi[e] : 0.0;
-                    pv[k] = in ? Pi[e] : 0.0;
-                    pe[k] = a.pack[in ? e : 0];
-                }
+                // (the global reads of this atom — W, p^, pack entries, c — were issued at the top of the kernel)
+                static_assert(MAXE == MAXE_H, "hoisted loads");
+                double (&wv)[MAXE] = wv_h, (&pv)[MAXE] = pv_h;
+                PackEntry (&pe)[MAXE] = pe_h;
 #pragma unroll
                 for (int s = 0; s < ST; s++)
 #pragma unroll
                     for (int k = 0; k < SPL; k++) {
                         const int slot = lane + 64 * k;
-                        if (SPL * 64 == NSLOT || slot < NSLOT)
-                            cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+                        if (SPL * 64 == NSLOT || slot < NSLOT) cl[s * NSLOT + slot] = cv_h[s * SPL + k];
                     }
                 if constexpr (ROWS) {
                     bool nz = false;
