@@ -14,11 +14,14 @@
 // by the allocator (api.hip), so the main loop carries no bounds checks.
 //
 // Tile: 64x64 (TM = 2) or 32x64 (TM = 1) per 256-thread workgroup, 4 waves as 2x2, each wave TM x 2 MFMA tiles;
-// 32-deep K stages through LDS, fetched two stages ahead through registers (see the main loops: the 32-row form
-// keeps THREE stages in LDS, one barrier per stage, stores and loads issued in the shadow of the MFMAs).
-// Measured alternatives on the 4096 x 512 x 320 K_nm product: 16-deep stages fetched one ahead
-// 31 us; LDS-free fragment-shaped direct loads 35 us (TA-bound: each quad of lanes touches four
-// cache lines).
+// K stages through LDS, fetched two stages ahead through registers.  The three products of a step run on the 32-row
+// form with 16-deep stages (KD = 16): THREE stages in 36 KB of XOR-swizzled LDS, one barrier per stage, stores and
+// loads issued in the shadow of the MFMAs, four workgroups per CU; K_mm, the Cholesky trailing update and dense
+// launches keep the 64-row form with two 32-deep stages.  Every form accumulates a dot product over k in the same
+// order: the results do not depend on the tile shape (tests/test_hip_paths.py::test_gemm_tile_shapes_agree_bit_for_bit).
+// Measured alternatives on the 4096 x 512 x 320 K_nm product: LDS-free fragment-shaped direct loads 35 us (TA-bound:
+// each quad of lanes touches four cache lines); a 16-row panel against 256 columns per workgroup (one wave per SIMD)
+// 19 us (tools/ubench_gemm5.hip).  Built with -mllvm -amdgpu-mfma-vgpr-form=1 (build.sh): accumulators stay in VGPRs.
 #include "sgpr_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -56,13 +59,12 @@ __device__ __forceinline__ double ipow_d(double x, int n)
     return y;
 }
 
-// TM = MFMA row tiles per wave: 2 -> 64-row workgroup tiles, 1 -> 32-row tiles (twice the tiles, half
-// the latency of each: used when a launch would otherwise leave most CUs empty).
+// TM = MFMA row tiles per wave: 2 -> 64-row workgroup tiles, 1 -> 32-row tiles.
 // __launch_bounds__(256, 2): two workgroups per CU = two waves per SIMD = a budget of 256 registers, which makes the
 // compiler pick the VGPR form of the MFMAs; with the full 512 it picks the AGPR form and copies the sixteen
 // accumulator registers to VGPRs and back around every trip of the stage loop (16 v_accvgpr_write + 16 _read each
 // draining the matrix pipe).
-// KD = depth of a stage of the 32-row form: 32 (two workgroups per CU) or 16 (38 KB of LDS, <= 128 registers: FOUR
+// KD = depth of a stage of the 32-row form: 32 (two workgroups per CU) or 16 (36 KB of LDS, <= 128 registers: FOUR
 // workgroups per CU — for launches of many short reductions, where the fixed cost of a tile (tile entry, first loads,
 // epilogue: ~4 us, measured with per-tile stamps) is what the other resident workgroups have to cover).
 template <int EPI, int TM = 2, int KD = 32>
