@@ -291,12 +291,14 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
     if (q == 10) {
         // eight loads in flight per thread: one workgroup with one load per thread and trip moves 2 KB per memory
         // round trip (32768 atoms: 60 us of reducers behind a 15 us gather)
+        // (four 16-B loads, not eight: the reducers share the kernel's register allocation with the gather waves, and
+        // 64 VGPRs keep eight of those per SIMD)
         int m8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int4 *src4 = (const int4 *)f.nn_raw;  // the array is padded to whole rows of 64: 16-B loads stay inside it
         const int n4 = (f.cnt + 3) / 4;
-        for (int k0 = tid; k0 < n4; k0 += 2048) {
+        for (int k0 = tid; k0 < n4; k0 += 1024) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 4; u++) {
                 const int k = k0 + 256 * u;
                 const int4 v = src4[min(k, n4 - 1)];
                 const int e = 4 * k;
@@ -384,13 +386,19 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     const size_t by = blockIdx.y;
     // the first 64 pair gradients of the row are requested before the neighbour count is known (the row has maxnn
     // slots; what lies beyond the count is masked after the load): one cold miss less on the chain
-    const bool spec = lane < f.maxnn;
+    // (frames of a few thousand atoms are bound by this chain; large ones by bytes, and the slots beyond the count are
+    // a third of the row: there the count is read first)
+    const bool spec = f.N <= 16384;
     double2 g0 = make_double2(0.0, 0.0), g1 = make_double2(0.0, 0.0);
-    if (spec) {
+    if (spec && lane < f.maxnn) {
         const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + lane) * 4);
         g0 = row[0]; g1 = row[1];
     }
     const int n = f.nn[i];
+    if (!spec && lane < n) {
+        const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + lane) * 4);
+        g0 = row[0]; g1 = row[1];
+    }
     double fs = lane < 3 ? f.Fself[by * f.f_stride + 3 * (size_t)i + lane] : 0.0;
     double *packed = f.packed + by * f.p_stride;
     const int c = f.perm[i];
