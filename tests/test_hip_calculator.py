@@ -382,3 +382,36 @@ def test_single_atom_lce_from_device():
         with pytest.raises(Exception):
             mdl.local(N)
         mdl.close()
+
+
+def test_changing_cell_between_steps_and_wait_modes():
+    """One handle stepping through a sequence of cells (constant, strained, back: a barostat) gives, at every step, the bits
+    a fresh handle gives for that frame alone: the neighbour grid kept from the previous step is reused only for the
+    cell it was made for, and a changed cell rebuilds the candidate lists.  The same sequence with the blocking wait
+    (option "spin_wait" = 0) instead of the polled stream gives the same bits again."""
+    from autoforce_amd import _lib
+    mdl, numbers, pos, cell, pbc = _lips_model(8, 128)
+    rng = np.random.default_rng(4)
+    strain = np.eye(3) + 0.01 * rng.normal(size=(3, 3))
+    frames = []
+    p = pos.copy()
+    for step in range(7):
+        c = cell if step in (0, 1, 2, 5, 6) else cell @ strain
+        scaled = np.linalg.solve(cell.T, p.T).T          # fractional coordinates in the reference cell
+        frames.append((scaled @ c, c.copy()))
+        p = p + 0.01 * rng.normal(size=p.shape)
+    seq = [mdl.predict(numbers, x, c, pbc) for x, c in frames]
+    mdl.close()
+    for k, (x, c) in enumerate(frames):
+        fresh, *_ = _lips_model(8, 128)
+        ref = fresh.predict(numbers, x, c, pbc)
+        fresh.close()
+        for key in ("energy", "forces", "stress", "beta"):
+            np.testing.assert_array_equal(np.asarray(seq[k][key]), np.asarray(ref[key]), err_msg=f"step {k}: {key}")
+    blocking, *_ = _lips_model(8, 128)
+    _lib.check(_lib.load().sgpr_set_option(blocking._h, b"spin_wait", 0))
+    for k, (x, c) in enumerate(frames):
+        out = blocking.predict(numbers, x, c, pbc)
+        for key in ("energy", "forces", "stress", "beta"):
+            np.testing.assert_array_equal(np.asarray(out[key]), np.asarray(seq[k][key]), err_msg=f"blocking wait, step {k}: {key}")
+    blocking.close()
