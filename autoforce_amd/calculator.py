@@ -353,11 +353,12 @@ class ActiveCalculator(Calculator):
             energies, kwargs = self.meta(self)
             if energies is not None:
                 meta = f"meta: {float(np.sum(energies))}"
-        try:
-            temperature = self.atoms.get_temperature()
-        except Exception:
-            temperature = 0.0
-        self.log("{} {} {} {}".format(float(energy), temperature, self.covlog, meta))
+        if (self.logfile or self.stdout) and self.rank == 0:  # (nobody reads the line otherwise: skip the kinetic energy)
+            try:
+                temperature = self.atoms.get_temperature()
+            except Exception:
+                temperature = 0.0
+            self.log("{} {} {} {}".format(float(energy), temperature, self.covlog, meta))
         self.step += 1
         self.results["free_energy"] = self.results["energy"]  # active.py:527
         timings.append(time.time())
