@@ -577,6 +577,7 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const bool rebuild = __builtin_amdgcn_readfirstlane(*n.flag) != 0;
     int ncand = 0;
+    int j_first = 0, cd_first = 0;  // reuse steps: candidate 0..63 of this atom (set below)
     if (rebuild) {
         // -------------------------------------------------------------- candidates: sweep + sort
         const NlGrid g = *n.grid;
@@ -779,7 +780,15 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
         if (ncand > NL_SORT_MAX) __threadfence();  // rare: the unsorted tail written during the sweep is read back below
         PHASE_STAMP(2);
     } else {
-        ncand = __builtin_amdgcn_readfirstlane(n.ncand[i]);
+        // reuse step: the first 64 candidates are requested together with their count (the row has maxnn slots), not
+        // behind it — one round trip less on the chain count -> candidates -> positions
+        const int nc_v = n.ncand[i];
+        if (lane < maxnn) {
+            const size_t e = (size_t)i * maxnn + lane;
+            j_first = n.cand_j[e];
+            cd_first = n.cand_code[e];
+        }
+        ncand = __builtin_amdgcn_readfirstlane(nc_v);
         if (lane == 0) n.nn_raw[ia] = ncand;
     }
     // ------------------------------------------------------------------ this step's list: filter the candidates
@@ -798,6 +807,8 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
                 const int f0 = (int)((img >> 16) & 0xff) - 128, f1 = (int)((img >> 8) & 0xff) - 128, f2 = (int)(img & 0xff) - 128;
                 j = (int)(key >> 40);
                 cd = (f0 & 0xff) | ((f1 & 0xff) << 8) | ((f2 & 0xff) << 16) | (((int)(key >> 12) & 0xf) << 24);
+            } else if (!rebuild && c0 == 0) {
+                j = j_first; cd = cd_first;
             } else {
                 const size_t e = (size_t)i * maxnn + c;
                 j = n.cand_j[e];
