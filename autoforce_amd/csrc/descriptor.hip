@@ -1188,11 +1188,20 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
             }
             wave_sync();
             // dE/dc[u][lm] = sum_v G[u][v][l] c[v][lm]
+            // (the column of c is read once per slot and kept for all species: this contraction is bound by LDS bytes —
+            // every wave of the CU is here at the same time — and the stores to dcl kept the compiler from doing it)
             if (!zero_dc)
 #pragma unroll
-            for (int s = 0; s < ST; s++)
+            for (int k = 0; k < SPL; k++) {
+                const int slot_c = lane + 64 * k;
+                double cvv[EXPAND ? UT : 1];
+                if constexpr (EXPAND) {
+                    const int lm_c = (SPL * 64 == NSLOT || slot_c < NSLOT) ? slot_c % LL : 0;
 #pragma unroll
-                for (int k = 0; k < SPL; k++) {
+                    for (int v = 0; v < UT; v++) cvv[v] = v < Ur ? cl[v * LL + lm_c] : 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < ST; s++) {
                     const int slot = lane + 64 * k;
                     if (SPL * 64 == NSLOT || slot < NSLOT) {
                         double d = 0.0;
@@ -1204,8 +1213,8 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                             const int u = s * N1 + n;
                             if constexpr (EXPAND) {
                                 const double *gu = gl + u * UT * L1 + l;
-#pragma unroll 4
-                                for (int v = 0; v < Ur; v++) d += gu[v * L1] * cl[v * LL + lm];
+#pragma unroll
+                                for (int v = 0; v < UT; v++) d += (v < Ur ? gu[v * L1] : 0.0) * cvv[v];
                             } else {
                                 for (int v = 0; v < Ur; v++) {
                                     const int lo = min(u, v), hi = max(u, v);
@@ -1217,6 +1226,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
                         dcl[s * NSLOT + slot] = d;
                     }
                 }
+            }
         }
         PHASE_STAMP(1);
         // ---------------------------------------------------------------- phase B: pair terms
