@@ -939,6 +939,10 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     PHASE_STAMP(4);
     // c out of the accumulators (C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg): LDS for the power
     // spectrum, memory for the reverse pass
+    constexpr int L1 = LMAX + 1;
+    constexpr int UMAX = ST * N1;
+    constexpr bool PMF = UMAX <= 16;             // the power spectrum as C_l . C_l^T on the matrix pipe (below)
+    constexpr int CLS = PMF ? LL + 1 : LL;       // row stride of c in LDS (padded: conflict-free operand reads)
 #pragma unroll
     for (int rb = 0; rb < RBL; rb++)
 #pragma unroll
@@ -948,18 +952,70 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
                 const int lm = 16 * rb + (lane >> 4) + 4 * q, c = 16 * cb + (lane & 15);
                 if ((RBL * 16 == LL || lm < LL) && (CBS * 16 == UC || c < UC)) {
                     const int idx = (c / N1) * NSLOT + (c % N1) * LL + lm;
-                    cl[idx] = D[rb][cb][q];
+                    cl[PMF ? c * CLS + lm : idx] = D[rb][cb][q];
                     if (a.C && c / N1 < a.S) a.C[(size_t)ia * a.CS + idx] = D[rb][cb][q];
                 }
             }
     wave_sync();
     // packed power spectrum: entry e = pair(u<=v)*L1 + l : coef * sum_{lm in l} c[u][lm] c[v][lm].
-    // One lane per (u,v) pair, the l shells and their m sums statically unrolled.
     double nrm2 = 0.0;
-    constexpr int L1 = LMAX + 1;
-    constexpr int UMAX = ST * N1;
-    constexpr int MAXP = ((UMAX * (UMAX + 1)) / 2 + 63) / 64;
     const int npair = a.Dc / L1;
+    if constexpr (PMF) {
+        // P_l = C_l . C_l^T, C_l = c[:, l^2 .. l^2 + 2l]: rows and columns are the channels u, v (<= 16), k runs over the
+        // m of the shell, so A[row = lane & 15][k = lane >> 4] and B[k][col = lane & 15] are the SAME value in every lane
+        // — one ds_read_b64 per MFMA, 1 + 1 + 2 + 2 of them for l = 0..3, where one lane per (u, v) pair read 32 values
+        // of c (64 reads per lane with two pairs: every wave of the CU does this at the same moment and LDS bytes bound it).
+        // The lane gets P_l[u = (lane >> 4) + 4 r][v = lane & 15] and keeps u <= v < U; the coefficient of the entry is
+        // requested first (its address depends on the lane only).
+        const int Ur = a.S * N1, vch = lane & 15;
+        double cf[L1][4];
+        int eidx[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int u = (lane >> 4) + 4 * r;
+            const bool keep = u <= vch && vch < Ur;
+            eidx[r] = keep ? (u * Ur - (u * (u - 1)) / 2 + (vch - u)) * L1 : -1;
+#pragma unroll
+            for (int l = 0; l < L1; l++) cf[l][r] = keep ? a.pack[eidx[r] + l].coef : 0.0;
+        }
+        v4d P[L1];
+#pragma unroll
+        for (int l = 0; l < L1; l++) {
+            P[l] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < (2 * l + 4) / 4; ks++) {
+                const int kk = 4 * ks + (lane >> 4);
+                const double av = (vch < Ur && kk < 2 * l + 1) ? cl[vch * CLS + l * l + kk] : 0.0;
+                P[l] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, P[l], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < L1; l++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double pvv = P[l][r] * cf[l][r];
+                cf[l][r] = pvv;
+                nrm2 += pvv * pvv;
+            }
+        nrm2 = wave_sum(nrm2);
+        const double nrm = sqrt(nrm2);
+        const double inv = nn > 0 ? 1.0 / (nrm + SGPR_EPS) : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (eidx[r] >= 0) {
+#pragma unroll
+                for (int l = 0; l < L1; l++) a.Pn[(size_t)ia * a.Dpad + eidx[r] + l] = cf[l][r] * inv;
+            }
+        for (int e = a.Dc + lane; e < a.Dpad; e += 64) a.Pn[(size_t)ia * a.Dpad + e] = 0.0;
+        if (lane == 0) {
+            a.norm[ia] = nn > 0 ? nrm : 0.0;
+            if (a.shear) a.shear[ia] = shear ? 1 : 0;
+        }
+        PHASE_STAMP(5);
+        return;
+    }
+    // (more than 16 channels) one lane per (u,v) pair, the l shells and their m sums statically unrolled.
+    constexpr int MAXP = ((UMAX * (UMAX + 1)) / 2 + 63) / 64;
     double pv[MAXP][L1];
 #pragma unroll
     for (int k = 0; k < MAXP; k++) {
