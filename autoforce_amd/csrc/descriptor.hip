@@ -913,26 +913,33 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
         }
         wave_sync();
         // c[lm][(s,n)] += sum over the tile's neighbours, four per MFMA: A = Y[t][lm], B = f[t][n] [s_t = s]
-        for (int g4 = 0; g4 < cnt; g4 += 4) {
-            const int tr = g4 + (lane >> 4);
-            const int st = sl[tr];
-            double av[RBL], bv[CBS];
+        // (four k-steps per trip, their operands requested together: the rows beyond the count hold zeros, CH is a
+        // multiple of 16; one k-step per trip was a chain of LDS round trips, one per MFMA)
+        for (int g16 = 0; g16 < cnt; g16 += 16) {
+            double av[4][RBL], bv[4][CBS];
 #pragma unroll
-            for (int rb = 0; rb < RBL; rb++) {
-                const int lm = 16 * rb + (lane & 15);
-                av[rb] = (RBL * 16 == LL || lm < LL) ? Yl[tr * LLP + (lm < LL ? lm : 0)] : 0.0;
+            for (int q = 0; q < 4; q++) {
+                const int tr = g16 + 4 * q + (lane >> 4);
+                const int st = sl[tr];
+#pragma unroll
+                for (int rb = 0; rb < RBL; rb++) {
+                    const int lm = 16 * rb + (lane & 15);
+                    av[q][rb] = (RBL * 16 == LL || lm < LL) ? Yl[tr * LLP + (lm < LL ? lm : 0)] : 0.0;
+                }
+#pragma unroll
+                for (int cb = 0; cb < CBS; cb++) {
+                    const int c = 16 * cb + (lane & 15);
+                    const double fv = fl[tr * N1 + (c < UC ? c % N1 : 0)];
+                    bv[q][cb] = (c < UC && st == c / N1) ? fv : 0.0;
+                }
             }
 #pragma unroll
-            for (int cb = 0; cb < CBS; cb++) {
-                const int c = 16 * cb + (lane & 15);
-                const double fv = fl[tr * N1 + (c < UC ? c % N1 : 0)];
-                bv[cb] = (c < UC && st == c / N1) ? fv : 0.0;
-            }
+            for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int rb = 0; rb < RBL; rb++)
+                for (int rb = 0; rb < RBL; rb++)
 #pragma unroll
-                for (int cb = 0; cb < CBS; cb++)
-                    D[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rb], bv[cb], D[rb][cb], 0, 0, 0);
+                    for (int cb = 0; cb < CBS; cb++)
+                        D[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q][rb], bv[q][cb], D[rb][cb], 0, 0, 0);
         }
     }
     wave_sync();
