@@ -960,10 +960,14 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
                 if ((RBL * 16 == LL || lm < LL) && (CBS * 16 == UC || c < UC)) {
                     const int idx = (c / N1) * NSLOT + (c % N1) * LL + lm;
                     cl[PMF ? c * CLS + lm : idx] = D[rb][cb][q];
-                    if (a.C && c / N1 < a.S) a.C[(size_t)ia * a.CS + idx] = D[rb][cb][q];
                 }
             }
     wave_sync();
+    // c for the reverse pass goes out from LDS, lane = consecutive entry: in the accumulator layout neighbouring lanes
+    // hold neighbouring CHANNELS (16 doubles apart in memory) and every store instruction touched 64 cache lines
+    if (a.C)
+        for (int idx = lane; idx < a.S * NSLOT; idx += 64)
+            a.C[(size_t)ia * a.CS + idx] = cl[PMF ? (idx / LL) * CLS + idx % LL : idx];
     // packed power spectrum: entry e = pair(u<=v)*L1 + l : coef * sum_{lm in l} c[u][lm] c[v][lm].
     double nrm2 = 0.0;
     const int npair = a.Dc / L1;
