@@ -13,7 +13,8 @@
 #include <algorithm>
 #include <numeric>
 
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl is opened on the first sgpr_comm_* call (single-GPU installs need none)
 
 #include "../../include/sgpr_hip.h"
 #include "sgpr_internal.h"
@@ -33,7 +34,44 @@ static int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(SGPR_E_NODEVICE, "%s: %s", #x, hipGetErrorString(e_));    \
     } while (0)
 
+#define SGPR_PEER_POISON 1e9  // overflow word of a rank whose step failed outright (summed by the all-reduce)
 static inline int rup(int x, int q) { return (x + q - 1) / q * q; }
+
+// RCCL entry points, resolved on first use: a single-GPU process never loads the library
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.lib) return SGPR_OK;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return fail(SGPR_E_NODEVICE, "RCCL is not available (dlopen librccl.so: %s): multi-GPU runs need it", dlerror());
+    RcclApi a;
+    a.lib = lib;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.CommAbort = (decltype(a.CommAbort))dlsym(lib, "ncclCommAbort");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
+        dlclose(lib);
+        return fail(SGPR_E_NODEVICE, "librccl.so lacks an expected entry point");
+    }
+    g_rccl = a;
+    return SGPR_OK;
+}
+
 
 template <typename T>
 struct DevBuf {
@@ -257,6 +295,9 @@ struct FinArgs {
     int *rebuilds;              // running count of rebuilds
     const double *pos;          // [N][3] sorted order
     double *pos0;               // [N][3] positions the candidate lists were built at
+    const double *cell;         // this step's cell and bin grid (its inverse): kept as cell0[0..8], cell0[9..17] on
+    const NlGrid *grid;         //   rebuild steps — the reference frame of the affine rebuild rule (neighbor.hip)
+    double *cell0;
 };
 
 // wave64 sum on the DPP network (quads, half rows, rows) and four scalar row sums: the result is wave-uniform and
@@ -332,7 +373,12 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
     __syncthreads();
     if (tid == 0) {
         if (q == 10 && by == 0) {
-            if (*f.flag) atomicAdd(f.rebuilds, 1);
+            if (*f.flag) {
+                atomicAdd(f.rebuilds, 1);
+                if (f.cell0 && f.cell) {
+                    for (int k = 0; k < 9; k++) { f.cell0[k] = f.cell[k]; f.cell0[9 + k] = f.grid->inv[k]; }
+                }
+            }
             const int mx = (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3]));
             f.stat[0] = max(f.stat[0], mx);  // sticky
             // packed[4N+10]: 1 when this rank's step overflowed a capacity (its results are invalid); summed
@@ -532,8 +578,8 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_stat.alloc(4);
     h->d_bin_count.alloc(4096);
     h->d_cell_in.alloc(9);
-    h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds
-    h->d_cell0.alloc(9);
+    h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds, [3] always zero
+    h->d_cell0.alloc(18);  // cell at the last rebuild + its inverse
     if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
     if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
@@ -636,7 +682,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     h->d_b_rec.release();
     h->d_b_aux.release();
     h->d_grid.release();
-    if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->comm) (void)g_rccl.CommDestroy(h->comm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -773,39 +819,53 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
                 if (slot_of(h, nbr_z[e]) < 0)
                     return fail(SGPR_E_SPECIES, "inducing LCE %d: neighbour Z=%d is not in the species table", q, nbr_z[e]);
     }
-    drop_graph(h);
-    h->has_mu = h->has_choli = false;
-    h->chol_valid = h->r1_valid = false;
-    h->m = m;
-    h->m_pad = rup(std::max(m, 1), 32);
-    h->m_rows = rup(std::max(m, 1), 64);
-    h->ind_perm.resize(m);
-    std::iota(h->ind_perm.begin(), h->ind_perm.end(), 0);
-    std::stable_sort(h->ind_perm.begin(), h->ind_perm.end(), [&](int a, int b) { return slot[a] < slot[b]; });
-    h->ind_slot.resize(m);
-    h->qoff.assign(h->S + 1, 0);
+    // sizes and host tables of the NEW set in locals; the device arrays are allocated before anything in the handle
+    // changes, so a failed allocation leaves the previous inducing set fully usable
+    const int m_pad_n = rup(std::max(m, 1), 32), m_rows_n = rup(std::max(m, 1), 64);
+    std::vector<int> ind_perm_n(m);
+    std::iota(ind_perm_n.begin(), ind_perm_n.end(), 0);
+    std::stable_sort(ind_perm_n.begin(), ind_perm_n.end(), [&](int a, int b) { return slot[a] < slot[b]; });
+    std::vector<int> ind_slot_n(m), qoff_n(h->S + 1, 0);
     std::vector<int64_t> ptr(m + 1, 0);
     std::vector<int> eslot;
     std::vector<double> er;
-    std::vector<int> nn(h->m_rows, 1), dslot(h->m_rows, -2);
+    std::vector<int> nn(m_rows_n, 1), dslot(m_rows_n, -2);
     for (int k = 0; k < m; k++) {
-        const int q = h->ind_perm[k];
-        h->ind_slot[k] = slot[q];
+        const int q = ind_perm_n[k];
+        ind_slot_n[k] = slot[q];
         dslot[k] = slot[q];
-        h->qoff[slot[q] + 1]++;
+        qoff_n[slot[q] + 1]++;
         const int64_t a = nbr_ptr[q], b = nbr_ptr[q + 1];
         const size_t before = eslot.size();
         for (int64_t e = a; e < b; e++) {
             const int s = slot_of(h, nbr_z[e]);
-            if (s < 0 && h->ignore_unknown) continue;  // descriptor/sesoap.py:343-346
-            if (s < 0) return fail(SGPR_E_SPECIES, "inducing LCE %d: neighbour Z=%d is not in the species table", q, nbr_z[e]);
+            if (s < 0) continue;  // descriptor/sesoap.py:343-346 (ignore_unknown; anything else was refused above)
             eslot.push_back(s);
             er.push_back(nbr_r[3 * e]); er.push_back(nbr_r[3 * e + 1]); er.push_back(nbr_r[3 * e + 2]);
         }
         ptr[k + 1] = (int64_t)eslot.size();
         nn[k] = (int)(eslot.size() - before);
     }
-    for (int s = 0; s < h->S; s++) h->qoff[s + 1] += h->qoff[s];
+    for (int s = 0; s < h->S; s++) qoff_n[s + 1] += qoff_n[s];
+    DevBuf<int> n_ind_slot, n_ind_nn, n_qoff;
+    DevBuf<double> n_Pm, n_PmT, n_pm_norm, n_M, n_mu, n_choli;
+    if (n_ind_slot.alloc(m_rows_n) || n_ind_nn.alloc(m_rows_n) || n_qoff.alloc(h->S + 1) ||
+        n_Pm.alloc((size_t)m_rows_n * h->Dpad) || n_PmT.alloc((size_t)rup(h->Dpad, 64) * m_pad_n) ||
+        n_pm_norm.alloc(m_rows_n) || n_M.alloc((size_t)m_rows_n * m_pad_n) || n_mu.alloc(std::max(m_pad_n, m_rows_n)) ||
+        n_choli.alloc((size_t)m_rows_n * m_pad_n)) {
+        n_ind_slot.release(); n_ind_nn.release(); n_qoff.release(); n_Pm.release(); n_PmT.release(); n_pm_norm.release();
+        n_M.release(); n_mu.release(); n_choli.release();
+        return fail(SGPR_E_NODEVICE, "hipMalloc failed (inducing set): the previous set is untouched");
+    }
+    // ---- commit
+    drop_graph(h);
+    h->has_mu = h->has_choli = false;
+    h->chol_valid = h->r1_valid = false;
+    h->m = m; h->m_pad = m_pad_n; h->m_rows = m_rows_n;
+    h->ind_perm.swap(ind_perm_n); h->ind_slot.swap(ind_slot_n); h->qoff.swap(qoff_n);
+    auto take = [](auto &dst, auto &src) { dst.release(); dst = src; src.p = nullptr; src.n = 0; };
+    take(h->d_ind_slot, n_ind_slot); take(h->d_ind_nn, n_ind_nn); take(h->d_qoff, n_qoff); take(h->d_Pm, n_Pm);
+    take(h->d_PmT, n_PmT); take(h->d_pm_norm, n_pm_norm); take(h->d_M, n_M); take(h->d_mu, n_mu); take(h->d_choli, n_choli);
     {   // keep the caller's list for the edit entry points (copy first: the inputs may alias h->env_*)
         const int64_t lo = m > 0 ? nbr_ptr[0] : 0, hi = m > 0 ? nbr_ptr[m] : 0;
         std::vector<int32_t> ezc(zc, zc + m), ez(nbr_z + lo, nbr_z + hi);
@@ -814,11 +874,6 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
         for (int q = 0; q < m; q++) eptr[q + 1] = nbr_ptr[q + 1] - lo;
         h->env_zc.swap(ezc); h->env_z.swap(ez); h->env_ptr.swap(eptr); h->env_r.swap(evr);
     }
-    if (h->d_ind_slot.alloc(h->m_rows) || h->d_ind_nn.alloc(h->m_rows) || h->d_qoff.alloc(h->S + 1) ||
-        h->d_Pm.alloc((size_t)h->m_rows * h->Dpad) || h->d_PmT.alloc((size_t)rup(h->Dpad, 64) * h->m_pad) ||
-        h->d_pm_norm.alloc(h->m_rows) || h->d_M.alloc((size_t)h->m_rows * h->m_pad) || h->d_mu.alloc(std::max(h->m_pad, h->m_rows)) ||
-        h->d_choli.alloc((size_t)h->m_rows * h->m_pad))
-        return fail(SGPR_E_NODEVICE, "hipMalloc failed (inducing set)");
     HIPCHK(hipMemcpy(h->d_ind_slot.p, dslot.data(), sizeof(int) * h->m_rows, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_ind_nn.p, nn.data(), sizeof(int) * h->m_rows, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_qoff.p, h->qoff.data(), sizeof(int) * (h->S + 1), hipMemcpyHostToDevice));
@@ -1175,8 +1230,12 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
     f.mean_energy = mean_energy; f.packed = packed_dev; f.stat = h->d_stat.p; f.bin_count = h->d_bin_count.p;
     f.flag = h->step_flag ? h->step_flag : h->d_flag.p; f.pos = h->d_pos.p; f.pos0 = h->d_pos0.p;
     f.rebuilds = h->d_flag.p + 2;
+    f.cell = h->last_cell; f.grid = (const NlGrid *)h->d_grid.p; f.cell0 = h->d_cell0.p;
     int batch = 1;
     if (fb) {
+        // column batches of the training rows re-use the lists of the step that ran just before them: that step's
+        // finalize has done the rebuild bookkeeping (pos0, cell0, the rebuild counter) — not again per batch
+        f.flag = h->d_flag.p + 3;
         batch = fb->batch;
         f.G = fb->G; f.Fnbr = fb->F; f.Fself = fb->F + 3 * (size_t)N; f.virpart = fb->virpart;
         f.g_stride = fb->g_stride; f.f_stride = fb->f_stride; f.v_stride = fb->v_stride; f.p_stride = fb->p_stride;
@@ -1359,20 +1418,25 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
 static int reduce_packed(sgpr_model *h, double *packed_dev, hipStream_t st)
 {
     if (!h->comm) return SGPR_OK;  // no communicator attached: the caller combines the partial sums
+    // an unsharded bind (rank 0 of 1) under a multi-rank communicator is a REPLICATED evaluation: every rank holds
+    // the totals of the whole frame already (initiate_model / get_unique_lces / training rows evaluate whole frames
+    // on every rank, calculator/active.py:612-676) — nothing to combine
+    if (h->world == 1) return SGPR_OK;
     if (h->comm_world != h->world || h->comm_rank != h->rank)
         return fail(SGPR_E_INVALID, "the bound sharding (rank %d of %d) differs from the communicator's (rank %d of %d)",
                     h->rank, h->world, h->comm_rank, h->comm_world);
-    const ncclResult_t r = ncclAllReduce(packed_dev, packed_dev, (size_t)sgpr_packed_len(h->N), ncclDouble, ncclSum, h->comm, st);
-    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    const ncclResult_t r = g_rccl.AllReduce(packed_dev, packed_dev, (size_t)sgpr_packed_len(h->N), ncclDouble, ncclSum, h->comm, st);
+    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     return SGPR_OK;
 }
 
 extern "C" int sgpr_comm_unique_id(void *id_out)
 {
     if (!id_out) return fail(SGPR_E_INVALID, "sgpr_comm_unique_id: bad arguments");
+    if (const int rl = rccl_load()) return rl;
     ncclUniqueId id;
-    const ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r));
     static_assert(sizeof(id) == SGPR_COMM_ID_BYTES, "ncclUniqueId size");
     memcpy(id_out, &id, sizeof(id));
     return SGPR_OK;
@@ -1381,12 +1445,13 @@ extern "C" int sgpr_comm_unique_id(void *id_out)
 extern "C" int sgpr_comm_init(sgpr_model *h, const void *id_in, int rank, int world)
 {
     if (!h || !id_in || world < 1 || rank < 0 || rank >= world) return fail(SGPR_E_INVALID, "sgpr_comm_init: bad arguments");
+    if (const int rl = rccl_load()) return rl;
     HIPCHK(hipSetDevice(h->device));
-    if (h->comm) { (void)ncclCommDestroy(h->comm); h->comm = nullptr; }
+    if (h->comm) { (void)g_rccl.CommDestroy(h->comm); h->comm = nullptr; }
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof(id));
-    const ncclResult_t r = ncclCommInitRank(&h->comm, world, id, rank);
-    if (r != ncclSuccess) { h->comm = nullptr; return fail(SGPR_E_NODEVICE, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
+    const ncclResult_t r = g_rccl.CommInitRank(&h->comm, world, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return fail(SGPR_E_NODEVICE, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
     h->comm_rank = rank; h->comm_world = world;
     drop_graph(h);
     return SGPR_OK;
@@ -1398,7 +1463,7 @@ extern "C" int sgpr_comm_destroy(sgpr_model *h)
     if (h->comm) {
         HIPCHK(hipSetDevice(h->device));
         HIPCHK(hipStreamSynchronize(h->stream));
-        (void)ncclCommDestroy(h->comm);
+        (void)g_rccl.CommDestroy(h->comm);
         h->comm = nullptr;
         drop_graph(h);
     }
@@ -1414,8 +1479,8 @@ extern "C" int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count
     if (!h->comm) return fail(SGPR_E_INVALID, "sgpr_comm_allreduce: no communicator (sgpr_comm_init)");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    const ncclResult_t r = ncclAllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, op_max ? ncclMax : ncclSum, h->comm, st);
-    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    const ncclResult_t r = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, op_max ? ncclMax : ncclSum, h->comm, st);
+    if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     return SGPR_OK;
 }
 
@@ -1491,6 +1556,19 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
     HIPCHK(hipMemcpyAsync(h->d_pos_in.p, positions, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_cell_in.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
     const int rc_ = run_checked(h, h->d_pos_in.p, h->d_cell_in.p, h->d_packed.p, h->stream);
+    if (rc_ && h->comm && h->world > 1) {
+        // A rank-local failure must not leave the peers blocked in the step's all-reduce: this rank still issues
+        // its collective, with a poison value in the overflow word, and every rank fails the call alike.
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        const double poison = SGPR_PEER_POISON;
+        if (hipMemsetAsync(h->d_packed.p, 0, sizeof(double) * n_out, h->stream) == hipSuccess &&
+            hipMemcpyAsync(h->d_packed.p + 4 * (size_t)N + 10, &poison, sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+            reduce_packed(h, h->d_packed.p, h->stream) == SGPR_OK)
+            (void)hipStreamSynchronize(h->stream);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc_;
+    }
     if (rc_) return rc_;
     h->warm = true;
     {   // (after the capacity-checked local pass: every rank issues exactly one collective per call)
@@ -1500,6 +1578,12 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
     }
     std::vector<double> out((size_t)4 * N + 11);
     HIPCHK(hipMemcpy(out.data(), h->d_packed.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
+    if (out[4 * (size_t)N + 10] >= 0.5 * SGPR_PEER_POISON) {
+        h->warm = false;
+        h->lists_valid = false;
+        return fail(SGPR_E_OVERFLOW, "sgpr_compute: another rank of the communicator failed this step (its own error "
+                    "message says why); the call fails on every rank");
+    }
     if (forces) memcpy(forces, out.data(), sizeof(double) * 3 * N);
     if (beta) memcpy(beta, out.data() + 3 * (size_t)N, sizeof(double) * N);
     if (energy) *energy = out[4 * (size_t)N];
@@ -1574,14 +1658,16 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
     int stat[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stat.p, 0, 4 * sizeof(int)));
-    if (stat[3] == 2) { h->warm = false; return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero"); }
+    if (stat[3] == 2) { h->warm = false; h->lists_valid = false; return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero"); }
     if (stat[3]) {
         h->warm = false;
+        h->lists_valid = false;
         return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 cells "
                     "from the origin): wrap the positions into the cell; results since the last check are invalid");
     }
     if (stat[0] > h->maxnn || stat[1] > h->bin_cap || (h->world == 1 && h->gather_ok && stat[2] > h->t_stride)) {
         h->warm = false;  // next step re-sizes eagerly
+        h->lists_valid = false;  // ... and rebuilds the candidates: a clamped list must not be reused as if complete
         return fail(SGPR_E_OVERFLOW, "neighbour-list capacity exceeded (neighbours %d/%d, bin %d/%d, reverse index %d/%d); "
                     "results of the steps since the last check are invalid", stat[0], h->maxnn, stat[1], h->bin_cap,
                     stat[2], h->t_stride);
@@ -1593,7 +1679,11 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
 extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
 {
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
-    if (!strcmp(name, "graph")) { h->use_graph = value != 0; drop_graph(h); return SGPR_OK; }
+    if (!strcmp(name, "graph")) {
+        // the effective list cutoff switches between rc (graph: rebuild every step) and rc + skin: candidates and
+        // the cached bin grid of the other mode must not be reused
+        h->use_graph = value != 0; drop_graph(h); h->lists_valid = false; return SGPR_OK;
+    }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "spin_wait")) { h->spin_wait = value != 0; return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }

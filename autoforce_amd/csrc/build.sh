@@ -16,5 +16,5 @@ for f in api descriptor neighbor gemm linalg tsqr; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/api.o build/descriptor.o build/neighbor.o build/gemm.o build/linalg.o build/tsqr.o -L/opt/rocm/lib -lrccl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/api.o build/descriptor.o build/neighbor.o build/gemm.o build/linalg.o build/tsqr.o -ldl
 echo "built $(realpath $OUT)"

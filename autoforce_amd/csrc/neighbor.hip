@@ -47,8 +47,10 @@ struct BinArgs {
     // Verlet candidates: rebuild decision of this step
     int *flag; int parity, force;
     double half_skin2;      // (skin / 2)^2
+    double rc_list;         // rc + skin: the cutoff the candidates were built with
+    double rc_phys;         // rc
     const double *pos0;     // [N][3] positions at the last rebuild (sorted order)
-    double *cell0;          // [9]
+    const double *cell0;    // [9] cell at the last rebuild, [9..17] its inverse (both written by finalize on rebuild steps)
 };
 
 __device__ void nl_make_grid(const double *cell, const int *pbc, double rc, NlGrid &g, int *stat)
@@ -137,6 +139,8 @@ static_assert(sizeof(NlGrid) <= 128, "the cached grid records of nl_bin_kernel a
 __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
 {
     __shared__ NlGrid g;
+    __shared__ double Aff[9];
+    __shared__ double thr2;
     const int tid = threadIdx.x, wg = blockIdx.x;
     if (tid == 0) {
         // The grid of the previous step is kept with the cell it was made for (two records, by step parity: this
@@ -151,18 +155,39 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         for (int k = 0; k < 9; k++) same = same && a.cell[k] == c_prev[k];
         if (same) g = gp;
         else nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
+        // Candidates under a CHANGED cell (NPT: cl/md.py:147-150 strains the cell every step).  With A = h0^-1 h
+        // (the affine map from the build-time cell to this one) and u_i = x_i - x_i0 A, a pair outside the
+        // candidates (|r0| >= rc + skin) has |r| >= sigma_min(A) (rc + skin) - |u_i| - |u_j|, so the lists stay
+        // complete while every |u_i| <= (sigma_min(A) (rc + skin) - rc) / 2; sigma_min(A) >= 1 - |A - I|_F.
+        // Same cell bit for bit: A = I and the bound is skin / 2.  Open directions keep the strict rule.
+        bool cell_same = true;
+        for (int k = 0; k < 9; k++) cell_same = cell_same && a.cell[k] == a.cell0[k];
+        double thr = 0.5 * (a.rc_list - a.rc_phys);
+        for (int k = 0; k < 9; k++) Aff[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        if (!cell_same) {
+            if (a.pbc[0] && a.pbc[1] && a.pbc[2]) {
+                const double *iv = a.cell0 + 9;
+                double fro = 0.0;
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) {
+                        const double v = iv[3 * r] * a.cell[c] + iv[3 * r + 1] * a.cell[3 + c] + iv[3 * r + 2] * a.cell[6 + c];
+                        Aff[3 * r + c] = v;
+                        const double d = v - (r == c ? 1.0 : 0.0);
+                        fro += d * d;
+                    }
+                thr = 0.5 * ((1.0 - sqrt(fro)) * a.rc_list - a.rc_phys);
+                if (!(fro < 1.0)) thr = -1.0;  // (also catches NaN: a degenerate build-time cell)
+            } else
+                thr = -1.0;
+        }
+        thr2 = thr > 0.0 ? thr * thr : -1.0;
         if (wg == 0) {
             *a.grid = g;
             *(NlGrid *)(cache + 256 * a.parity) = g;
             for (int k = 0; k < 9; k++) ((double *)(cache + 256 * a.parity + 128))[k] = a.cell[k];
-            // rebuild decision, part 1: forced, or the cell differs from the one the candidates were built in;
-            // the other parity's flag is cleared for the next step (nobody reads it during this one)
-            bool changed = a.force != 0;
-            for (int k = 0; k < 9; k++) changed |= a.cell[k] != a.cell0[k];
-            if (changed) {
-                for (int k = 0; k < 9; k++) a.cell0[k] = a.cell[k];
-                atomicMax(&a.flag[a.parity], 1);
-            }
+            // rebuild decision, part 1: forced, or the cell moved too far from the one the candidates were built
+            // in (below); the other parity's flag is cleared for the next step (nobody reads it during this one)
+            if (a.force != 0 || !(thr2 > 0.0)) atomicMax(&a.flag[a.parity], 1);
             a.flag[a.parity ^ 1] = 0;
         }
     }
@@ -184,8 +209,9 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     if (i >= a.N) return;
     a.pos[3 * i] = x; a.pos[3 * i + 1] = y; a.pos[3 * i + 2] = z;
     {   // rebuild decision, part 2: has this atom moved more than half the skin since the candidates were built?
-        const double dx = x - x0, dy = y - y0, dz = z - z0;
-        if (!(dx * dx + dy * dy + dz * dz <= a.half_skin2)) atomicMax(&a.flag[a.parity], 1);
+        const double dx = x - (x0 * Aff[0] + y0 * Aff[3] + z0 * Aff[6]), dy = y - (x0 * Aff[1] + y0 * Aff[4] + z0 * Aff[7]),
+                     dz = z - (x0 * Aff[2] + y0 * Aff[5] + z0 * Aff[8]);
+        if (!(dx * dx + dy * dy + dz * dz <= thr2)) atomicMax(&a.flag[a.parity], 1);
     }
     int bidx[3], w[3];
 #pragma unroll
@@ -234,6 +260,6 @@ void launch_neighbor_bin(const NlParams &p, const int *perm, const double *pos_i
     a.slot = s.slot; a.bin_of = s.bin_of; a.kslot = s.kslot; a.stat = s.stat;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
     a.flag = s.flag; a.parity = s.parity; a.force = s.force; a.half_skin2 = 0.25 * s.skin * s.skin; a.pos0 = s.pos0;
-    a.cell0 = s.cell0;
+    a.cell0 = s.cell0; a.rc_list = rc; a.rc_phys = rc - s.skin;
     hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
 }

@@ -83,6 +83,13 @@ class SGPRModel:
     def handle(self):
         return self._h
 
+    def list_rebuilds(self):
+        """How many steps of this handle rebuilt the Verlet candidate lists so far (the others filtered the kept
+        candidates: descriptor.hip)."""
+        n = C.c_int64(0)
+        check(_lib.load().sgpr_get_list_rebuilds(self._h, C.addressof(n)))
+        return int(n.value)
+
     # ------------------------------------------------------------------ multi-GPU (one process per GPU)
     @staticmethod
     def comm_unique_id():
@@ -114,8 +121,13 @@ class SGPRModel:
         wildcard kernel of the reference (calculator/active.py:28-38, a 120-wide sparse table) is
         served by a dense table — it is re-laid-out when a new species turns up.  Descriptor blocks
         of absent species are zero, so every kernel value, mu and choli stay what they were."""
-        new = SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=species, device=self.device,
-                        unknown_species=self.unknown_species)
+        # species already in the table keep their length unit (a model built with custom radii must not fall back
+        # to the defaults on the first re-layout: the kernel would change under mu and choli); new ones get the
+        # default (descriptor/sesoap.py:84-99)
+        have = {int(z): float(r) for z, r in zip(self.species, self.radii)}
+        radii = [have.get(int(z), float(default_radii([z])[0])) for z in species]
+        new = SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=species, radii=radii,
+                        device=self.device, unknown_species=self.unknown_species)
         new.mean.update(self.mean)
         new._vscale = dict(self._vscale)
         if self.X:

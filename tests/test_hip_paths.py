@@ -254,3 +254,43 @@ def test_degenerate_inputs():
     with pytest.raises(SgprError) as e:
         SGPRModel(5, 3, 4.0, 6.0, species=[14])  # not compiled in
     assert e.value.code == -6
+
+
+def test_npt_walk_reuses_candidates_under_strain():
+    """A barostat strains the cell a little EVERY step (cl/md.py:147-150).  The candidate lists stay valid while the
+    non-affine displacement of every atom, u_i = x_i - x_i0 h0^-1 h, stays below (sigma_min(h0^-1 h) (rc + skin) - rc) / 2
+    (neighbor.hip): over a 40-step walk with a 1e-4 random strain and thermal-size moves per step the lists are rebuilt
+    a handful of times, not 40, and every step gives bit for bit what a handle that rebuilds its lists every step
+    gives — same pairs, same order, same sums."""
+    from autoforce_amd import _lib
+    from test_hip_parity import load, model_from_fixture
+    g = load("g5_mixed64")
+    fast, slow = model_from_fixture(g), model_from_fixture(g)
+    _lib.check(_lib.load().sgpr_set_option(slow.handle, b"skin_milliangstrom", 0))
+    rng = np.random.default_rng(23)
+    pos, cell = g["positions"].copy(), g["cell"].copy()
+    N = len(pos)
+    steps = 40
+    for step in range(steps):
+        strain = np.eye(3) + 1e-4 * rng.normal(size=(3, 3))
+        frac = np.linalg.solve(cell.T, pos.T).T
+        cell = cell @ strain
+        pos = frac @ cell + 0.012 * rng.normal(size=pos.shape)   # affine move with the cell + thermal-size noise
+        a = fast.predict(g["numbers"], pos, cell, g["pbc"], cov=True)
+        b = slow.predict(g["numbers"], pos, cell, g["pbc"], cov=True)
+        for k in ("energy", "forces", "stress", "beta", "cov"):
+            np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]), err_msg=f"step {step}: {k}")
+        for x, y in zip(fast.neighbors(N), slow.neighbors(N)):
+            np.testing.assert_array_equal(x, y)
+    assert slow.list_rebuilds() >= steps
+    assert fast.list_rebuilds() <= 6, fast.list_rebuilds()
+    # a strain beyond the bound (here 5 %: sigma_min * 6.5 < 6) must rebuild, and still agree
+    cell = cell @ (np.eye(3) * 1.05)
+    pos = pos * 1.05
+    before = fast.list_rebuilds()
+    a = fast.predict(g["numbers"], pos, cell, g["pbc"])
+    b = slow.predict(g["numbers"], pos, cell, g["pbc"])
+    assert fast.list_rebuilds() == before + 1
+    for k in ("energy", "forces", "stress", "beta"):
+        np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
+    fast.close(); slow.close()
