@@ -69,6 +69,7 @@ SIGNATURES = {
     "sgpr_comm_allreduce": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
     "sgpr_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "sgpr_get_list_rebuilds": (C.c_int, [_vp, _vp]),
+    "sgpr_solve_info": (C.c_int, [_vp, _vp, C.c_int]),
     "sgpr_stress_from_virial": (C.c_int, [_vp, _vp, _vp]),
     "sgpr_get_descriptors": (C.c_int, [_vp, _vp]),
     "sgpr_get_neighbors": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -183,7 +183,9 @@ struct sgpr_model {
     // kernels they served: a refit makes a dozen such calls)
     DevBuf<double> sc_s2A, sc_s2x, sc_s2work, sc_mv_v, sc_mv_o, sc_ra_y, sc_ra_t, sc_vs_t, sc_ai_er, sc_ai_p, sc_ai_norm,
         sc_ai_krow, sc_ai_kself, sc_y, sc_bA, sc_bx, sc_bwork;
-    DevBuf<int> sc_s2so, sc_ai_eslot, sc_ai_oslot, sc_ai_onn, sc_ai_info;
+    DevBuf<int> sc_s2so, sc_ai_eslot, sc_ai_oslot, sc_ai_onn, sc_ai_info, sc_sel_idx, sc_sel_map, sc_chol_info;
+    DevBuf<double> sc_sel_A, sc_sel_work;
+    DevBuf<double> d_design_alt;  // second buffer of the resident matrix: column selections gather into it, then swap
     DevBuf<int64_t> sc_ai_ptr, sc_erow;
     DevBuf<unsigned char> sc_ise;
     int64_t design_rcap = 0, design_ccap = 0, design_rows = 0;
@@ -213,8 +215,21 @@ struct sgpr_model {
         std::vector<TsqrPanel> panels;     // the panels of the full factorisation
         size_t store_base = 0;             // where the appended columns' reflectors start in `store`: slot a holds
                                            // v [ldr], sc, alpha
-        std::vector<int> app_k0;           // appended columns: their column index (one flat reflector each),
-        std::vector<char> app_snap;        //   whether ysnap holds Q^T Y from before them
+        // what came after the full factorisation, in order (each one an orthogonal map of the rows):
+        //   kind 0  ONE flat reflector over rows [k0, R): the column appended at position k0
+        //   kind 1  the panels of a column SELECTION (sgpr_select_inducing: downsize(lii) / popfirst /
+        //           remove at an index, gppotential.py:815-842, :1037-1046): the QR of R1[:, idx] over the leading
+        //           `rows` rows, kept with its own reflectors in `pstore`
+        struct Op {
+            int kind = 0, k0 = 0, flat_ix = 0, rows = 0;
+            char snap = 0;                 // flat: ysnap[flat_ix] holds Q^T Y from before it
+            std::vector<TsqrPanel> panels;
+            DevBuf<double> pstore;
+        };
+        std::vector<Op> ops;
+        bool selected = false;             // a selection since the last refit (diagnostics)
+        int nflat = 0;                     // flats among the ops (slots of `store` / `ysnap` in use: a stack)
+        void clear_ops() { for (auto &o : ops) o.pstore.release(); ops.clear(); nflat = 0; }
         uint64_t age = 0;
     };
     QrKeep qr_keep[4];
@@ -223,6 +238,13 @@ struct sgpr_model {
     DevBuf<double> d_L, d_R1;
     DevBuf<double> d_edit_tmp;  // scratch of the incremental inducing-set edits
     bool chol_valid = false, r1_valid = false;
+    // K_mm is block diagonal by species, so is its factor: blocks are factored one by one and an edit only
+    // invalidates the blocks it touches.  blk_ok[s]: block s of d_L / d_choli is the factor of block s of d_M at
+    // chol_ridge (only meaningful while chol_shape: both arrays have the current m x m_pad shape)
+    std::vector<char> blk_ok;
+    bool chol_shape = false;
+    std::string info_stage1 = "none";        // sgpr_solve_info
+    int info_blocks_done = 0, info_blocks = 0;
     double chol_ridge = 0.0, chol_dmean = 0.0;
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
@@ -666,14 +688,16 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                                 &h->sc_ai_er, &h->sc_ai_p, &h->sc_ai_norm, &h->sc_ai_krow, &h->sc_ai_kself, &h->sc_y, &h->sc_bA, &h->sc_bx,
                                 &h->sc_bwork};
         for (auto b : sd) b->release();
-        DevBuf<int> *si[] = {&h->sc_s2so, &h->sc_ai_eslot, &h->sc_ai_oslot, &h->sc_ai_onn, &h->sc_ai_info};
+        DevBuf<int> *si[] = {&h->sc_s2so, &h->sc_ai_eslot, &h->sc_ai_oslot, &h->sc_ai_onn, &h->sc_ai_info, &h->sc_sel_idx,
+                             &h->sc_sel_map, &h->sc_chol_info};
+        h->sc_sel_A.release(); h->sc_sel_work.release(); h->d_design_alt.release();
         for (auto b : si) b->release();
         h->sc_ai_ptr.release();
         h->sc_erow.release();
         h->sc_ise.release();
     }
     for (auto &e : h->r1_cache) e.r1.release();
-    for (auto &k : h->qr_keep) { k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
+    for (auto &k : h->qr_keep) { k.clear_ops(); k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
     h->d_T.release();
     h->d_hm.release();
@@ -861,6 +885,7 @@ extern "C" int sgpr_set_inducing(sgpr_model *h, int m, const int32_t *zc, const 
     drop_graph(h);
     h->has_mu = h->has_choli = false;
     h->chol_valid = h->r1_valid = false;
+    h->chol_shape = false;
     h->m = m; h->m_pad = m_pad_n; h->m_rows = m_rows_n;
     h->ind_perm.swap(ind_perm_n); h->ind_slot.swap(ind_slot_n); h->qoff.swap(qoff_n);
     auto take = [](auto &dst, auto &src) { dst.release(); dst = src; src.p = nullptr; src.n = 0; };

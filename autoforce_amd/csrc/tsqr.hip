@@ -91,6 +91,7 @@ __device__ __forceinline__ double half_swap(double v)
     return __hiloint2double(low ? rh[1] : rh[0], low ? rl[1] : rl[0]);
 }
 
+#define TSQR_TINY2 1e-280  // squared column norms below this are zero (see tsqr_leaf_kernel)
 #define TLT 512  // threads of the leaf kernel
 #define TRG 16   // rows per thread (= row groups)
 __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
@@ -150,8 +151,13 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
         const double akk = vbuf[jb][(j & 15) * TRG + (j >> 4)];
         // |x| and 2 / (v.v) = 1 / (|x| (|x| + |x_j|)) from the hardware seeds + one Newton step each (every wave
         // repeats this chain at every step: the IEEE sqrt / division sequences were a third of the step's instructions)
+        // (a column whose squared norm is below TSQR_TINY2 counts as zero: its reflector is the identity.  The chunks
+        // of a panel can be EXACTLY rank deficient — columns that are combinations of one or two reflectors of the
+        // previous panel, as in the column selections of a kept factor — and then every further pivot is rounding
+        // noise of rounding noise, a factor 1e-16 smaller each step, until s2 is subnormal and the reciprocal
+        // square root seed overflows: NaN)
         double nrm = 0.0, sc = 0.0;
-        if (s2 > 0.0) {
+        if (s2 > TSQR_TINY2) {
             double rs = __builtin_amdgcn_rsq(s2);
             rs = rs * (1.5 - 0.5 * s2 * rs * rs);
             nrm = s2 * rs;
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(256) void flat_make_kernel(int n, int np, const dou
     const int i0 = blockIdx.x * FCH, i1 = min(n, i0 + FCH);
     for (int i = i0 + threadIdx.x; i < i1; i += 256) v[i] = i == 0 ? v0 : x[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sc[0] = vv > 0.0 ? 2.0 / vv : 0.0;
+        sc[0] = vv > TSQR_TINY2 ? 2.0 / vv : 0.0;
         alpha_out[0] = alpha;
     }
 }

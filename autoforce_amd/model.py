@@ -83,6 +83,12 @@ class SGPRModel:
     def handle(self):
         return self._h
 
+    def solve_info(self):
+        """Route of the last data_solve / data_factor (sgpr_solve_info): 'stage1=...; kmm_blocks=a/b'."""
+        buf = C.create_string_buffer(256)
+        check(_lib.load().sgpr_solve_info(self._h, buf, 256))
+        return buf.value.decode()
+
     def list_rebuilds(self):
         """How many steps of this handle rebuilt the Verlet candidate lists so far (the others filtered the kept
         candidates: descriptor.hip)."""

@@ -71,6 +71,117 @@ def oxide(shape=(32, 32, 16), seed=0, sigma=0.15):
     return numbers, pos, cell, np.array([True, True, True])
 
 
+def oxide_ordered(shape=(32, 32, 16), seed=0, sigma=0.05):
+    """C5 for on-the-fly MD: the same 4 species and 2:1:1:4 stoichiometry (Li, Zr, La, O) on the same 2.72 A sites, but
+    ORDERED — a rocksalt-type arrangement, O on the odd-parity sublattice, Zr / La / Li / Li on the four sites of the
+    even one inside every 2x2x2 cube.  Its environments repeat, so a learner can cover them with ~10^3 inducing LCEs:
+    in the randomly shuffled `oxide` every atom is its own environment (active.py:631-654 keeps every LCE whose
+    similarity to the kept ones is below 0.95) and the reference's sampling loop would never stop adding."""
+    rng = np.random.default_rng(seed)
+    if any(n % 2 for n in shape):
+        raise ValueError("even numbers of sites per direction")
+    g = np.stack(np.meshgrid(*[np.arange(n) for n in shape], indexing="ij"), -1).reshape(-1, 3)
+    par = g % 2
+    even = par.sum(1) % 2 == 0
+    key = par[:, 0] * 4 + par[:, 1] * 2 + par[:, 2]      # even sites: 0 (000), 3 (011), 5 (101), 6 (110)
+    numbers = np.full(len(g), 8, np.int32)
+    numbers[even & (key == 0)] = 40
+    numbers[even & (key == 6)] = 57
+    numbers[even & ((key == 3) | (key == 5))] = 3
+    pos = g * 2.72 + sigma * rng.normal(size=(len(g), 3))
+    return numbers, pos, np.diag([n * 2.72 for n in shape]).astype(float), np.array([True, True, True])
+
+
+class PairTeacher:
+    """Stand-in for the ab initio teacher of an on-the-fly run (a real run passes any ASE calculator: VASP, GPAW, ...):
+    phi(r) = eps [(1 - e^{-a (r - r0)})^2 - 1] (1 - (r/rc)^2)^2 summed over the pairs of the DEVICE neighbour list,
+    analytic forces and stress, ASE-calculator protocol (get_property(name, atoms))."""
+    implemented_properties = ["energy", "forces", "stress", "free_energy"]
+
+    def __init__(self, species, rc=5.0, eps=0.25, a=1.4, r0=2.8, device=0):
+        from .model import SGPRModel
+        self.rc, self.eps, self.a, self.r0 = rc, eps, a, r0
+        self.nl = SGPRModel(3, 3, 4, rc, species=species, device=device)  # used for its neighbour list only
+        self.calls, self.seconds, self.results, self._key = 0, 0.0, {}, None
+
+    def calculate(self, atoms):
+        import time
+        t0 = time.time()
+        self.calls += 1
+        pos = np.asarray(atoms.positions, float)
+        cell = np.asarray(getattr(atoms.cell, "array", atoms.cell), float)
+        N = len(pos)
+        self.nl.predict(atoms.numbers, pos, cell, atoms.pbc, beta=False)
+        ptr, j, off = self.nl.neighbors(N)
+        i = np.repeat(np.arange(N), np.diff(ptr))
+        d = pos[j] - pos[i] + off @ cell
+        r = np.linalg.norm(d, axis=1)
+        x = np.exp(-self.a * (r - self.r0))
+        m_, dm = self.eps * ((1 - x) ** 2 - 1), self.eps * 2 * (1 - x) * self.a * x
+        s = 1 - (r / self.rc) ** 2
+        phi, dphi = m_ * s * s, dm * s * s - m_ * 4 * s * r / self.rc ** 2
+        g = (dphi / r)[:, None] * d
+        F = np.stack([np.bincount(i, weights=g[:, k], minlength=N) for k in range(3)], axis=1)
+        vir = 0.5 * np.einsum("pa,pb->ab", d, g)
+        stress = (vir / abs(np.linalg.det(cell)))[[0, 1, 2, 1, 0, 0], [0, 1, 2, 2, 2, 1]]
+        self.results = dict(energy=0.5 * phi.sum(), forces=F, stress=stress, free_energy=0.5 * phi.sum())
+        self.seconds += time.time() - t0
+
+    def get_property(self, name, atoms=None):
+        key = None if atoms is None else atoms.positions.tobytes()
+        if atoms is not None and key != self._key:
+            self.calculate(atoms)
+            self._key = key
+        return self.results[name]
+
+    def close(self):
+        self.nl.close()
+
+
+FS = 0.09822694788464063  # ase.units.fs: 1 fs in A sqrt(amu/eV)
+MASS = {1: 1.008, 3: 6.94, 8: 15.999, 9: 18.998, 11: 22.99, 12: 24.305, 14: 28.085, 15: 30.974, 16: 32.06, 17: 35.45,
+        40: 91.224, 57: 138.905}
+
+
+def langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=1e-3, seed=1, vel=None):
+    """BAOAB Langevin dynamics in numpy around any calculator with the ASE surface; parameters as the reference's
+    driver (cl/md.py:31,70-74: dt = 1 fs, friction 1e-3 per ASE time unit, T = 600 K; Maxwell-Boltzmann start as
+    util/aseutil.py:11-20, or the velocities handed over).  Generator: yields (step, energy, temperature, wall seconds,
+    positions, velocities) after every step.  With ASE installed, ase.md.langevin.Langevin drives the same calculator."""
+    import time
+    from .ase_shim import Atoms, kB
+    rng = np.random.default_rng(seed)
+    N = len(numbers)
+    mass = np.array([MASS[int(z)] for z in numbers])[:, None]
+    kT = kB * temperature
+    if vel is None:
+        vel = rng.normal(size=(N, 3)) * np.sqrt(kT / mass)
+        vel -= (mass * vel).sum(0) / mass.sum()
+    vel = np.array(vel, float)
+    dt = dt_fs * FS
+    c1 = np.exp(-friction * dt)
+    c2 = np.sqrt(1 - c1 * c1)
+    pos = np.array(pos, float)
+
+    def forces(p, v):
+        at = Atoms(numbers, p, cell, pbc, velocities=v, masses=mass[:, 0])
+        at.calc = calc
+        return at.get_forces(), at.get_potential_energy()
+
+    t0 = time.time()
+    F, E = forces(pos, vel)
+    yield 0, E, float((mass * vel ** 2).sum() / (3 * N * kB)), time.time() - t0, pos, vel
+    for step in range(1, steps + 1):
+        t0 = time.time()
+        vel += 0.5 * dt * F / mass
+        pos = pos + 0.5 * dt * vel
+        vel = c1 * vel + c2 * np.sqrt(kT / mass) * rng.normal(size=(N, 3))
+        pos = pos + 0.5 * dt * vel
+        F, E = forces(pos, vel)
+        vel += 0.5 * dt * F / mass
+        yield step, E, float((mass * vel ** 2).sum() / (3 * N * kB)), time.time() - t0, pos, vel
+
+
 def inducing_from_frame(model, numbers, pos, cell, pbc, m, seed, noise=0.05):
     """m LCEs drawn species-proportionally from a frame (+ noise), using the MODEL's own device
     neighbour list (the product path; no oracle involved)."""
@@ -94,3 +205,43 @@ def inducing_from_frame(model, numbers, pos, cell, pbc, m, seed, noise=0.05):
         keep = np.linalg.norm(r, axis=1) < rc - 1e-3
         X.append(Local(int(numbers[a]), numbers[j[s]][keep], r[keep]))
     return X
+
+
+def config5_preseeded(shape=(32, 32, 16), m_seed=1000, max_inducing=1024, n_exceed=8, seed=0, device=0, temperature=600.0,
+                      friction=0.1, n_equil=250, **calc_kw):
+    """BASELINE config 5 with the model ALREADY near its size limit, in a STATIONARY state: the ordered 4-species oxide
+    (16384 atoms for the default shape) is first equilibrated at `temperature` by `n_equil` steps of Langevin MD under
+    the teacher alone; an SGPR model is pre-seeded with `m_seed` inducing LCEs drawn species-proportionally from two
+    frames of that trajectory and fitted to a third; a fourth, held out, sets the sampling threshold: ediff = the
+    `n_exceed`-th largest covloss of that frame — so that on-the-fly MD continued from there offers a handful of
+    environments per step (not none, not all: the default 2 kcal/mol is calibrated for DFT energies), reaches
+    `max_inducing` within a few update steps, and from then on every update ends in downsize(lii=True)
+    (calculator/active.py:963-969 -> regression/gppotential.py:829-832).
+    Returns (calc, teacher, (numbers, positions, cell, pbc), velocities)."""
+    from .calculator import ActiveCalculator
+    from .model import SGPRModel
+    from .posterior import Frame, PosteriorPotential
+    numbers, pos, cell, pbc = oxide_ordered(shape, seed=seed, sigma=0.05)
+    species = sorted(set(int(z) for z in numbers))
+    teacher = PairTeacher(species, device=device)
+    marks = sorted({max(1, int(n_equil * f)) for f in (0.6, 0.75, 0.9)} | {n_equil})
+    snaps = {}
+    vel = None
+    for step, E, T, wall, p, v in langevin_nvt(teacher, numbers, pos, cell, pbc, n_equil, temperature, 1.0, friction, seed=seed + 5):
+        if step in marks:
+            snaps[step] = (p.copy(), teacher.results["energy"], teacher.results["forces"].copy(), teacher.results["stress"].copy())
+        pos, vel = p, v
+    model = SGPRModel(3, 3, 4, 6.0, species=species, device=device)
+    X = []
+    for k, st in enumerate(marks[:2]):
+        X += inducing_from_frame(model, numbers, snaps[st][0], cell, pbc, m_seed // 2 + (k == 0) * (m_seed % 2), seed=seed + 21 + k, noise=0.0)
+    p3, e3, f3, s3 = snaps[marks[2]]
+    post = PosteriorPotential(model)
+    post.set_data([Frame(numbers, p3, cell, pbc, e3, f3, s3)], X)
+    post.make_munu(algo=3, noise_f=calc_kw.get("noise_f", 0.043))
+    beta = np.sort(np.asarray(model.predict(numbers, snaps[marks[3]][0], cell, pbc)["beta"]))
+    ediff = float(beta[-max(1, int(n_exceed))])
+    kw = dict(logfile=None, tape=None, pckl=None, ediff=ediff, fdiff=3 * ediff, ediff_tot=2 * ediff, max_inducing=max_inducing)
+    kw.update(calc_kw)
+    calc = ActiveCalculator(covariance=post, calculator=teacher, **kw)
+    return calc, teacher, (numbers, pos, cell, pbc), vel

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 as worded: on-the-fly inducing-set updates at the size limit inside NVT MD — 16384-atom
+4-species oxide (ordered: `autoforce_amd.workloads.oxide_ordered`), the model pre-seeded to ~1000 inducing LCEs,
+max_inducing = 1024, Langevin 600 K, 1 fs.  Every update step past the limit ends in downsize(lii=True)
+(calculator/active.py:963-969 -> regression/gppotential.py:829-832), which the library follows incrementally:
+K_mm factor per species block, kept first-stage QR through the reflectors of R1[:, idx].
+
+    python examples/md_nvt_config5.py --steps 250            # prints one line per step and a summary
+
+`run()` is also what tests/test_hip_config5.py drives.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from autoforce_amd import workloads  # noqa: E402
+
+
+def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=0.1, temperature=600.0, n_exceed=8,
+        verbose=False, stop_after_downsizes=None, min_steps=0):
+    """friction: per ASE time unit.  The reference CLI's default, 1e-3 (cl/md.py:31), is a 10-ps coupling: invisible
+    in a few hundred fs.  The default here (0.1: 0.1 ps) lets a short run show whether the thermostat HOLDS the
+    temperature while the model is edited under it."""
+    t_setup = time.time()
+    calc, teacher, (numbers, pos, cell, pbc), vel = workloads.config5_preseeded(shape, m_seed, max_inducing, n_exceed,
+                                                                                temperature=temperature, friction=friction)
+    np.random.seed(1)
+    model = calc.model
+    stats = dict(downsizes=0, downsize_ms=[], routes=[])
+    inner = model.downsize
+
+    def counted(*a, **k):
+        t0 = time.time()
+        ch1, ch2 = inner(*a, **k)
+        if ch2:
+            stats["downsizes"] += 1
+            stats["downsize_ms"].append(1e3 * (time.time() - t0))
+            stats["routes"].append(model.engine.solve_info())  # of the refit that ends the downsize
+        return ch1, ch2
+
+    model.downsize = counted
+    setup_s = time.time() - t_setup
+    rows = []
+    last = None
+    for step, E, T, wall, p, v in workloads.langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature, 1.0, friction, vel=vel):
+        rows.append(dict(step=step, E=E, T=T, wall=wall, size=calc.size, updated=bool(calc.updated), covloss=calc.covlog,
+                         teacher_s=teacher.seconds, downsizes=stats["downsizes"], info=model.engine.solve_info()))
+        if len(rows) > 1:
+            rows[-1]["teacher_ms"] = 1e3 * (rows[-1]["teacher_s"] - rows[-2]["teacher_s"])
+        else:
+            rows[-1]["teacher_ms"] = 1e3 * teacher.seconds
+        if verbose:
+            r = rows[-1]
+            print(f"{step:5d} E={E:14.6f} T={T:7.1f} covloss={str(r['covloss'])[:8]:>8s} size={r['size']} upd={int(r['updated'])} "
+                  f"wall={1e3 * wall:8.1f} ms teacher={r['teacher_ms']:7.1f} ms downsizes={r['downsizes']}  {r['info']}", flush=True)
+        last = p
+        if stop_after_downsizes and stats["downsizes"] >= stop_after_downsizes and step >= min_steps:
+            break
+    return dict(calc=calc, teacher=teacher, system=(numbers, last, cell, pbc), rows=rows, stats=stats, setup_s=setup_s)
+
+
+def verify(res, tol_choli=1e-9, tol_fit=1e-7):
+    """The edited model against the same model set up and factored from scratch on the device: K_mm bit for bit,
+    choli, and the fit (K mu) of the same targets at the same noise."""
+    model = res["calc"].model
+    eng = model.engine
+    ref = eng.scratch()
+    ref.set_inducing(eng.X)
+    out = {}
+    out["kmm_equal"] = bool(np.array_equal(eng.M, ref.M))
+    for fr in model.data:
+        ref.data_push(*fr.system(), fr.nv)
+    Y = model._store_targets()
+    noise = 1.0 / (1.0 + np.exp(-model._noise["all"]))
+    mu_ref = ref.data_solve(Y, with_energies=True, noise=noise)
+    mu_now = eng.data_solve(Y, with_energies=True, noise=noise)
+    out["route"] = eng.solve_info()
+    c0, c1 = ref.choli, eng.choli
+    out["choli_err"] = float(np.abs(c0 - c1).max() / np.abs(c0).max())
+    p0, p1 = ref.data_matvec(mu_ref), eng.data_matvec(mu_now)
+    out["fit_err"] = float(np.abs(p0 - p1).max() / np.abs(p0).max())
+    out["ridge"] = (ref.ridge, eng.ridge)
+    ref.close()
+    assert out["kmm_equal"], "K_mm differs from a rebuild"
+    assert out["choli_err"] <= tol_choli, out
+    assert out["fit_err"] <= tol_fit, out
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=250)
+    ap.add_argument("--side", type=int, nargs=3, default=[32, 32, 16])
+    ap.add_argument("--m-seed", type=int, default=1000)
+    ap.add_argument("--max-inducing", type=int, default=1024)
+    ap.add_argument("--friction", type=float, default=0.1)
+    ap.add_argument("--n-exceed", type=int, default=8, help="ediff = the n-th largest covloss of a held-out equilibrated frame")
+    args = ap.parse_args()
+    t0 = time.time()
+    res = run(args.steps, tuple(args.side), args.m_seed, args.max_inducing, args.friction, n_exceed=args.n_exceed, verbose=True)
+    rows = res["rows"]
+    upd = [1e3 * r["wall"] - r["teacher_ms"] for r in rows[1:] if r["updated"]]
+    capped = [1e3 * r["wall"] - r["teacher_ms"] for r in rows[1:] if r["updated"] and r["size"][1] >= args.max_inducing]
+    quiet = [1e3 * r["wall"] for r in rows[1:] if not r["updated"]]
+    print(f"# set-up {res['setup_s']:.1f} s, {len(rows) - 1} steps in {time.time() - t0 - res['setup_s']:.1f} s; final size {res['calc'].size}; "
+          f"downsizes {res['stats']['downsizes']} (median {np.median(res['stats']['downsize_ms'] or [0]):.1f} ms each)")
+    if upd:
+        print(f"# model-update steps: {len(upd)}, median {np.median(upd):.1f} ms excluding the teacher; at m = max_inducing: "
+              f"{len(capped)} steps, median {np.median(capped or [0]):.1f} ms")
+    if quiet:
+        print(f"# prediction-only steps: {len(quiet)}, median {np.median(quiet):.2f} ms")
+    T = np.array([r["T"] for r in rows])
+    print(f"# temperature over the last 100 steps: mean {T[-100:].mean():.1f} K, min {T[-100:].min():.1f}, max {T[-100:].max():.1f}")
+    print("# against a from-scratch model:", verify(res))
+
+
+if __name__ == "__main__":
+    main()

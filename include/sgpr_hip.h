@@ -187,13 +187,23 @@ int sgpr_data_get(sgpr_model *h, double *K);
 int sgpr_data_solve(sgpr_model *h, const double *Y, int with_energies, double noise, double *mu_out,
                     double *choli_out, double *ridge_out, double *sigma_out);
 int sgpr_data_factor(sgpr_model *h, const double *Y, int with_energies);
+/* Diagnostics of the last sgpr_data_solve / sgpr_data_factor: which route the first stage took ("full factorisation",
+ * "columns appended / popped through the kept reflectors", "kept", "rows of the new frame appended to the kept
+ * factor", "found in the cache", "from scratch") and how many species blocks of K_mm were factored, as text
+ * ("stage1=...; kmm_blocks=a/b").  The reference always refits from scratch (gppotential.py:548-605); tests use this
+ * to assert that an edit (append, pop, select / downsize) was followed incrementally. */
+int sgpr_solve_info(sgpr_model *h, char *buf, int cap);
 
 /*
  * Inducing-set edits (PosteriorPotential.add_inducing / pop_1inducing / popfirst_1inducing /
  * select_inducing, gppotential.py:745-842, :1037-1046).  The caller's order is kept: a new LCE is
  * appended as index m; `remove` deletes one index (-1 = last); `select` keeps `indices` in the
- * given order.  K_mm and the descriptors are rebuilt on the device; weights are invalidated
- * (call sgpr_solve / sgpr_set_weights next, as the reference calls make_munu).
+ * given order (downsize(lii=True), gppotential.py:829-832, selects the max_inducing LCEs with the smallest K_mm
+ * row sums in argsort order).  All three are incremental on the device: descriptors, K_mm and the resident design
+ * matrix are re-indexed (one new row / column for an appended LCE), the cached K_mm factor is bordered (append),
+ * trimmed (pop) or re-factored per species block (select), and the kept first-stage QR of [K | Y] follows
+ * through its reflectors; weights are invalidated (call sgpr_solve / sgpr_data_solve / sgpr_set_weights next, as
+ * the reference calls make_munu).
  */
 int sgpr_add_inducing(sgpr_model *h, int32_t zc, int nn, const int32_t *nbr_z, const double *nbr_r);
 int sgpr_remove_inducing(sgpr_model *h, int index);

@@ -458,3 +458,78 @@ def test_fit_statistics_on_the_device():
     np.testing.assert_allclose(st, want, rtol=1e-12, atol=1e-10)
     np.testing.assert_array_equal(mdl.M_diag, np.diag(mdl.M))
     mdl.close()
+
+
+def test_downsize_follows_incrementally():
+    """downsize(lii=True) / popfirst / removal at an index (gppotential.py:815-842, :1037-1046; the reference refits
+    from scratch after each).  The library re-indexes what survives: K_mm bit for bit, the K_mm factor per species
+    block (only the blocks whose order changed are factored again), the kept first-stage QR through the reflectors
+    of R1[:, idx] — and the fit after every edit equals the fit of a model set up and factored from scratch."""
+    g = load("g5_mixed64")
+    mdl = model_from_fixture(g)
+    pool = list(mdl.X)
+    rng = np.random.default_rng(31)
+    # a larger pool: rattled copies, so that every species block has a dozen LCEs
+    X = [x.__class__(x.number, x._b, x._r + 0.03 * rng.normal(size=x._r.shape)) for x in pool for _ in range(2)]
+    X = X[:44]
+    frames = systems()
+    mdl.set_inducing(X)
+    for fr in frames:
+        mdl.data_push(*fr, 6)
+    K_rows = mdl.data_info()[1]
+    Y = rng.normal(size=K_rows)
+
+    def check(route=None, blocks=None):
+        got = mdl.data_solve(Y, noise=0.02).copy()
+        info = mdl.solve_info()
+        if route is not None:
+            assert route in info, info
+        if blocks is not None:
+            assert f"kmm_blocks={blocks}/" in info, info
+        ref = mdl.scratch()
+        ref.set_inducing(mdl.X)
+        np.testing.assert_array_equal(mdl.M, ref.M)
+        K = np.concatenate([np.concatenate([ke[None], kf, kv]) for fr in frames for ke, kf, kv in [ref.kernel_rows(*fr)]])
+        np.testing.assert_array_equal(mdl.data_get(), K)
+        want = ref.solve(K, Y, noise=0.02)
+        assert ref.ridge == mdl.ridge == 0.0
+        np.testing.assert_allclose(mdl.choli, ref.choli, rtol=0, atol=1e-10 * np.abs(ref.choli).max())
+        scale = np.abs(K @ want).max()
+        assert np.abs(K @ got - K @ want).max() <= 1e-8 * scale, np.abs(K @ got - K @ want).max() / scale
+        ref.close()
+        return got
+
+    check(route="full factorisation")
+    nblocks = len(set(x.number for x in mdl.X))
+    # 1. an LCE in the middle of the list goes: one block is factored again, the QR follows through the selection
+    victim = 7
+    mdl.remove_inducing(victim)
+    assert len(mdl.X) == 43
+    check(route="columns selected through the kept reflectors", blocks=1)
+    # 2. the first of the list (popfirst_1inducing)
+    mdl.remove_inducing(0)
+    check(route="columns selected through the kept reflectors", blocks=1)
+    # 3. downsize(lii=True): the 36 LCEs with the smallest K_mm row sums, IN ARGSORT ORDER (a permutation)
+    order = np.argsort(mdl.M.sum(axis=1), kind="stable").tolist()[:36]
+    mdl.select_inducing(order)
+    check(route="columns selected through the kept reflectors")
+    # 4. trials on top of the selection: append, refit, pop, refit (the pop restores the pre-trial fit bit for bit)
+    mu0 = check()
+    mdl.add_inducing(X[3].__class__(X[3].number, X[3]._b, X[3]._r + 0.01))
+    check(route="columns appended / popped through the kept reflectors", blocks=0)
+    mdl.remove_inducing(-1)
+    np.testing.assert_array_equal(check(route="columns appended / popped through the kept reflectors", blocks=0), mu0)
+    # 5. a trailing LCE of a block goes: that block keeps its factor (a leading part of L is the factor of the
+    #    leading part)
+    last_of_block = max(i for i, x in enumerate(mdl.X) if x.number == mdl.X[-1].number)
+    mdl.remove_inducing(last_of_block)
+    check(blocks=0)
+    # 6. several selections in a row, then appended columns again, against the from-scratch path of the library itself
+    for _ in range(3):
+        keep = sorted(rng.permutation(len(mdl.X))[:len(mdl.X) - 2].tolist())
+        mdl.select_inducing(keep)
+        check(route="columns selected through the kept reflectors")
+        mdl.add_inducing(X[40].__class__(X[40].number, X[40]._b, X[40]._r + 0.02 * rng.normal(size=X[40]._r.shape)))
+        check(route="columns appended / popped through the kept reflectors")
+    assert nblocks >= 2
+    mdl.close()
