@@ -177,9 +177,35 @@ class ActiveCalculator(Calculator):
         rank, world = self._dist()
         if world < 2:
             return
-        box = [eng.comm_unique_id() if rank == 0 else None]
+        # every rank takes the same branch: the outcome is agreed on (MIN over ranks) before anybody evaluates.  A rank
+        # that cannot build the communicator (RCCL missing; two ranks on one device — RCCL refuses duplicate GPUs)
+        # must not leave the others inside ncclCommInitRank: the id travels first, the attempt is made by all, and on
+        # any failure all fall back to the host-side all-reduce of `_evaluate_engine`.
+        import torch
+        ok = 1
+        try:
+            box = [eng.comm_unique_id() if rank == 0 else None]
+        except Exception as exc:  # noqa: BLE001
+            box, ok = [None], 0
+            self.log(f"native communicator unavailable on rank 0: {exc}")
         dist.broadcast_object_list(box, src=dist.get_global_rank(self.process_group, 0), group=self.process_group)
-        eng.comm_init(box[0], rank, world)
+        if box[0] is None:
+            ok = 0
+        else:
+            try:
+                from .watchdog import Watchdog
+                with Watchdog("sgpr_comm_init (ncclCommInitRank)", rank=rank):
+                    eng.comm_init(box[0], rank, world)
+            except Exception as exc:  # noqa: BLE001
+                ok = 0
+                if rank == 0:
+                    self.log(f"native communicator not built ({exc}): host-side all-reduce instead")
+        flag = torch.tensor([ok])
+        if dist.get_backend(self.process_group) == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
+        if int(flag.item()) == 0 and getattr(eng, "comm_world", 1) > 1:
+            eng.comm_destroy()
 
     @property
     def engine(self):
@@ -633,7 +659,10 @@ class ActiveCalculator(Calculator):
             self.log("added data: {} -> size: {} {}".format(1, *self.size))
             n = 1
         if m > 0 or n > 0:
-            ch1, ch2 = self.model.downsize(self.max_data, self.max_inducing, first=True, lii=True)
+            # (ioptim == 1: optimize() below refits the downsized model from the same matrix — hyper-parameter search
+            # and weights — so the refit downsize would end with is the one result nobody reads)
+            ch1, ch2 = self.model.downsize(self.max_data, self.max_inducing, first=True, lii=True,
+                                           remake=self.ioptim != 1)
             if ch1 or ch2:
                 self.log("downsized -> size: {} {}".format(*self.size))
             if self.ioptim == 1:

@@ -1652,8 +1652,10 @@ extern "C" int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const d
         return reduce_packed(h, packed_dev, st);
     }
     if (!h->use_graph || h->profile) {
-        const int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
-        return rc_ ? rc_ : reduce_packed(h, packed_dev, st);
+        int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st);
+        if (!rc_) rc_ = reduce_packed(h, packed_dev, st);
+        if (!rc_ && h->comm && h->world > 1) stamp(h, "allreduce", st);  // (profiling: the collective as its own stage)
+        return rc_;
     }
     if (!h->gexec || h->g_pos != positions_dev || h->g_cell != cell_dev || h->g_out != packed_dev || h->g_stream != st) {
         drop_graph(h);

@@ -39,6 +39,24 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6  # BASELINE.md §4 (MI355X FP64 matrix peak)
 
 
+def csrc_sha():
+    """Hash of the kernel sources: a committed PMC summary is only quoted while it describes THESE kernels."""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "autoforce_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "autoforce_amd", "csrc", "*.inc")) +
+                    glob.glob(os.path.join(ROOT, "autoforce_amd", "csrc", "*.h"))):
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def latest_profile(pattern):
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return c[-1] if c else None
+
+
 def build_model(device, numbers, pos, cell, pbc, m, workload_seed=1):
     from autoforce_amd import SGPRModel
     from autoforce_amd.workloads import inducing_from_frame, lips
@@ -90,6 +108,52 @@ def algorithmic_flops(atom_z, ind_z, Dpad, world=1):
     return {"gemm_knm": knm, "gemm_w_covloss": w + cov}
 
 
+def calculate_wall_big(device, sigma):
+    """BASELINE configs[4] size through the drop-in surface: 16384-atom 4-species oxide, 1024 inducing LCEs — the
+    calculate() wall (numpy in, numpy out, synchronised) next to the device time of the same step."""
+    import torch
+    from autoforce_amd import SGPRModel, _lib
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.workloads import inducing_from_frame, oxide
+    numbers, pos, cell, pbc = oxide(seed=0)
+    species = sorted(set(int(z) for z in numbers))
+    mdl = SGPRModel(3, 3, 4, 6.0, species=species, device=device)
+    n2, p2, c2, b2 = oxide(seed=1)
+    mdl.set_inducing(inducing_from_frame(mdl, n2, p2, c2, b2, 1024, seed=1))
+    rng = np.random.default_rng(2)
+    mdl.solve(rng.normal(size=(64, 1024)), rng.normal(size=64))
+    mdl.set_weights(rng.normal(size=1024), choli=mdl.choli, vscale=mdl.make_vscale())
+    calc = ActiveCalculator(covariance=mdl, logfile=None)
+    atoms = Atoms(numbers, pos.copy(), cell, pbc)
+    atoms.calc = calc
+    walls = []
+    for it in range(35):
+        atoms.positions = atoms.positions + sigma * rng.normal(size=pos.shape)
+        tc = time.perf_counter()
+        atoms.get_forces()
+        walls.append(time.perf_counter() - tc)
+    w = float(np.median(walls[5:]))
+    # the same step device-resident: K steps enqueued back to back
+    lib, h, N = _lib.load(), mdl.handle, len(numbers)
+    dev = torch.device("cuda", device)
+    pos_d = torch.from_numpy(atoms.positions).to(dev)
+    cell_d = torch.from_numpy(cell).to(dev)
+    packed = torch.zeros(int(lib.sgpr_packed_len(N)), dtype=torch.float64, device=dev)
+    sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(3):
+        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(30):
+        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+    torch.cuda.synchronize(dev)
+    dstep = (time.perf_counter() - t0) / 30
+    mdl.close()
+    return {"median_ms": w * 1e3, "atom_steps_per_s": N / w, "device_step_ms": dstep * 1e3, "wall_over_device": w / dstep,
+            "atoms": N, "inducing": 1024, "calls": len(walls) - 5}
+
+
 def cpu_baseline(numbers, pos, cell, pbc, mdl, mu, sample_atoms, min_seconds=12.0):
     """Times the CPU oracle (C/OpenMP restatement of the reference path, pinned by the golden
     vectors) on a bounded sample of the SAME frame: descriptors + K_nm + reverse pass + covloss for
@@ -131,6 +195,7 @@ def main():
     ap.add_argument("--skin", type=float, default=0.5, help="Verlet skin of the neighbour candidates, A (0 = rebuild every step)")
     ap.add_argument("--overlap", type=int, default=0, help="1: covloss GEMM on a side stream next to the reverse pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-big-wall", action="store_true", help="skip the calculate() wall time of the 16384-atom / 1024 frame")
     ap.add_argument("--collective", default="native", choices=["native", "torch"],
                     help="native: the library's own RCCL all-reduce on the step's stream (default); torch: "
                          "torch.distributed all_reduce of the packed buffer (dry runs of several ranks on one GPU)")
@@ -152,8 +217,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (libsgpr_hip has no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()  # dry runs may put several ranks on one GPU (gloo only)
     torch.cuda.set_device(local_rank)
+    from autoforce_amd.watchdog import Watchdog
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own diagnostics of a failed start-up reach stderr
         # CPU-side group: carries the communicator id at start-up and the barriers / max around the timed
         # region; the step's collective is the library's own (RCCL over xGMI)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -193,7 +260,10 @@ def main():
         try:
             box = [mdl.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            mdl.comm_init(box[0], rank, world)  # collective: ncclCommInitRank on every rank
+            # a rank that dies before it gets here would leave the others inside ncclCommInitRank for ever: the
+            # watchdog names the stuck rank and ends the process with exit code 3 (never a re-exec)
+            with Watchdog("sgpr_comm_init (ncclCommInitRank)", seconds=180, rank=rank):
+                mdl.comm_init(box[0], rank, world)  # collective: ncclCommInitRank on every rank
         except Exception as exc:  # noqa: BLE001 - report and fall back rather than lose the measurement
             print(f"[bench] rank {rank}: native RCCL communicator failed ({exc}); host-staged all-reduce instead",
                   file=sys.stderr, flush=True)
@@ -218,9 +288,10 @@ def main():
             dist.all_reduce(t)
             packed.copy_(t)
 
-    for _ in range(max(args.warmup, 2)):
-        step()
-    _lib.check(lib.sgpr_sync_check(h, sp))
+    with Watchdog("warm-up steps (the first collective of every rank)", seconds=300, rank=rank):
+        for _ in range(max(args.warmup, 2)):
+            step()
+        _lib.check(lib.sgpr_sync_check(h, sp))
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -231,11 +302,12 @@ def main():
     fence()
     rb0 = C.c_int64(0)
     _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb0)))
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    with Watchdog("timed steps", seconds=600, rank=rank):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
     rb1 = C.c_int64(0)
     _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb1)))
     _lib.check(lib.sgpr_sync_check(h, sp))
@@ -270,9 +342,31 @@ def main():
     overhead_ms = max((sum(stage_ms.values()) - t_plain_ms) / max(len(stage_ms), 1), 0.0)
     stage_ms = {k: max(v - overhead_ms, 0.0) for k, v in stage_ms.items()}
     dims = mdl.dims
+    # N > 1: every rank's own stage times (a curve can only be read if one sees whose share is the long one) and the
+    # collective alone: the packed buffer all-reduced back to back, hip events on the step's stream
+    per_rank, allreduce_us = None, None
+    if world > 1:
+        if native:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            scratch = packed.clone()
+            nar = 50
+            for _ in range(5):
+                _lib.check(lib.sgpr_comm_allreduce(h, scratch.data_ptr(), scratch.numel(), 0, sp))
+            e0.record(stream)
+            for _ in range(nar):
+                _lib.check(lib.sgpr_comm_allreduce(h, scratch.data_ptr(), scratch.numel(), 0, sp))
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            allreduce_us = e0.elapsed_time(e1) / nar * 1e3
+        mine = {"rank": rank, "local_atoms": (N - rank + world - 1) // world, "step_us": round(t_plain_ms * 1e3, 2),
+                "allreduce_us": None if allreduce_us is None else round(allreduce_us, 2),
+                **{k + "_us": round(v * 1e3, 2) for k, v in stage_ms.items()}}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     # PCIe-inclusive rate of the host-array entry point (never `value`): numpy in, numpy out
     host_rate = None
     calc_wall = None
+    calc_wall_big = None
     if world == 1:
         mdl.predict(numbers, pos, cell, pbc, beta=True)
         th = time.perf_counter()
@@ -298,7 +392,10 @@ def main():
             walls.append(time.perf_counter() - tc)
         w = float(np.median(walls[5:]))
         calc_wall = {"median_ms": w * 1e3, "atom_steps_per_s": N / w, "calls": len(walls) - 5,
+                     "device_step_ms": t_plain_ms, "wall_over_device": w * 1e3 / t_plain_ms,
                      "what": "ActiveCalculator.calculate() wall, numpy in / numpy out, one synchronised call per step"}
+        if not args.no_big_wall:
+            calc_wall_big = calculate_wall_big(local_rank, args.walk_sigma or 1e-3)
 
     result = None
     if rank == 0:
@@ -315,11 +412,18 @@ def main():
         # is a separate pass); the committed summary of the builder's own pass over this command is quoted
         # with its source, or null
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_lips{N}_m{m}.json")
-        if world == 1 and os.path.exists(tpath):
+        sha = csrc_sha()
+        tpath = latest_profile(f"r*_pmc_traffic_lips{N}_m{m}.json")
+        pmc = None
+        if world == 1 and tpath:
             tj = json.load(open(tpath))
-            traffic = tj["kernels"].get(dom, {}).get("fetch_x2_plus_write")
-            traffic_source = f"profiles/{os.path.basename(tpath)} ({tj.get('source', 'builder run')})"
+            if tj.get("csrc_sha") == sha:
+                pmc = tj
+                traffic = tj["kernels"].get(dom, {}).get("fetch_x2_plus_write")
+                traffic_source = f"profiles/{os.path.basename(tpath)} ({tj.get('source', 'builder run')}; same kernel sources: csrc sha {sha})"
+            else:
+                traffic_source = (f"null: profiles/{os.path.basename(tpath)} was collected on other kernel sources "
+                                  f"(csrc sha {tj.get('csrc_sha')} then, {sha} now)")
         af = algorithmic_flops(numbers, [x.number for x in mdl.X], dims["Dpad"], world)
         if dom in af:  # a GEMM leads: price it against the dense fp64 MFMA peak
             head = {"bound": "mfma", "achieved": af[dom] / dom_s / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -336,6 +440,20 @@ def main():
             "avg_launch_us": stage_ms[dom] * 1e3,
             "timing": f"hip events on the launch stream, {nprof} eager steps after the timed region, minus the "
                       f"per-stage marker overhead ({overhead_ms * 1e3:.2f} us = (sum of intervals - marker-free step time) / stages)",
+            # scalar keys (a parser that drops nested objects keeps these): per-kernel time, the descriptor kernels
+            # against the HBM roofline with their algorithmic bytes, the GEMMs against the fp64 MFMA peak
+            **{k + "_us": round(v * 1e3, 2) for k, v in stage_ms.items()},
+            "desc_fwd_GBs": round(ab["list_forward"] / (stage_ms["list_forward"] * 1e-3) / 1e9, 1) if stage_ms.get("list_forward") else None,
+            "desc_rev_GBs": round(ab["descriptor_rev"] / (stage_ms["descriptor_rev"] * 1e-3) / 1e9, 1) if stage_ms.get("descriptor_rev") else None,
+            "desc_hbm_frac": round((ab["list_forward"] + ab["descriptor_rev"]) /
+                                   ((stage_ms.get("list_forward", 0) + stage_ms.get("descriptor_rev", 0)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if stage_ms.get("list_forward") and stage_ms.get("descriptor_rev") else None,
+            "desc_valu_frac": (pmc or {}).get("desc_valu_frac"),
+            "desc_valu_note": (pmc or {}).get("desc_valu_note"),
+            "knm_TFs": round(af["gemm_knm"] / (stage_ms["gemm_knm"] * 1e-3) / 1e12, 2) if stage_ms.get("gemm_knm") else None,
+            "wcov_TFs": round(af["gemm_w_covloss"] / (stage_ms["gemm_w_covloss"] * 1e-3) / 1e12, 2) if stage_ms.get("gemm_w_covloss") else None,
+            "knm_frac": round(af["gemm_knm"] / (stage_ms["gemm_knm"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4) if stage_ms.get("gemm_knm") else None,
+            "wcov_frac": round(af["gemm_w_covloss"] / (stage_ms["gemm_w_covloss"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4) if stage_ms.get("gemm_w_covloss") else None,
             "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
             "gemm_TFLOPs": {k: round(af[k] / (stage_ms[k] * 1e-3) / 1e12, 2) for k in af if stage_ms.get(k)},
             "hbm_GBs": {k: round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) for k in ab if stage_ms.get(k)},
@@ -370,7 +488,11 @@ def main():
                                f"({'issued by libsgpr_hip on the step stream' if native else 'torch.distributed, host staged' if world > 1 else 'single rank: none'})",
             },
             "roofline": roof,
+            "per_rank": per_rank,
+            "allreduce_us": allreduce_us,
             "calculate_wall": calc_wall,
+            "calculate_wall_ms": None if calc_wall is None else calc_wall["median_ms"],
+            "calculate_wall_16384": calc_wall_big,
             "energy": float(out_host[4 * N]),
             "max_force": float(np.abs(out_host[:3 * N]).max()),
         }

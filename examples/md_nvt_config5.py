@@ -31,8 +31,8 @@ def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=
                                                                                 temperature=temperature, friction=friction)
     np.random.seed(1)
     model = calc.model
-    stats = dict(downsizes=0, downsize_ms=[], routes=[])
-    inner = model.downsize
+    stats = dict(downsizes=0, downsize_ms=[], routes=[], pending=False)
+    inner, inner_munu = model.downsize, model.make_munu
 
     def counted(*a, **k):
         t0 = time.time()
@@ -40,10 +40,17 @@ def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=
         if ch2:
             stats["downsizes"] += 1
             stats["downsize_ms"].append(1e3 * (time.time() - t0))
-            stats["routes"].append(model.engine.solve_info())  # of the refit that ends the downsize
+            stats["pending"] = True
         return ch1, ch2
 
-    model.downsize = counted
+    def munu(*a, **k):
+        out = inner_munu(*a, **k)
+        if stats["pending"]:  # the refit that follows a downsize: which route did its first stage take?
+            stats["routes"].append(model.engine.solve_info())
+            stats["pending"] = False
+        return out
+
+    model.downsize, model.make_munu = counted, munu
     setup_s = time.time() - t_setup
     rows = []
     last = None

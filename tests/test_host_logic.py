@@ -150,3 +150,17 @@ def test_calculator_world2_gloo(name, tmp_path):
     # only rank 0 writes the log
     lines = open(tmp_path / "active.log").read().strip().splitlines()
     assert len(lines) == 5  # hello, kernel, settings, model size, one step
+
+
+def test_watchdog_ends_a_stuck_rank():
+    """autoforce_amd.watchdog: a rank blocked inside a collective set-up is reported and ended with exit code 3 (never a
+    re-exec); a call that returns in time is left alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); from autoforce_amd.watchdog import Watchdog\n"
+            "with Watchdog('quick', seconds=5, rank=1):\n    pass\n"
+            "with Watchdog('ncclCommInitRank', seconds=0.3, rank=1):\n    time.sleep(20)\n") % root
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3
+    assert "rank 1" in p.stderr and "ncclCommInitRank" in p.stderr

@@ -25,8 +25,19 @@ def medians(path, counter):
     return {k: st.median(v) for k, v in acc.items() if len(v) >= 10}
 
 
+def csrc_sha():
+    import glob, hashlib, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "autoforce_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "autoforce_amd", "csrc", "*.inc")) +
+                    glob.glob(os.path.join(root, "autoforce_amd", "csrc", "*.h"))):
+        hsh.update(open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 fetch, write = medians(sys.argv[1], "FETCH_SIZE"), medians(sys.argv[2], "WRITE_SIZE")
 out = {
+    "csrc_sha": csrc_sha(),  # bench.py quotes this summary only while the kernel sources are the ones it was made on
     "workload": "LiPS 4096 atoms / 512 inducing, 1 GPU",
     "source": sys.argv[4] if len(sys.argv) > 4 else "builder run",
     "unit": "bytes per launch",
