@@ -41,11 +41,14 @@ from .sharding import pack_partial, rank_of_atoms, unpack_total
 inf = float("inf")
 
 
-def default_kernel(lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, device=0):
-    """theforce/calculator/active.py:28-38: SeSoapKernel(lmax,nmax,exponent,cutoff,
-    radii=DefaultRadii()).  `species` is the table of atomic numbers the model may meet (the
-    reference's wildcard kernel indexes a fixed 120-wide table; the device layout is dense)."""
-    return SGPRModel(lmax, nmax, exponent, cutoff, species=species, device=device)
+def default_kernel(lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, device=0, wildcard=False):
+    """theforce/calculator/active.py:28-38.  Without `species`: the wildcard SeSoapKernel(lmax, nmax, exponent, cutoff,
+    radii=DefaultRadii()) — the reference indexes a fixed 120-wide table, the device layout is dense over the species
+    met so far (`wildcard=True` with the current table).  With `species`: the reference builds ONE SubSeSoapKernel per
+    listed species and sums them; the only place where that differs from one kernel over the same table is the
+    lone-atom term, added once per kernel object (SGPRModel's `lone_weight`)."""
+    return SGPRModel(lmax, nmax, exponent, cutoff, species=species, device=device,
+                     lone_weight=1 if wildcard or not species else len(species))
 
 
 class Switch:
@@ -108,6 +111,7 @@ class ActiveCalculator(Calculator):
         self.logfile, self.stdout, self._logpref = logfile, stdout, ""
         self.step = 0
         self._wildcard = False
+        self._comm_note, self._hello = "", False
         self.get_model(engine if engine is not None else covariance, kernel_kw or {})
         self.ediff = ediff
         self.ediff_lb = ediff_lb or ediff
@@ -117,6 +121,9 @@ class ActiveCalculator(Calculator):
         self.max_data, self.max_inducing = max_data, max_inducing
         self.meta = meta
         self.log("active calculator says Hello!", mode="w")
+        self._hello = True
+        if self._comm_note:
+            self.log(self._comm_note)
         self.log_settings()
         self.log("model size: {} {}".format(*self.size))
         self.tape = None if tape is None else SgprIO(tape, rank=self.rank)
@@ -158,6 +165,7 @@ class ActiveCalculator(Calculator):
                     # starts with the first frame's species and grows when a new one turns up (_ensure_species)
                     self._wildcard = True
                     kw["species"] = [0]  # placeholder, replaced before the first evaluation
+                    kw["wildcard"] = True
                 model = default_kernel(**kw)
         if not isinstance(model, PosteriorPotential):
             model = PosteriorPotential(model)
@@ -187,7 +195,7 @@ class ActiveCalculator(Calculator):
             box = [eng.comm_unique_id() if rank == 0 else None]
         except Exception as exc:  # noqa: BLE001
             box, ok = [None], 0
-            self.log(f"native communicator unavailable on rank 0: {exc}")
+            self._comm_note = f"native communicator unavailable on rank 0: {exc}"
         dist.broadcast_object_list(box, src=dist.get_global_rank(self.process_group, 0), group=self.process_group)
         if box[0] is None:
             ok = 0
@@ -198,14 +206,18 @@ class ActiveCalculator(Calculator):
                     eng.comm_init(box[0], rank, world)
             except Exception as exc:  # noqa: BLE001
                 ok = 0
-                if rank == 0:
-                    self.log(f"native communicator not built ({exc}): host-side all-reduce instead")
+                self._comm_note = f"native communicator not built ({exc}): host-side all-reduce instead"
         flag = torch.tensor([ok])
         if dist.get_backend(self.process_group) == "nccl":
             flag = flag.cuda()
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
-        if int(flag.item()) == 0 and getattr(eng, "comm_world", 1) > 1:
-            eng.comm_destroy()
+        if int(flag.item()) == 0:
+            if getattr(eng, "comm_world", 1) > 1:
+                eng.comm_destroy()
+            if not self._comm_note:
+                self._comm_note = "native communicator not built on another rank: host-side all-reduce instead"
+        if self._comm_note and self._hello:
+            self.log(self._comm_note)
 
     @property
     def engine(self):

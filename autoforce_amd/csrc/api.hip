@@ -138,6 +138,7 @@ struct sgpr_model {
     // neighbour list
     int maxnn = 0, nn_max_seen = 0;
     bool warm = false;  // a synchronised, capacity-checked step has run since the last bind
+    bool zero_copy_out = true;  // sgpr_compute's warm path: finalize writes the results into mapped host memory
     bool spin_wait = true;   // sgpr_compute's warm path polls the stream instead of a blocking wait (option "spin_wait"; -16 us per call)
     DevBuf<char> d_grid;
     DevBuf<int> d_bin_of, d_bin_count, d_nn, d_nbr_j, d_nbr_shift, d_stat;
@@ -249,6 +250,7 @@ struct sgpr_model {
     // per-step work arrays (local rows)
     DevBuf<double> d_Pn, d_norm, d_C, d_K, d_Aw, d_W, d_F, d_virpart, d_Epart, d_csq, d_packed;
     int csq_slots = 1;
+    double *pin_dev = nullptr; // the same buffer as the device addresses it (zero-copy results)
     double *pin = nullptr;     // page-locked staging of sgpr_compute: [3N + 9] in | [4N + 11] out
     size_t pin_doubles = 0;
     DevBuf<int> d_shear;
@@ -266,6 +268,7 @@ struct sgpr_model {
     hipStream_t g_stream = nullptr;
     bool use_graph = false;  // eager launches pipeline fine while a step is >100 us of kernels; graph replay
                              // measured 8 us/step slower (177 vs 169 us) — opt in with sgpr_set_option("graph",1)
+    double lone_w = 1.0;          // option "lone_atom_weight": k of two lone atoms of one species (GemmParams::lone_m1)
     bool ignore_unknown = false;  // option "ignore_unknown_species": atoms and LCE neighbours whose species is not in
                                   // the table are invisible (the reference's fixed-species kernels drop them
                                   // silently, descriptor/sesoap.py:343-346); default: SGPR_E_SPECIES
@@ -603,6 +606,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds, [3] always zero
     h->d_cell0.alloc(18);  // cell at the last rebuild + its inverse
     if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
@@ -816,7 +820,7 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
     g.tiles = tiles.p; g.ntiles = (int)tiles.n;
     g.bm = (&tiles == &h->t_kmm) ? 64 : h->gemm_bm_k;
     g.kd = h->gemm_kd_k;
-    g.eta = h->eta; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
+    g.eta = h->eta; g.lone_m1 = h->lone_w - 1.0; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
     g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
     launch_gemm_nt(g, EPI_KERNEL, st);
@@ -1548,8 +1552,11 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
     if (h->pin_doubles < n_in + n_out) {
         if (h->pin) (void)hipHostFree(h->pin);
         h->pin = nullptr; h->pin_doubles = 0;
-        if (hipHostMalloc((void **)&h->pin, sizeof(double) * (n_in + n_out + 64), hipHostMallocDefault) == hipSuccess)
+        if (hipHostMalloc((void **)&h->pin, sizeof(double) * (n_in + n_out + 64), hipHostMallocMapped) == hipSuccess) {
             h->pin_doubles = n_in + n_out + 64;
+            h->pin_dev = nullptr;
+            if (hipHostGetDevicePointer((void **)&h->pin_dev, h->pin, 0) != hipSuccess) h->pin_dev = nullptr;
+        }
     }
     if (h->warm && h->pin && !cov) {
         double *pi = h->pin, *po = h->pin + n_in;
@@ -1557,10 +1564,14 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         memcpy(pi + 3 * (size_t)N, cell, sizeof(double) * 9);
         // positions and cell travel as ONE copy (a second 72-byte copy is a whole DMA command of its own)
         HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
-        int rf = enqueue_step(h, h->d_pos_in.p, h->d_pos_in.p + 3 * (size_t)N, h->d_packed.p, h->stream);
+        // single rank: the last kernel writes the packed results straight into the page-locked buffer (host memory
+        // mapped into the device's address space: posted PCIe writes inside the kernel) — no device-to-host copy
+        // command behind the step, one synchronisation point less on the way out (option "zero_copy_out")
+        const bool direct = h->zero_copy_out && !h->comm && h->world == 1 && h->pin_dev;
+        int rf = enqueue_step(h, h->d_pos_in.p, h->d_pos_in.p + 3 * (size_t)N, direct ? h->pin_dev + n_in : h->d_packed.p, h->stream);
         if (!rf) rf = reduce_packed(h, h->d_packed.p, h->stream);
         if (rf) return rf;
-        HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+        if (!direct) HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
         if (h->spin_wait) {  // option "spin_wait": poll the stream instead of a blocking wait
             hipError_t q;
             while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
@@ -1713,7 +1724,14 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "spin_wait")) { h->spin_wait = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "zero_copy_out")) { h->zero_copy_out = value != 0; return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "lone_atom_weight")) {
+        if (value < 1) return fail(SGPR_E_INVALID, "sgpr_set_option: lone_atom_weight >= 1");
+        if (h->m > 0 && (double)value != h->lone_w) return fail(SGPR_E_INVALID, "sgpr_set_option: lone_atom_weight is set before the inducing set");
+        h->lone_w = (double)value;
+        return SGPR_OK;
+    }
     if (!strcmp(name, "qr_keep")) {
         if (value < 0 || value > 2) return fail(SGPR_E_INVALID, "sgpr_set_option: qr_keep is 0, 1 or 2");
         h->qr_keep_mode = value;

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, KD == 16 ? 4 : 2) void gemm_nt_kernel(GemmArgs
                         } else
                             pm1 = pow(v, p.eta - 1.0);
                         const double eta_d = g.ieta >= 1 ? (double)g.ieta : p.eta;
-                        double k = (!rl && !cl) ? pm1 * v : ((rl && cl) ? 1.0 : 0.0);  // similarity.py:94-103
+                        double k = (!rl && !cl) ? pm1 * v : ((rl && cl) ? 1.0 + p.lone_m1 : 0.0);  // similarity.py:94-103
                         const double kp = (!rl && !cl) ? eta_d * pm1 : 0.0;
                         if (same && row < p.M && col < p.N) {
                             p.C[(size_t)row * p.ldc + col] = k;

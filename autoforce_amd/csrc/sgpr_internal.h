@@ -165,6 +165,9 @@ struct GemmParams {
     int tri;              // unused by the kernel (the tile table carries the trimmed k range)
     // EPI_KERNEL extras
     double eta;
+    double lone_m1;       // value of k(lone atom, lone atom of the same species) minus one: the reference adds its lone-atom
+                          //   term (similarity/similarity.py:94-103) once PER KERNEL of the list, so the fixed-species
+                          //   kernel list of calculator/active.py:31-38 gives S there, the wildcard kernel 1
     const double *mu;     // [N]
     const int *row_nn;    // [M] neighbour counts (lone-atom term), may be null => all > 0
     const int *col_nn;    // [N]

@@ -37,10 +37,14 @@ def default_radii(species):
 
 class SGPRModel:
     def __init__(self, lmax=3, nmax=3, exponent=4, cutoff=6.0, species=None, radii=None, device=0,
-                 unknown_species="error"):
+                 unknown_species="error", lone_weight=1):
         """unknown_species: "error" (default) or "ignore" — atoms and LCE neighbours whose atomic number is
         not in `species` are invisible, as in the reference's fixed-species kernels
-        (descriptor/sesoap.py:343-346, similarity/heterosoap.py:37-71)."""
+        (descriptor/sesoap.py:343-346, similarity/heterosoap.py:37-71).
+        lone_weight: k(x, x') of two lone atoms (no neighbour inside the cutoff) of one species.  The reference adds
+        that term once per kernel OBJECT (similarity/similarity.py:38-40, :94-103) and sums the kernels
+        (regression/gppotential.py:63-84): 1 for the wildcard SeSoapKernel, len(species) for the list of fixed-species
+        kernels that `kernel_kw={'species': [...]}` builds (calculator/active.py:31-38)."""
         if species is None or len(species) == 0:
             raise ValueError("SGPRModel needs the species table (atomic numbers the model may meet)")
         self.lmax, self.nmax, self.exponent, self.cutoff = int(lmax), int(nmax), float(exponent), float(cutoff)
@@ -56,6 +60,9 @@ class SGPRModel:
             check(lib.sgpr_set_option(self._h, b"ignore_unknown_species", 1))
         elif unknown_species != "error":
             raise ValueError("unknown_species must be 'error' or 'ignore'")
+        self.lone_weight = int(lone_weight)
+        if self.lone_weight != 1:
+            check(lib.sgpr_set_option(self._h, b"lone_atom_weight", self.lone_weight))
         self.X = []
         self.mu = None
         self._choli, self._choli_on_device = None, False
@@ -120,7 +127,7 @@ class SGPRModel:
         """A second, empty model with the same kernel on the same device (used for one-off
         K(atoms, atoms) evaluations that must not disturb this model's inducing set)."""
         return SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=self.species, radii=self.radii,
-                         device=self.device, unknown_species=self.unknown_species)
+                         device=self.device, unknown_species=self.unknown_species, lone_weight=self.lone_weight)
 
     def with_species(self, species):
         """The same model over another species table (same kernel, inducing LCEs, weights): how the
@@ -133,7 +140,7 @@ class SGPRModel:
         have = {int(z): float(r) for z, r in zip(self.species, self.radii)}
         radii = [have.get(int(z), float(default_radii([z])[0])) for z in species]
         new = SGPRModel(self.lmax, self.nmax, self.exponent, self.cutoff, species=species, radii=radii,
-                        device=self.device, unknown_species=self.unknown_species)
+                        device=self.device, unknown_species=self.unknown_species, lone_weight=self.lone_weight)
         new.mean.update(self.mean)
         new._vscale = dict(self._vscale)
         if self.X:

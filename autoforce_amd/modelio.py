@@ -54,7 +54,7 @@ def save_model(path, model):
             mean_w=np.array([mean[z] for z in sorted(mean)], float),
             vscale_z=np.array(sorted(eng._vscale), np.int32),
             vscale=np.array([eng._vscale[z] for z in sorted(eng._vscale)], float),
-            ridge=eng.ridge, **extra,
+            ridge=eng.ridge, lone_weight=int(getattr(eng, "lone_weight", 1)), **extra,
         )
 
 
@@ -65,7 +65,8 @@ def load_model(path, device=0, engine=None):
     if str(g["format"]) not in ("autoforce_amd.sgpr.v1", "autoforce_amd.sgpr.v2"):
         raise ValueError(f"{path}: not an autoforce_amd model file")
     mdl = engine or SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["exponent"]), float(g["cutoff"]),
-                              species=g["species"].tolist(), radii=g["radii"], device=device)
+                              species=g["species"].tolist(), radii=g["radii"], device=device,
+                              lone_weight=int(g["lone_weight"]) if "lone_weight" in g else 1)
     ptr = g["ind_ptr"]
     X = [Local(int(z), g["ind_nbr_z"][ptr[q]:ptr[q + 1]], g["ind_nbr_r"][ptr[q]:ptr[q + 1]])
          for q, z in enumerate(g["ind_z"])]

@@ -155,3 +155,49 @@ def check_g12_bcm(make_engine):
     assert np.abs(s - want["stress"]).max() <= 1e-8 * np.abs(want["stress"]).max()
     np.testing.assert_allclose(bcm.get_covloss_total(), np.minimum(want["covloss_a"], want["covloss_live"]), rtol=0, atol=2e-6)
     assert abs(float(np.max(np.minimum(want["covloss_a"].max(), want["covloss_live"].max()))) - float(want["covloss_max"])) < 1e-12
+
+
+def check_g14_hpo(engine):
+    """tests/golden/g14_hpo.npz: the reference's OWN _regression(optimize=True, noise_f) (gppotential.py:1265-1335, scipy
+    BFGS through torch autograd) on a case whose objective (MAE_f(noise) - noise_f)^2 is not flat, against
+    PosteriorPotential.make_munu(algo=3) — a deterministic scan + bounded refinement of the same objective.
+    The root MAE_f = noise_f is the minimiser whatever search finds it; BFGS stops at gtol = 1e-5, i.e. within ~1 % of
+    it in the noise.  So: (1) the noise found here is within 5 % of the reference's and is at least as good a
+    minimiser of the reference's objective; (2) refitted AT the reference's noise the predictions agree to the level
+    the reference's fp32-tainted analytic K_f rows allow (2e-5, as g8); (3) the mean offsets agree."""
+    from autoforce_amd.model import Local
+    from autoforce_amd.posterior import Frame, PosteriorPotential, _logit, _sigmoid
+    from helpers import load
+    want, g = load("g14_hpo"), load("g5_big40")
+    ptr = g["ind_ptr"]
+    locs = [Local(int(z), g["ind_nbr_z"][ptr[q]:ptr[q + 1]], g["ind_nbr_r"][ptr[q]:ptr[q + 1]])
+            for q, z in enumerate(g["ind_z"])]
+    fr = Frame(g["numbers"], g["positions"], g["cell"], g["pbc"], float(want["energy"]), want["forces"], want["stress"])
+    p = PosteriorPotential(engine)
+    p.set_data([fr], [locs[i] for i in want["idx"]])
+    p._noise["all"] = float(want["noise_logit_start"])
+    nf = float(want["noise_f"])
+    p.make_munu(algo=3, noise_f=nf)
+    noise = _sigmoid(p._noise["all"])
+    assert abs(noise - float(want["noise"])) <= 0.05 * float(want["noise"]), (noise, float(want["noise"]))
+    assert abs(p.scaled_noise["all"] - float(want["sigma"])) <= 0.05 * float(want["sigma"])
+    pred = p.K @ p.mu
+    scale = np.abs(want["pred"]).max()
+    assert np.abs(pred - want["pred"]).max() <= 5e-3 * scale
+    for z, w in zip(want["mean_z"], want["mean_w"]):
+        assert abs(p.mean.weights[int(z)] - float(w)) <= 5e-3 * abs(float(w))
+    # the objective at both answers: the force-only fit's MAE against noise_f
+    f = fr.forces.reshape(-1)
+
+    def objective(x):
+        p._solve(with_energies=False, x=x)
+        return (np.abs(p._matvec(p.engine.mu)[1] - f).mean() - nf) ** 2
+
+    assert objective(p._noise["all"]) <= objective(float(want["noise_logit"])) + 1e-12
+    # the same noise, the same fit
+    p._noise["all"] = float(want["noise_logit"])
+    for z, w in zip(want["mean_z"], want["mean_w"]):
+        p.mean.weights[int(z)] = float(w)
+    p.make_munu(algo=2)
+    assert abs(p.scaled_noise["all"] - float(want["sigma"])) <= 1e-12 * float(want["sigma"])
+    assert np.abs(p.K @ p.mu - want["pred"]).max() <= 2e-5 * scale

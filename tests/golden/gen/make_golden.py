@@ -331,6 +331,46 @@ def g3_subsesoap():
     print("g3_subsesoap done:", names)
 
 
+
+# ----------------------------------------------------------------------------- G13 fixed-species KERNEL values
+def g13_subsesoap_kernel():
+    """K-level fixture of the `species=[...]` kernels: calculator/active.py:28-38 builds one SubSeSoapKernel per
+    central species (similarity/sesoap.py:27-43 = HeterogeneousSoapKernel with DotProd()**exponent on the SubSeSoap
+    descriptor, similarity/heterosoap.py:37-71) and regression/gppotential.py:63-84 sums them.  Environments: the g2
+    cases as LCEs with several central species, one whose neighbours include a species outside the table (dropped
+    silently, descriptor/sesoap.py:343-346), and two lone atoms (similarity/similarity.py:94-103 adds its term once
+    PER KERNEL of the list).  Output: K[i][j] = sum over the kernels of kern(loc_i, loc_j)."""
+    from theforce.similarity.sesoap import SubSeSoapKernel
+    g2 = np.load(os.path.join(OUT, "g2_sesoap.npz"))
+    table = [3, 15, 16]
+    kerns = [SubSeSoapKernel(3, 3, 4, 6.0, z, table, radii=DefaultRadii()) for z in table]
+    efk = EnergyForceKernel(kerns)
+    envs = []
+    for case, zc in (("s3", 3), ("s3", 15), ("s3", 16), ("s3_nearz", 16), ("s1", 3), ("s3_nearz", 3)):
+        r, z = g2[case + "_r"], g2[case + "_z"].astype(np.int64)
+        envs.append((zc, z, r))
+    rng = np.random.default_rng(1313)
+    r, z = g2["s3_r"] + 0.05 * rng.normal(size=g2["s3_r"].shape), g2["s3_z"].astype(np.int64).copy()
+    z[::7] = 8                                     # oxygen neighbours: not in the table
+    envs.append((15, z, r))
+    envs.append((3, np.zeros(0, np.int64), np.zeros((0, 3))))   # lone atoms
+    envs.append((3, np.zeros(0, np.int64), np.zeros((0, 3))))
+    envs.append((16, np.zeros(0, np.int64), np.zeros((0, 3))))
+    locs = []
+    for k, (zc, z, r) in enumerate(envs):
+        n = len(z)
+        loc = Local(0, np.arange(1, n + 1), zc, z, torch.tensor(r).reshape(n, 3), None, efk.kernels, dont_save_grads=True)
+        loc.natoms = n + 1
+        locs.append(loc)
+    K = efk(locs, locs).detach().numpy()
+    out = dict(table=np.array(table, np.int32), lmax=3, nmax=3, eta=4.0, rc=6.0, K=K, n_env=len(envs),
+               zc=np.array([e[0] for e in envs], np.int32),
+               ptr=np.concatenate([[0], np.cumsum([len(e[1]) for e in envs])]).astype(np.int64),
+               nbr_z=np.concatenate([e[1] for e in envs]).astype(np.int32),
+               nbr_r=np.concatenate([e[2].reshape(-1, 3) for e in envs]))
+    np.savez_compressed(os.path.join(OUT, "g13_subsesoap_kernel.npz"), **out)
+    print("g13_subsesoap_kernel done:", K.shape, "lone-atom block:\n", K[-3:, -3:])
+
 # ----------------------------------------------------------------------------- KAT
 def kat_absseries():
     """descriptor/soap.py:488-525: inputs and the target tensor, plus what the reference
@@ -718,6 +758,86 @@ def g8_edits(name="g5_big40"):
 
 
 
+
+# ----------------------------------------------------------------------------- G14 hyper-parameter search
+def g14_hpo(name="g5_big40"):
+    """_regression(optimize=True, noise_f=...) of the reference itself (gppotential.py:1265-1335: scipy BFGS through
+    torch autograd on (MAE_f(noise) - noise_f)^2, then on the mean weights) on a case where the objective is NOT
+    flat: forces that the model fits to a MAE between 0.044 (small noise) and 0.078 (noise -> 1), noise_f = 0.06 in
+    between — the minimiser is the root MAE_f = noise_f, whatever the search that finds it."""
+    g = np.load(os.path.join(OUT, name + ".npz"))
+    kern, efk = make_kernel(int(g["lmax"]), int(g["nmax"]), int(g["eta"]), float(g["rc"]))
+    locs, X = _ref_locals(g, efk)
+    N, numbers = len(g["numbers"]), g["numbers"]
+    idx = list(range(10))
+    Xs = [X[i] for i in idx]
+    m = len(Xs)
+    M = efk(Xs, Xs).detach()
+    Ke = efk.base_kerns(locs, Xs, "func").detach().sum(0).view(1, m)
+    Kf = -efk.base_kerns(locs, Xs, "leftgrad").detach().view(N, 3 * N, m).sum(0)
+    Kv = efk.base_kerns(locs, Xs, "virial").detach().view(N, 6, m).sum(0)
+    rng = np.random.default_rng(140)
+    mu_true = rng.normal(size=m)
+    forces = (Kf.numpy() @ mu_true).reshape(N, 3) + 0.05 * rng.normal(size=(N, 3))
+    vol = abs(np.linalg.det(g["cell"]))
+    stress = (Kv.numpy() @ mu_true) / vol + 1e-4 * rng.normal(size=6)
+    energy = float(Ke.numpy() @ mu_true) + 0.7 * N   # an offset for the mean to find
+    noise_f = 0.06
+
+    class _A:
+        target_forces = torch.tensor(forces)
+        target_stress = torch.tensor(stress)
+
+        def get_volume(self):
+            return vol
+
+        def counts(self):
+            u, c = np.unique(numbers, return_counts=True)
+            return {int(a): int(b) for a, b in zip(u, c)}
+
+    class _D(list):
+        target_energy = torch.tensor([energy])
+        natoms = [N]
+
+        def counts(self):
+            return self[0].counts()
+
+    data = _D([_A()])
+    mean = AutoMean()
+    mean.set_data(data)
+    ns = SimpleNamespace(
+        ignore_forces=False, M=M, Ke=Ke, Kf=Kf, Kv=Kv, X=[SimpleNamespace(number=int(x.number)) for x in Xs],
+        data=data, gp=SimpleNamespace(noise=White(signal=0.01, requires_grad=False),
+                                      mean=lambda dat, forces=False: torch.stack([mean(a) for a in dat])),
+        mean=mean)
+    ns.K = torch.cat([Ke, Kf, Kv])
+    # the shape of the objective, for the record: the force-only fit's MAE_f over a scan of the noise (numpy
+    # restatement of make_mu(), gppotential.py:1245-1263, used for this diagnostic curve only)
+    from theforce.regression.gppotential import to_0_1, to_inf_inf
+    Lc = np.linalg.cholesky(M.numpy())
+    Kfv = np.concatenate([Kf.numpy(), Kv.numpy()])
+    Yfv = np.concatenate([forces.reshape(-1), stress * vol, np.zeros(m)])
+    scale = float(np.diag(M.numpy()).mean() * 0.99)
+    scan = []
+    for x in np.linspace(-9.0, 6.0, 31):
+        sig = 1.0 / (1.0 + np.exp(-x)) * scale
+        mu_x = np.linalg.lstsq(np.concatenate([Kfv, sig * Lc.T]), Yfv, rcond=None)[0]
+        scan.append((float(x), float(np.abs(Kf.numpy() @ mu_x - forces.reshape(-1)).mean())))
+    x_start = 0.5   # a continuing run: the search starts from the noise the previous refit ended with
+    ns._noise = {"all": torch.tensor(x_start)}
+    _regression(ns, optimize=True, noise_f=noise_f)
+    mae = float((ns.Kf @ ns.mu - torch.tensor(forces).view(-1)).abs().mean())
+    out = dict(frame=name, idx=np.array(idx, np.int32), energy=energy, forces=forces, stress=stress, noise_f=noise_f,
+               noise_logit_start=x_start,
+               noise_logit=float(ns._noise["all"]), noise=float(to_0_1(ns._noise["all"])), sigma=float(ns.scaled_noise["all"]),
+               mu=ns.mu.detach().numpy(), pred=(ns.K @ ns.mu).detach().numpy(), mae_f=mae, ridge=float(ns.ridge),
+               mean_z=np.array(sorted(mean.weights), np.int32),
+               mean_w=np.array([float(mean.weights[z]) for z in sorted(mean.weights)]), scan=np.array(scan))
+    np.savez_compressed(os.path.join(OUT, "g14_hpo.npz"), **out)
+    print("scan:", [(round(a, 1), round(b, 4)) for a, b in scan])
+    print("g14_hpo done: noise", out["noise"], "sigma", out["sigma"], "MAE_f", mae, "(target", noise_f, ") mean", out["mean_w"],
+          "scan MAE range", min(s_[1] for s_ in scan), max(s_[1] for s_ in scan))
+
 # ----------------------------------------------------------------------------- G11 acceptance rules
 def g11_acceptance(name="g5_big40"):
     """The decisions of the on-the-fly sampler, taken by the reference's OWN code
@@ -1065,3 +1185,7 @@ if __name__ == "__main__":
         g12_bcm()
     if "g10" in which:
         g10_tape()
+    if "g13" in which:
+        g13_subsesoap_kernel()
+    if "g14" in which:
+        g14_hpo()

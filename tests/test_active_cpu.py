@@ -433,3 +433,9 @@ def test_bcm_committee(tmp_path):
     # restart: members on disk are picked up again
     again = BCMActiveCalculator(engine=engine(), logfile=None, pckl=str(tmp_path / "c" / "model"), member_engine=engine)
     assert again.pckl_id == 2 and len(again.model_dict) == 1
+
+
+def test_hyperparameter_search_against_the_reference():
+    g = load("g5_big40")
+    ac.check_g14_hpo(OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
+                                 species=g["species"].tolist()))

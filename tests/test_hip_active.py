@@ -199,3 +199,45 @@ def test_bcm_committee_on_device(tmp_path):
     np.testing.assert_allclose(res["hip"][2], res["cpu"][2], rtol=0, atol=1e-5)
     for k in res["hip"][3]:
         assert abs(res["hip"][3][k] - res["cpu"][3][k]) < 1e-5
+
+
+def test_hyperparameter_search_against_the_reference_on_device():
+    """g14: the reference's own _regression(optimize=True) (scipy BFGS) against make_munu(algo=3) on the device."""
+    from autoforce_amd import SGPRModel
+    g = load("g5_big40")
+    ac.check_g14_hpo(SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=g["species"].tolist()))
+
+
+@pytest.mark.parametrize("units", ["metal", "real"])
+def test_lammps_fix_external_callback_on_the_device(units):
+    """cl/lmp.py:42-71 with the HIP engine behind the calculator: forces in LAMMPS' tag order and units, energy, the
+    virial in LAMMPS' component order — against the CPU oracle on the same model."""
+    import test_lammps_bridge as tl
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.lammps_bridge import NKTV2P, FixExternalBridge, convert
+    from helpers import OracleEngine
+    g = load("g5_tric24")
+    cell = np.triu(g["cell"])
+    mdl = model_from_fixture(g)
+    calc = ActiveCalculator(covariance=mdl, logfile=None)
+    zs = sorted(set(g["numbers"].tolist()))
+    types = np.array([zs.index(z) + 1 for z in g["numbers"]])
+    lmp = tl.FakeLammps(g["positions"], types, cell, 1.0)
+    bridge = FixExternalBridge(lmp, calc, units, {k + 1: z for k, z in enumerate(zs)}, "autoforce")
+    N = len(types)
+    tag = np.random.default_rng(0).permutation(N) + 1
+    fext = np.zeros((N, 3))
+    oracle = OracleEngine(g)
+    for step, shift in enumerate((0.0, 0.01)):
+        lmp.x = g["positions"] + shift
+        bridge(None, step, N, tag, None, fext)
+        ref = oracle.predict(g["numbers"], g["positions"] + shift, cell, [True] * 3)
+        fmax = np.abs(ref["forces"]).max()
+        np.testing.assert_allclose(fext, convert(ref["forces"][tag - 1], "force", "ASE", units), rtol=0,
+                                   atol=1e-9 * float(convert(fmax, "force", "ASE", units)))
+        assert lmp.energy[0] == "autoforce"
+        assert abs(lmp.energy[1] - float(convert(ref["energy"], "energy", "ASE", units))) <= 1e-10 * abs(float(convert(1.0, "energy", "ASE", units)))
+        vol = abs(np.linalg.det(cell))
+        want = -convert(ref["stress"], "pressure", "ASE", units) / (NKTV2P[units] / vol)
+        np.testing.assert_allclose(lmp.virial[1], want[[0, 1, 2, 5, 4, 3]], rtol=0, atol=1e-8 * np.abs(want).max())
+    mdl.close()

@@ -295,3 +295,31 @@ def test_atoms_outside_the_species_table_can_be_ignored():
     np.testing.assert_allclose(a["cov"][keep], b["cov"], rtol=0, atol=1e-13)
     assert np.abs(a["cov"][ghosts]).max() == 0.0
     mdl.close()
+
+
+def test_fixed_species_kernel_values():
+    """g13: K(X, X) of the reference's `species=[...]` kernel list (calculator/active.py:31-38: one SubSeSoapKernel per
+    species, similarity/sesoap.py:27-43 + similarity/heterosoap.py:37-71, summed by regression/gppotential.py:63-84) on
+    ten environments — three central species, a neighbour species outside the table (dropped silently), and lone atoms,
+    whose term the reference adds once per kernel object (similarity/similarity.py:94-103): 3 here, 1 for the wildcard
+    kernel.  The device K_mm of the same LCEs must match, and so must k(loc, X) for a single LCE."""
+    from autoforce_amd import Local, SGPRModel
+    g = load("g13_subsesoap_kernel")
+    table = g["table"].tolist()
+    ptr = g["ptr"]
+    X = [Local(int(z), g["nbr_z"][ptr[k]:ptr[k + 1]], g["nbr_r"][ptr[k]:ptr[k + 1]]) for k, z in enumerate(g["zc"])]
+    mdl = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=table, unknown_species="ignore",
+                    lone_weight=len(table))
+    mdl.set_inducing(X)
+    np.testing.assert_allclose(mdl.M, g["K"], rtol=1e-10, atol=1e-13)
+    for k in (0, 6, 7, 9):
+        kx, kxx = mdl.kernel_local(X[k])
+        np.testing.assert_allclose(kx, g["K"][k], rtol=1e-10, atol=1e-13)
+        assert abs(kxx - g["K"][k, k]) <= 1e-12 * max(1.0, g["K"][k, k])
+    # the wildcard kernel over the same table: the same values except the lone-atom block (1 instead of 3)
+    wild = SGPRModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]), species=table, unknown_species="ignore")
+    wild.set_inducing(X)
+    K1 = g["K"].copy()
+    K1[-3:, -3:] /= 3.0
+    np.testing.assert_allclose(wild.M, K1, rtol=1e-10, atol=1e-13)
+    mdl.close(); wild.close()

@@ -277,3 +277,47 @@ def test_kernel_rows(name):
     np.testing.assert_allclose(Ke, rows["Ke"], rtol=1e-11, atol=1e-13)
     assert np.abs(Kf - rows["Kf"]).max() <= 2e-6 * np.abs(rows["Kf"]).max()
     assert np.abs(Kv - rows["Kv"]).max() <= 2e-6 * np.abs(rows["Kv"]).max()
+
+
+def test_g13_fixed_species_kernel_values():
+    """The oracle's kernel restatement against the reference's `species=[...]` kernel LIST (one SubSeSoapKernel per
+    species, summed: calculator/active.py:31-38, regression/gppotential.py:63-84): neighbours outside the table are
+    dropped before the descriptor (descriptor/sesoap.py:343-346) and the lone-atom term counts once per kernel object
+    (similarity/similarity.py:94-103)."""
+    g = load("g13_subsesoap_kernel")
+    table = g["table"].astype(np.int32)
+    ptr = g["ptr"]
+    keep = np.isin(g["nbr_z"], table)
+    counts = np.array([keep[ptr[k]:ptr[k + 1]].sum() for k in range(len(g["zc"]))])
+    ptr2 = np.concatenate([[0], np.cumsum(counts)])
+    Pm, nnm = orc.inducing_descriptors(int(g["lmax"]), int(g["nmax"]), float(g["rc"]), table, g["zc"], ptr2, g["nbr_z"][keep],
+                                       g["nbr_r"][keep])
+    K = orc.kernel_matrix(g["zc"], nnm, Pm, g["zc"], nnm, Pm, float(g["eta"]))
+    lone = nnm == 0
+    K[np.ix_(lone, lone)] *= len(table)
+    np.testing.assert_allclose(K, g["K"], rtol=1e-11, atol=1e-13)
+
+
+def test_decisions_of_the_fixtures_sit_far_from_their_thresholds():
+    """What the device's tolerances can and cannot flip.  The sampling rules compare numbers with thresholds:
+    add_1inducing accepts when the energy change de reaches ediff (gppotential.py:955-982), update_lce compares the
+    covloss beta with ediff / ediff_lb / ediff_ub (active.py:806-839).  The device holds de to ~1e-9 relative and beta
+    to 5e-6 absolute (beta = sqrt(1 - |L^-1 k|^2) amplifies rounding near zero; beta^2 is held to 1e-9), so a decision
+    can only differ from the reference's when the quantity lies within that distance of its threshold.  In the
+    fixtures none does:
+      * g11: every finite de / ediff of the reference's own decisions is at least 5 % away from 1;
+      * the covloss of every atom of every golden frame is at least 1e-4 eV (20 x the device's absolute tolerance on
+        beta) away from the default ediff = 2 kcal/mol = 0.0867 eV (active.py:79,118)."""
+    g = load("g11_acceptance")
+    ratios = [de / t1 for kind, idx, added, de, df, m, nd, ridge, t1, t2 in g["events"] if kind == 0 and np.isfinite(de)]
+    assert len(ratios) >= 12
+    assert min(abs(r - 1.0) for r in ratios) > 0.05, ratios
+    for kind, idx, added, de, df, m, nd, ridge, t1, t2 in g["events"]:
+        if kind == 0 and np.isfinite(de):
+            assert bool(added) == (de >= t1)      # the rule itself, on the reference's numbers
+    ediff = 2 * 0.04336410390059322
+    near = []
+    for name in ("g5_big40", "g5_bigtric36", "g5_cluster16", "g5_mixed64", "g5_si32", "g5_si32_l2n2", "g5_slab18_nearz", "g5_tric24"):
+        f = load(name)
+        near.append(float(np.abs(f["covloss"] - ediff).min()))
+    assert min(near) > 1e-4, near
