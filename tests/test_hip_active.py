@@ -219,6 +219,7 @@ def test_lammps_fix_external_callback_on_the_device(units):
     g = load("g5_tric24")
     cell = np.triu(g["cell"])
     mdl = model_from_fixture(g)
+    mdl.set_weights(g["mu"], choli=g["choli"])
     calc = ActiveCalculator(covariance=mdl, logfile=None)
     zs = sorted(set(g["numbers"].tolist()))
     types = np.array([zs.index(z) + 1 for z in g["numbers"]])
