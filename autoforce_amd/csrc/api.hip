@@ -259,6 +259,11 @@ struct sgpr_model {
     DevBuf<long long> d_stamps2; // the same for the grouped W + covloss launch
     DevBuf<long long> d_pstamps; // SGPR_STAMPS=1 + a -DSGPR_PHASE_STAMPS build: [2][N][8] phase stamps (forward | reverse)
     DevBuf<int4> t_knm, t_w, t_cov, t_kmm, t_wcov;  // working-tile tables of the GEMMs
+    DevBuf<int4> t_covl;                            // covloss tiles alone, longest reductions first (ride in the reverse kernel)
+    bool cov_in_rev = false; // option "cov_in_rev": covloss tiles in the reverse kernel's launch instead of grouped with W
+                             // (measured at 4096 / 512: W alone 22.7 -> 18.5 us, reverse + covloss 17.0 -> 24.6: the reverse pass
+                             // already fills every SIMD's four wave slots, the tiles only push a third of its workgroups
+                             // into a second round)
     int gemm_bm_k = 64, gemm_bm_w = 64;  // rows per tile of t_knm  /  t_w, t_cov, t_wcov
     int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
     std::vector<int4> h_t_w, h_t_cov;
@@ -607,6 +612,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_cell0.alloc(18);  // cell at the last rebuild + its inverse
     if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
@@ -703,6 +709,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     for (auto &e : h->r1_cache) e.r1.release();
     for (auto &k : h->qr_keep) { k.clear_ops(); k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
+    h->t_covl.release();
     h->d_T.release();
     h->d_hm.release();
     h->d_pos0.release();
@@ -796,6 +803,23 @@ static int build_tiles(sgpr_model *h, int kind)
         std::vector<int4> both(dp * 8, make_int4(0, 0, 0, 0));
         for (int x = 0; x < 8; x++)
             for (size_t j = 0; j < bk[x].size(); j++) both[j * 8 + x] = bk[x][j];
+        {   // the covloss tiles alone, same XCD rule, longest first
+            std::vector<std::vector<int4>> bc(8);
+            for (const int4 &t : h->h_t_cov)
+                if (t.w > t.z) bc[t.x % 8].push_back(t);
+            for (auto &b : bc)
+                std::stable_sort(b.begin(), b.end(), [](const int4 &p, const int4 &q) { return p.w - p.z > q.w - q.z; });
+            size_t dc = 0;
+            for (auto &b : bc) dc = std::max(dc, b.size());
+            std::vector<int4> only(dc * 8, make_int4(0, 0, 0, 0));
+            for (int x = 0; x < 8; x++)
+                for (size_t j = 0; j < bc[x].size(); j++) only[j * 8 + x] = bc[x][j];
+            h->t_covl.release();
+            if (!only.empty()) {
+                if (h->t_covl.alloc(only.size(), false)) return -1;
+                if (hipMemcpy(h->t_covl.p, only.data(), sizeof(int4) * only.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+            }
+        }
         h->t_wcov.release();
         if (!both.empty()) {
             if (h->t_wcov.alloc(both.size(), false)) return -1;
@@ -1342,9 +1366,11 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     gc.tiles = h->t_cov.p; gc.ntiles = (int)h->t_cov.n; gc.bm = h->gemm_bm_w; gc.kd = h->gemm_kd_w;
     gc.rowsq = h->d_csq.p; gc.rowsq_ld = h->csq_slots;
     gw.stamps = (h->d_stamps2.p && h->t_wcov.n <= 8192) ? h->d_stamps2.p : nullptr;
+    GemmParams gcl = gc;  // the covloss product on its own tile list (longest first)
+    gcl.tiles = h->t_covl.p; gcl.ntiles = (int)h->t_covl.n;
     // "overlap" option: the covloss product (MFMA-bound) runs on a side stream next to the reverse pass
     // (VALU/latency-bound) instead of being grouped with the W product
-    bool forked = false;
+    bool forked = false, cov_rides = false;
     if (predict && beta && h->use_fork && h->side && !h->profile) {
         (void)hipEventRecord(h->ev_fork, st);
         (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
@@ -1352,6 +1378,11 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         (void)hipEventRecord(h->ev_join, h->side);
         launch_gemm_nt(gw, EPI_STORE, st);
         forked = true;
+    } else if (predict && beta && h->cov_in_rev && h->gemm_bm_w == 32 && h->gemm_kd_w == 16 && h->t_covl.n > 0) {
+        // W alone; the covloss tiles ride in the reverse kernel's launch below
+        launch_gemm_nt(gw, EPI_STORE, st);
+        stamp(h, "gemm_w", st);
+        cov_rides = true;
     } else if (predict && beta) {
         launch_gemm_wcov(gw, gc, h->t_wcov.p, (int)h->t_wcov.n, st);
         stamp(h, "gemm_w_covloss", st);
@@ -1367,9 +1398,9 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
                                          h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p,
                                          h->d_W.p, h->d_prec.p, gather ? h->d_G.p : nullptr, h->d_aux.p,
                                          h->d_T.p, h->t_stride, h->d_cidx.p, h->d_hm.p, h->hmw, h->d_F.p, h->d_virpart.p,
-                                         st);
+                                         st, nullptr, cov_rides ? &gcl : nullptr);
         if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
-        stamp(h, "descriptor_rev", st);
+        stamp(h, cov_rides ? "descriptor_rev_covloss" : "descriptor_rev", st);
     }
     if (forked) (void)hipStreamWaitEvent(st, h->ev_join, 0);
     launch_finalize(h, gather && predict, predict ? h->epart_len : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
@@ -1723,6 +1754,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
         h->use_graph = value != 0; drop_graph(h); h->lists_valid = false; return SGPR_OK;
     }
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
+    if (!strcmp(name, "cov_in_rev")) { h->cov_in_rev = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "spin_wait")) { h->spin_wait = value != 0; return SGPR_OK; }
     if (!strcmp(name, "zero_copy_out")) { h->zero_copy_out = value != 0; return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }

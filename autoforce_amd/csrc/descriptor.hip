@@ -16,6 +16,7 @@
 // recurrence coefficients for q (ylm.py:57-77,146-159).  Only sum_m c c* enters any output,
 // so this real basis is equivalent to the reference's packed complex layout.
 #include "sgpr_internal.h"
+#include "gemm_tile.inc"  // the covloss tiles of a step ride in the reverse kernel's launch
 
 __constant__ HarmCoef c_hc;
 
@@ -1111,20 +1112,34 @@ static int rev_region_doubles(int Dpad)
 
 // ROWS: the training-rows form (a batch of inducing columns over blockIdx.y, the seed formed from Aw and P^m);
 // compiled apart so that the predict path carries none of its bookkeeping
-template <int LMAX, int NMAX, int ST, bool GATHER, bool ROWS>
-__global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
+// COV: the first `n_cov` workgroups of the launch are not atoms but tiles of the covloss product |choli k_i|^2
+// (gemm_tile.inc, row-square epilogue): they depend on K_nm only, as this kernel depends on W only, and they are bound by
+// the matrix pipe where the reverse pass is bound by vector issue and latency — in one launch the two fill each other's
+// gaps, and the W product that used to share a launch with them gets shorter (no event hops: the side-stream form of
+// the same idea paid more for its two events than the overlap returned).
+template <int LMAX, int NMAX, int ST, bool GATHER, bool ROWS, bool COV = false>
+__global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs gc, int n_cov)
 {
+    extern __shared__ double smem[];
+    if constexpr (COV) {
+        if ((int)blockIdx.x < n_cov) {
+            using GL = GemmLds<EPI_ROWSQ, 1, 16>;
+            gemm_tile_body<EPI_ROWSQ, 1, 16>(gc, (int)blockIdx.x, smem, smem + GL::NBUF * GL::ASZ);
+            return;
+        }
+    }
+    const int bx = COV ? (int)blockIdx.x - n_cov : (int)blockIdx.x;      // workgroup of the reverse pass
+    const int nbx = COV ? (int)gridDim.x - n_cov : (int)gridDim.x;
     const double *const rows_aw = ROWS ? a.rows_aw : nullptr;
     using RD = RevDims<LMAX, NMAX>;
     constexpr int N1 = RD::N1, L1 = RD::L1, LL = RD::LL, NSLOT = RD::NSLOT;
     constexpr int KS = RD::KS, CB = RD::CB, CH = RD::CH, RB = RD::RB, SP = RD::SP, FS = RD::FS;
     constexpr int SPL = (NSLOT + 63) / 64;
-    extern __shared__ double smem[];
     __shared__ double vred[4][9];
     // wave index through readfirstlane: everything derived from it (atom index, LDS bases, row
     // addresses) is then scalar and stays out of the VGPR budget
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ia = blockIdx.x * 4 + wave;
+    const int ia = bx * 4 + wave;
     const bool active = ia < a.N;
     const int perwave = ST * NSLOT + a.rsz + CH / 2;
     double *dcl = smem + (size_t)wave * perwave;  // [ST][NSLOT] dE/dc of this atom
@@ -1470,7 +1485,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a)
     }
     __syncthreads();
     if (wave == 0 && lane < 9)
-        vir_b[(size_t)lane * gridDim.x + blockIdx.x] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
+        vir_b[(size_t)lane * nbx + bx] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
 }
 
 // =========================================================================== unpack (tests)
@@ -1521,27 +1536,41 @@ static int run_fwd(const DescArgs &a, hipStream_t st)
 }
 
 template <int LMAX, int NMAX, int ST>
-static int run_bwd(DescArgs a, hipStream_t st)
+static int run_bwd(DescArgs a, hipStream_t st, const GemmParams *cov = nullptr)
 {
     if (a.N <= 0) return 0;
     using RD = RevDims<LMAX, NMAX>;
     a.rsz = rev_region_doubles<LMAX, NMAX, ST>(a.Dpad);
-    const size_t lds = sizeof(double) * 4 * (size_t)(ST * RD::NSLOT + a.rsz + RD::CH / 2);
-    static size_t attr_set[4] = {0, 0, 0, 0};
+    size_t lds = sizeof(double) * 4 * (size_t)(ST * RD::NSLOT + a.rsz + RD::CH / 2);
+    static size_t attr_set[6] = {0, 0, 0, 0, 0, 0};
     const bool gather = a.G != nullptr, rows = a.rows_aw != nullptr;
-    const void *fn = gather ? (rows ? (const void *)desc_rev_kernel<LMAX, NMAX, ST, true, true>
+    const bool with_cov = cov && !rows && cov->tiles && cov->ntiles > 0 && cov->bm == 32 && cov->kd == 16;
+    GemmArgs gc = {};
+    int n_cov = 0;
+    if (with_cov) {
+        gc.p = *cov;
+        gc.ieta = -1;
+        n_cov = cov->ntiles;
+        lds = std::max(lds, sizeof(double) * (size_t)GemmLds<EPI_ROWSQ, 1, 16>::DOUBLES);
+    }
+    const int which = with_cov ? 4 + gather : 2 * gather + rows;
+    const void *fn = with_cov ? (gather ? (const void *)desc_rev_kernel<LMAX, NMAX, ST, true, false, true>
+                                        : (const void *)desc_rev_kernel<LMAX, NMAX, ST, false, false, true>)
+                   : gather ? (rows ? (const void *)desc_rev_kernel<LMAX, NMAX, ST, true, true>
                                     : (const void *)desc_rev_kernel<LMAX, NMAX, ST, true, false>)
                             : (rows ? (const void *)desc_rev_kernel<LMAX, NMAX, ST, false, true>
                                     : (const void *)desc_rev_kernel<LMAX, NMAX, ST, false, false>);
-    if (attr_set[2 * gather + rows] < lds) {
+    if (attr_set[which] < lds) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[2 * gather + rows] = lds;
+        attr_set[which] = lds;
     }
-    const dim3 grid((a.N + 3) / 4, rows ? a.batch : 1);
-    if (gather && rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, true>), grid, dim3(256), lds, st, a);
-    else if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false>), grid, dim3(256), lds, st, a);
-    else if (rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false>), grid, dim3(256), lds, st, a);
+    const dim3 grid((a.N + 3) / 4 + n_cov, rows ? a.batch : 1);
+    if (with_cov && gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false, true>), grid, dim3(256), lds, st, a, gc, n_cov);
+    else if (with_cov) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false, true>), grid, dim3(256), lds, st, a, gc, n_cov);
+    else if (gather && rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, true>), grid, dim3(256), lds, st, a, gc, n_cov);
+    else if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false>), grid, dim3(256), lds, st, a, gc, n_cov);
+    else if (rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, true>), grid, dim3(256), lds, st, a, gc, n_cov);
+    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false>), grid, dim3(256), lds, st, a, gc, n_cov);
     return 0;
 }
 
@@ -1590,7 +1619,7 @@ static DescArgs make_args(const DescParams &p)
 }
 
 #define FWD_ENV(L, N, S, a, st) run_fwd<L, N, S, true>(a, st)
-#define BWD(L, N, S, a, st) run_bwd<L, N, S>(a, st)
+#define BWD(L, N, S, a, st, cov) run_bwd<L, N, S>(a, st, cov)
 
 template <int LMAX, int NMAX, int ST>
 static int run_list_fwd(const DescArgs &a, const NlArgs &n, hipStream_t st)
@@ -1639,7 +1668,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                const PackEntry *pack, const double *Pn, const double *norm, const double *C,
                                const int *shear, const double *W, const double *prec, double *G, const int *aux,
                                const unsigned short *T, int t_stride, const int *cidx, const unsigned long long *hm,
-                               int hmw, double *F, double *virial, hipStream_t st, const RowsBatch *rows)
+                               int hmw, double *F, double *virial, hipStream_t st, const RowsBatch *rows, const GemmParams *cov)
 {
     DescArgs a = make_args(p);
     a.pos = pos; a.cell = cell; a.slot = slot; a.radii = radii; a.nn = nn; a.nbr_j = nbr_j;
@@ -1656,5 +1685,5 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
         a.rows_aw = rows->aw; a.rows_pm = rows->pm; a.rows_cols = rows->cols; a.rows_colslot = rows->col_slot; a.rows_ld = rows->ld; a.batch = rows->batch;
         a.g_stride = rows->g_stride; a.f_stride = rows->f_stride; a.v_stride = rows->v_stride;
     }
-    DISPATCH_LNS(BWD, a, st);
+    DISPATCH_LNS(BWD, a, st, cov);
 }

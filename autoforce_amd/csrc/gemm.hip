@@ -24,392 +24,15 @@
 // 19 us (tools/ubench_gemm5.hip).  Built with -mllvm -amdgpu-mfma-vgpr-form=1 (build.sh): accumulators stay in VGPRs.
 #include "sgpr_internal.h"
 
-typedef double v4d __attribute__((ext_vector_type(4)));
+#include "gemm_tile.inc"
 
-#define BM 64
-#define BN 64
-#define KT 32
-#define LDS_LD 17
-
-struct GemmArgs {
-    GemmParams p;
-    GemmParams p2;   // EPI_WCOV: second problem of the group (tile table entries with bit 16 of .x set)
-    int ieta;        // integer exponent or -1
-    const int *row_slot, *col_slot;
-    double *Epart;
-    int row_tiles, rows_pad, col_tiles;
-    long long *stamps;  // diagnostic only (SGPR_STAMPS=1): [block][8] s_memtime stamps
-};
-
-// the value a DPP control hands to this lane (row = 16 lanes): 0xB1 / 0x4E swap inside quads, 0x141 / 0x140 mirror
-// half rows / rows — a sum over the 16 lanes of a row without LDS round trips (four ds_bpermute chains per row sum
-// made the covloss epilogue 3.7k cycles long)
-template <int CTRL>
-__device__ __forceinline__ double row_dpp(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double ipow_d(double x, int n)
-{
-    double y = 1.0;
-    for (int k = 0; k < n; k++) y *= x;
-    return y;
-}
-
-// TM = MFMA row tiles per wave: 2 -> 64-row workgroup tiles, 1 -> 32-row tiles.
-// __launch_bounds__(256, 2): two workgroups per CU = two waves per SIMD = a budget of 256 registers, which makes the
-// compiler pick the VGPR form of the MFMAs; with the full 512 it picks the AGPR form and copies the sixteen
-// accumulator registers to VGPRs and back around every trip of the stage loop (16 v_accvgpr_write + 16 _read each
-// draining the matrix pipe).
-// KD = depth of a stage of the 32-row form: 32 (two workgroups per CU) or 16 (36 KB of LDS, <= 128 registers: FOUR
-// workgroups per CU — for launches of many short reductions, where the fixed cost of a tile (tile entry, first loads,
-// epilogue: ~4 us, measured with per-tile stamps) is what the other resident workgroups have to cover).
 template <int EPI, int TM = 2, int KD = 32>
 __global__ __launch_bounds__(256, KD == 16 ? 4 : 2) void gemm_nt_kernel(GemmArgs g)
 {
-    constexpr int BMT = 32 * TM;
-    // EPI_WCOV: one launch serves two independent products that share the row dimension (W = Aw.Pm with
-    // a plain store, covloss = K.choli^T with the row-square epilogue); the tile table says which.
-    const bool second = (EPI == EPI_WCOV) && ((g.p.tiles[blockIdx.x].x >> 16) & 1);
-    const GemmParams &p = second ? g.p2 : g.p;
-    // 64-row tiles: two stages of A and B (68 KB, two workgroups per CU); 32-row tiles: three (76.5 KB, two per CU)
-    // LDS rows: 32-deep stages are padded by two doubles (conflict-free fragment reads); 16-deep stages are XOR-swizzled
-    // instead (16-B chunk c of row r sits at chunk c ^ ((r >> 1) & 7)): 36 KB for three stages, four workgroups per CU
-    constexpr bool SWZ = KD == 16;
-    constexpr int LDR = SWZ ? KD : KD + 2;
-    constexpr int NBUF = TM == 1 ? 3 : 2, ASZ = BMT * LDR, BSZ = BN * LDR;
-    __shared__ double As[NBUF * ASZ];
-    __shared__ double Bs[NBUF * BSZ];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wr = wave >> 1, wc = wave & 1;
-    // Tile selection.  With a host-built tile table (species-sorted operands: K_nm, K_mm, choli are
-    // block-diagonal) only the working tiles are launched, each with its trimmed reduction range;
-    // the table is ordered so that list position p sits on XCD p % 8 together with the other
-    // column tiles of the same row panel of A (one L2 fetches the panel once).  Without a table
-    // the grid is dense, row tile fastest (same XCD property).
-    const long long t_start = g.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    int rt, ct, kbeg = 0, kend = p.K;
-    if (g.p.tiles) {
-        const int4 t = g.p.tiles[blockIdx.x];
-        rt = t.x & 0xffff; ct = t.y; kbeg = t.z; kend = t.w;
-        if (kend <= kbeg) return;  // padding entry
-    } else {
-        rt = blockIdx.x % g.rows_pad;
-        ct = blockIdx.x / g.rows_pad;
-        if (rt >= g.row_tiles) return;
-    }
-    long long t_entry = 0, t_pro = 0;
-    if (g.stamps) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_entry) : "s"(rt + ct));  // tile entry has arrived
-    const int row0 = rt * BMT, col0 = ct * BN;
-    const bool skip = (EPI == EPI_SUBLOWER && col0 > row0);  // symmetric update: lower tiles only
-
-    v4d acc[TM][2];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
-    // EPI_KERNEL: species slot / neighbour count per row, slot / count / weight per column of this
-    // lane's 8 rows and 2 columns, requested now so the latency hides under the main loop
-    // (all arrays are padded to whole tiles by the allocator).
-    int e_rs[TM][4], e_rn[TM][4], e_cs[2], e_cn[2];
-    double e_mu[2];
-    if (EPI == EPI_KERNEL) {
-#pragma unroll
-        for (int tm = 0; tm < TM; tm++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
-                e_rs[tm][r] = g.row_slot[row];
-                e_rn[tm][r] = p.row_nn ? p.row_nn[row] : 1;
-            }
-#pragma unroll
-        for (int tn = 0; tn < 2; tn++) {
-            const int col = col0 + wc * 32 + tn * 16 + (lane & 15);
-            e_cs[tn] = g.col_slot[col];
-            e_cn[tn] = p.col_nn ? p.col_nn[col] : 1;
-            e_mu[tn] = p.mu ? p.mu[col] : 0.0;
-        }
-    }
-
-    if constexpr (TM == 2) {
-    if (!skip) {
-        // LDS-staged main loop, KS = 32 deep stages, double-buffered in LDS and fetched TWO stages
-        // ahead through registers: every stage touches new cache lines (compulsory L2 misses,
-        // ~2000+ cycles under load) while its 32 MFMAs per wave issue in 2048 cycles.
-        // Global side: thread t moves 64 contiguous bytes of row t/4 (full-line coalescing: the
-        // four lanes of a quad cover two whole 128-B lines; fragment-shaped direct loads measured
-        // TA-bound at 4x the cycles).  LDS side: row stride 34 doubles -> conflict-free ds_read_b64
-        // fragment reads and 16-B aligned ds_write_b128 stores.
-        constexpr int KS = 32, LD = KS + 2;
-        const int lr = tid >> 2, lk = (tid & 3) * 8;
-        const double *Ag = p.A + (size_t)(row0 + lr) * p.lda + lk;
-        const double *Bg = p.B + (size_t)(col0 + lr) * p.ldb + lk;
-        // register stages as plain named values (a struct taken by reference in a lambda ended up
-        // in scratch: 272 B/lane of spills and a 45 us kernel)
-        double2 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;  // stage "p"
-        double2 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;  // stage "q"
-#define GLOAD(S, K0)                                                                             \
-    if ((K0) < kend) {                                                                           \
-        if (TM == 2 || lr < BMT) {                                                               \
-        S##a0 = *(const double2 *)(Ag + (K0)); S##a1 = *(const double2 *)(Ag + (K0) + 2);        \
-        S##a2 = *(const double2 *)(Ag + (K0) + 4); S##a3 = *(const double2 *)(Ag + (K0) + 6);    \
-        }                                                                                        \
-        S##b0 = *(const double2 *)(Bg + (K0)); S##b1 = *(const double2 *)(Bg + (K0) + 2);        \
-        S##b2 = *(const double2 *)(Bg + (K0) + 4); S##b3 = *(const double2 *)(Bg + (K0) + 6);    \
-    }
-#define LSTORE(S, BUF)                                                                           \
-    {                                                                                            \
-        double *da = &As[(BUF) * ASZ + lr * LD + lk], *db = &Bs[(BUF) * BSZ + lr * LD + lk];                       \
-        if (TM == 2 || lr < BMT) {                                                               \
-        *(double2 *)(da) = S##a0; *(double2 *)(da + 2) = S##a1;                                  \
-        *(double2 *)(da + 4) = S##a2; *(double2 *)(da + 6) = S##a3;                              \
-        }                                                                                        \
-        *(double2 *)(db) = S##b0; *(double2 *)(db + 2) = S##b1;                                  \
-        *(double2 *)(db + 4) = S##b2; *(double2 *)(db + 6) = S##b3;                              \
-    }
-        const int fa = (wr * 16 * TM + (lane & 15)) * LD + (lane >> 4);
-        const int fb = (wc * 32 + (lane & 15)) * LD + (lane >> 4);
-        auto compute = [&](int buf) {
-#pragma unroll
-            for (int kk = 0; kk < KS; kk += 4) {
-                const double b0 = Bs[buf * BSZ + fb + kk], b1 = Bs[buf * BSZ + fb + 16 * LD + kk];
-#pragma unroll
-                for (int tm = 0; tm < TM; tm++) {
-                    const double a0 = As[buf * ASZ + fa + tm * 16 * LD + kk];
-                    acc[tm][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[tm][0], 0, 0, 0);
-                    acc[tm][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[tm][1], 0, 0, 0);
-                }
-            }
-        };
-        // prologue: stage 0 -> LDS buffer 0, stage 1 and 2 in flight in registers
-        pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = pb2 = pb3 = make_double2(0.0, 0.0);
-        qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = make_double2(0.0, 0.0);
-        GLOAD(p, kbeg);
-        GLOAD(q, kbeg + KS);
-        LSTORE(p, 0);
-        GLOAD(p, kbeg + 2 * KS);
-        __syncthreads();
-        // steady state, unrolled by two so the register stages keep static names
-        for (int k0 = kbeg; k0 < kend; k0 += 2 * KS) {
-            // buffer 0 holds stage k0; s1 = stage k0+KS; s0 = stage k0+2KS
-            if (k0 + KS < kend) LSTORE(q, 1);
-            GLOAD(q, k0 + 3 * KS);
-            compute(0);
-            __syncthreads();
-            if (k0 + KS >= kend) break;
-            // buffer 1 holds stage k0+KS; s0 = stage k0+2KS; s1 = stage k0+3KS
-            if (k0 + 2 * KS < kend) LSTORE(p, 0);
-            GLOAD(p, k0 + 4 * KS);
-            compute(1);
-            __syncthreads();
-        }
-    }
-
-    } else {
-        // 32-row tiles.  Stage s lives in LDS buffer s % 3 (cur / nxt / stb rotate).  One barrier at the TOP of a
-        // stage: behind it every wave is done reading stage s-1, whose buffer now takes stage s+2, and the stores of
-        // stage s+1 (issued during stage s-1) are visible — so the first fragments of stage s+1 are read before the
-        // next barrier and the MFMA stream does not stop at the stage boundary.  The stage body is straight-line:
-        // eight k-steps of two MFMAs, the fragments one step ahead, and in the shadow of the MFMAs the six
-        // ds_write_b128 of stage s+2 (steps 0-2) and the six global loads of stage s+4 (steps 3-5);
-        // __builtin_amdgcn_sched_barrier keeps them there.  The steady-state loop has no conditions and is entered
-        // from an unconditional prologue, so the compiler counts vmcnt exactly (vmcnt(10) / vmcnt(6): a conditional
-        // load anywhere before the loop made it wait for vmcnt(0), i.e. a prefetch distance of one stage).
-        // tools/ubench_gemm4.hip, dense 4096 x 512 x 320: 12.8 -> 10.2 us for two tiles per CU (MFMA bound 8.5).
-        constexpr int KS = KD, LD = LDR, NJ = KS / 4, NA = KS / 16, NB = KS / 8;
-        // global side: 64 B (KS = 32) or 32 B (16) per thread of B (4 threads per row), half of that of A (8 per row)
-        const int lrb = tid >> 2, lkb = (tid & 3) * (KS / 4);
-        const int lra = tid >> 3, lka = (tid & 7) * (KS / 8);
-        const double *Ag = p.A + (size_t)(row0 + lra) * p.lda + lka + kbeg;
-        const double *Bg = p.B + (size_t)(col0 + lrb) * p.ldb + lkb + kbeg;
-        const int ga = (lra >> 1) & 7, gb = (lrb >> 1) & 7;  // swizzle keys of the rows this thread stores
-        const int la = SWZ ? lra * LD + (((tid & 7) ^ ga) << 1) : lra * LD + lka;
-        const int lb = SWZ ? lrb * LD + ((((tid & 3) << 1) ^ gb) << 1) : lrb * LD + lkb;
-        const int lb1 = SWZ ? lrb * LD + (((((tid & 3) << 1) | 1) ^ gb) << 1) : lb + 2;  // second chunk of B
-        const int fra_r = wr * 16 + (lane & 15), frb_r = wc * 32 + (lane & 15);
-        const int fa = fra_r * LD + (lane >> 4);
-        const int fb = frb_r * LD + (lane >> 4);
-        // swizzled fragment offsets of the four k-steps: chunk 2j + (lane >> 5), low double (lane >> 4) & 1
-        int oa[4], ob[4];
-        if (SWZ) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int c = 2 * j + (lane >> 5), lo = (lane >> 4) & 1;
-                oa[j] = fra_r * LD + ((c ^ ((fra_r >> 1) & 7)) << 1) + lo;
-                ob[j] = frb_r * LD + ((c ^ ((frb_r >> 1) & 7)) << 1) + lo;  // row + 16 has the same key
-            }
-        }
-        double2 pa[2], pb[4], qa[2], qb[4];  // KS = 16 uses the first 1 / 2 of them
-        double fra[2], frb[2][2];
-        const int nst = (kend - kbeg + KS - 1) / KS;
-#define GLA(S, ST, I0, I1) _Pragma("unroll") for (int i = I0; i < I1; i++) S##a[i] = *(const double2 *)(Ag + (ST) * KS + 2 * i);
-#define GLB(S, ST, I0, I1) _Pragma("unroll") for (int i = I0; i < I1; i++) S##b[i] = *(const double2 *)(Bg + (ST) * KS + 2 * i);
-#define LSA(S, BUF, I0, I1) _Pragma("unroll") for (int i = I0; i < I1; i++) *(double2 *)(As + (BUF) * ASZ + la + 2 * i) = S##a[i];
-#define LSB(S, BUF, I0, I1) _Pragma("unroll") for (int i = I0; i < I1; i++) *(double2 *)(Bs + (BUF) * BSZ + (SWZ ? (i ? lb1 : lb) : lb + 2 * i)) = S##b[i];
-#define RDF(SL, BUF, KK)                                                                         \
-    {                                                                                            \
-        if (SWZ) {                                                                               \
-            frb[SL][0] = Bs[(BUF) * BSZ + ob[((KK) / 4) & 3]]; frb[SL][1] = Bs[(BUF) * BSZ + ob[((KK) / 4) & 3] + 16 * LD]; \
-            fra[SL] = As[(BUF) * ASZ + oa[((KK) / 4) & 3]];                                      \
-        } else {                                                                                 \
-            frb[SL][0] = Bs[(BUF) * BSZ + fb + (KK)]; frb[SL][1] = Bs[(BUF) * BSZ + fb + 16 * LD + (KK)]; \
-            fra[SL] = As[(BUF) * ASZ + fa + (KK)];                                               \
-        }                                                                                        \
-    }
-#define STAGE(R, DO_ST, DO_LD, SLD)                                                              \
-    {                                                                                            \
-        __syncthreads();                                                                         \
-        _Pragma("unroll") for (int j = 0; j < NJ; j++) {                                         \
-            const int sl = j & 1;                                                                \
-            if (j < NJ - 1) RDF(sl ^ 1, cur, 4 * (j + 1)) else RDF(sl ^ 1, nxt, 0)               \
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(fra[sl], frb[sl][0], acc[0][0], 0, 0, 0); \
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fra[sl], frb[sl][1], acc[0][1], 0, 0, 0); \
-            if (KS == 32) {                                                                      \
-                if (DO_ST) { if (j == 0) LSA(R, stb, 0, 2) if (j == 1) LSB(R, stb, 0, 2) if (j == 2) LSB(R, stb, 2, 4) } \
-                if (DO_LD) { if (j == 3) GLA(R, SLD, 0, 2) if (j == 4) GLB(R, SLD, 0, 2) if (j == 5) GLB(R, SLD, 2, 4) } \
-            } else {                                                                             \
-                if (DO_ST) { if (j == 0) LSA(R, stb, 0, 1) if (j == 1) LSB(R, stb, 0, 2) }       \
-                if (DO_LD) { if (j == 2) GLA(R, SLD, 0, 1) if (j == 3) GLB(R, SLD, 0, 2) }       \
-            }                                                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-        }                                                                                        \
-        const int t_ = cur; cur = nxt; nxt = stb; stb = t_;                                      \
-    }
-        for (int i = 0; i < NA; i++) pa[i] = qa[i] = make_double2(0.0, 0.0);
-        for (int i = 0; i < NB; i++) pb[i] = qb[i] = make_double2(0.0, 0.0);
-        int cur = 0, nxt = 1, stb = 2, s = 0;
-        if (nst >= 6) {
-            GLA(p, 0, 0, NA) GLB(p, 0, 0, NB)
-            GLA(q, 1, 0, NA) GLB(q, 1, 0, NB)
-            LSA(p, 0, 0, NA) LSB(p, 0, 0, NB)
-            GLA(p, 2, 0, NA) GLB(p, 2, 0, NB)
-            LSA(q, 1, 0, NA) LSB(q, 1, 0, NB)
-            GLA(q, 3, 0, NA) GLB(q, 3, 0, NB)
-            __syncthreads();
-            if (g.stamps) t_pro = (long long)__builtin_amdgcn_s_memtime();
-            RDF(0, 0, 0)
-            for (; s + 5 < nst; s += 2) {  // both stages of the pair store (s+2, s+3) and load (s+4, s+5)
-                STAGE(p, 1, 1, s + 4)
-                STAGE(q, 1, 1, s + 5)
-            }
-        } else {
-            GLA(p, 0, 0, NA) GLB(p, 0, 0, NB)
-            if (nst > 1) { GLA(q, 1, 0, NA) GLB(q, 1, 0, NB) }
-            LSA(p, 0, 0, NA) LSB(p, 0, 0, NB)
-            if (nst > 2) { GLA(p, 2, 0, NA) GLB(p, 2, 0, NB) }
-            LSA(q, 1, 0, NA) LSB(q, 1, 0, NB)
-            if (nst > 3) { GLA(q, 3, 0, NA) GLB(q, 3, 0, NB) }
-            __syncthreads();
-            if (g.stamps) t_pro = (long long)__builtin_amdgcn_s_memtime();
-            RDF(0, 0, 0)
-        }
-        // at most five stages left; one of them may still load
-        for (; s < nst; s += 2) {
-            if (s + 4 < nst) STAGE(p, 1, 1, s + 4)
-            else if (s + 2 < nst) STAGE(p, 1, 0, 0)
-            else STAGE(p, 0, 0, 0)
-            if (s + 1 >= nst) break;
-            if (s + 3 < nst) STAGE(q, 1, 0, 0)
-            else STAGE(q, 0, 0, 0)
-        }
-#undef GLA
-#undef GLB
-#undef LSA
-#undef LSB
-#undef RDF
-#undef STAGE
-    }
-
-#undef GLOAD
-#undef LSTORE
-    const long long t_loop = g.stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    // ------------------------------------------------------------------ epilogues
-    // C/D map of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
-    double esum = 0.0;
-    if (!skip) {
-#pragma unroll
-        for (int tm = 0; tm < TM; tm++) {
-            double rsq[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int tn = 0; tn < 2; tn++) {
-                const int col = col0 + wc * 32 + tn * 16 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
-                    const double v = acc[tm][tn][r];
-                    if (EPI == EPI_STORE || (EPI == EPI_WCOV && !second)) {
-                        if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] = v;
-                    } else if (EPI == EPI_SUBLOWER) {
-                        if (row < p.M && col < p.N) p.C[(size_t)row * p.ldc + col] -= v;
-                    } else if (EPI == EPI_KERNEL) {
-                        // branch-free: per-row / per-column metadata was fetched before the main
-                        // loop (a load inside a data-dependent branch cost one L2 round trip per
-                        // element: 24.7k cycles of epilogue, measured with s_memtime stamps)
-                        const bool same = e_rs[tm][r] == e_cs[tn];
-                        const bool rl = e_rn[tm][r] == 0, cl = e_cn[tn] == 0;
-                        double pm1;
-                        if (g.ieta == 4)  // the reference's default exponent: no loop
-                            pm1 = v * v * v;
-                        else if (g.ieta >= 1) {
-                            pm1 = 1.0;
-                            for (int q = 1; q < g.ieta; q++) pm1 *= v;
-                        } else
-                            pm1 = pow(v, p.eta - 1.0);
-                        const double eta_d = g.ieta >= 1 ? (double)g.ieta : p.eta;
-                        double k = (!rl && !cl) ? pm1 * v : ((rl && cl) ? 1.0 + p.lone_m1 : 0.0);  // similarity.py:94-103
-                        const double kp = (!rl && !cl) ? eta_d * pm1 : 0.0;
-                        if (same && row < p.M && col < p.N) {
-                            p.C[(size_t)row * p.ldc + col] = k;
-                            if (p.Aw) p.Aw[(size_t)row * p.ldc + col] = e_mu[tn] * kp;
-                            esum += k * e_mu[tn];
-                        }
-                    } else {  // EPI_ROWSQ
-                        if (col < p.N) rsq[r] += v * v;
-                    }
-                }
-            }
-            if (EPI == EPI_ROWSQ || (EPI == EPI_WCOV && second)) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    double s = rsq[r];
-                    s += row_dpp<0xB1>(s);   // the same pairs, in the same order, as xor 1, 2, 4, 8
-                    s += row_dpp<0x4E>(s);
-                    s += row_dpp<0x141>(s);
-                    s += row_dpp<0x140>(s);
-                    const int row = row0 + wr * 16 * TM + tm * 16 + (lane >> 4) + 4 * r;
-                    if ((lane & 15) == 0 && row < p.M && s != 0.0) p.rowsq[(size_t)row * p.rowsq_ld + 2 * ct + wc] = s;
-                }
-            }
-        }
-    }
-    if (EPI == EPI_KERNEL && g.Epart) {
-        // one energy partial per WAVE (no workgroup barrier: the waves retire independently)
-        esum += row_dpp<0xB1>(esum);
-        esum += row_dpp<0x4E>(esum);
-        esum += row_dpp<0x141>(esum);
-        esum += row_dpp<0x140>(esum);  // every lane holds the sum of its row of 16; the four row sums through SGPRs
-        {
-            const int lo = __double2loint(esum), hi = __double2hiint(esum);
-            double r4[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                r4[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
-            esum = (r4[0] + r4[1]) + (r4[2] + r4[3]);
-        }
-        if (lane == 0) g.Epart[(size_t)(g.p.tiles ? (int)blockIdx.x : rt * g.col_tiles + ct) * 4 + wave] = esum;
-    }
-    if (g.stamps && threadIdx.x == 0) {
-        long long *o = g.stamps + (size_t)blockIdx.x * 8;
-        o[4] = t_entry; o[5] = t_pro;
-        // reduction length | second-problem flag << 20 | XCC_ID << 24 | HW_ID << 32
-        const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
-        o[0] = t_start; o[1] = t_loop; o[2] = (long long)__builtin_amdgcn_s_memtime();
-        o[3] = (long long)(kend - kbeg) | ((long long)second << 20) | ((long long)xcc << 24) | ((long long)hw << 32);
-    }
+    using L = GemmLds<EPI, TM, KD>;
+    __shared__ double As[L::NBUF * L::ASZ];
+    __shared__ double Bs[L::NBUF * L::BSZ];
+    gemm_tile_body<EPI, TM, KD>(g, (int)blockIdx.x, As, Bs);
 }
 
 void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st)
@@ -442,7 +65,9 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
     g.rows_pad = (g.row_tiles + 7) / 8 * 8;
     dim3 grid(p.tiles ? p.ntiles : g.rows_pad * g.col_tiles), block(256);
     if (p.tiles && p.ntiles <= 0) return;
-    if (epi == EPI_STORE && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_STORE, 1>), grid, block, 0, st, g);
+    if (epi == EPI_STORE && p.bm == 32 && p.tiles && p.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_STORE, 1, 16>), grid, block, 0, st, g);
+    else if (epi == EPI_ROWSQ && p.bm == 32 && p.tiles && p.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_ROWSQ, 1, 16>), grid, block, 0, st, g);
+    else if (epi == EPI_STORE && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_STORE, 1>), grid, block, 0, st, g);
     else if (epi == EPI_ROWSQ && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_ROWSQ, 1>), grid, block, 0, st, g);
     else if (epi == EPI_STORE) hipLaunchKernelGGL(gemm_nt_kernel<EPI_STORE>, grid, block, 0, st, g);
     else if (epi == EPI_KERNEL && p.bm == 32 && p.tiles && p.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_KERNEL, 1, 16>), grid, block, 0, st, g);

@@ -142,7 +142,8 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                double *G /*[Nall][maxnn][4] or null*/, const int *aux, const unsigned short *T,
                                int t_stride, const int *cidx, const unsigned long long *hm, int hmw,
                                double *F /*[2][Nall][3]: atomic part | own part*/,
-                               double *virial /*[9][workgroups]*/, hipStream_t st, const RowsBatch *rows = nullptr);
+                               double *virial /*[9][workgroups]*/, hipStream_t st, const RowsBatch *rows = nullptr,
+                               const struct GemmParams *cov = nullptr /*covloss tiles (EPI_ROWSQ, 32-row, 16-deep) to run in the same launch*/);
 
 // Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
 void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,

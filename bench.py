@@ -89,7 +89,10 @@ def algorithmic_bytes(N, nn, D, m, cs):
         "list_forward": N * nn * 44 + 8 * N * D + N * nn * (8 + 32) + 8 * N * cs,
         "gemm_knm": 8 * N * D + 8 * m * D + 8 * N * m,
         "gemm_w_covloss": 8 * N * m + 8 * m * D + 8 * N * D + 8 * N * m + 8 * m * m,
+        "gemm_w": 8 * N * m + 8 * m * D + 8 * N * D,
         "descriptor_rev": 2 * 8 * N * D + 8 * N * cs + N * nn * 32 + N * nn * 32 + 24 * N,
+        # (the covloss tiles ride in the reverse kernel's launch: K and choli read once more, row sums out)
+        "descriptor_rev_covloss": 2 * 8 * N * D + 8 * N * cs + N * nn * 32 + N * nn * 32 + 24 * N + 8 * N * m + 8 * m * m,
         "finalize": N * nn * 32 + 24 * N + 32 * N,
     }
 
@@ -105,7 +108,7 @@ def algorithmic_flops(atom_z, ind_z, Dpad, world=1):
         knm += 2.0 * n_s * m_s * Dpad
         w += 2.0 * n_s * m_s * Dpad
         cov += n_s * m_s * m_s
-    return {"gemm_knm": knm, "gemm_w_covloss": w + cov}
+    return {"gemm_knm": knm, "gemm_w_covloss": w + cov, "gemm_w": w, "covloss": cov}
 
 
 def calculate_wall_big(device, sigma):
@@ -406,6 +409,8 @@ def main():
         # algorithmic bytes of THIS formulation: packed rows (Dc) and only this rank's atoms
         cs = dims["S"] * 64
         ab = algorithmic_bytes(cnt, nn_mean, Dc, m, cs)
+        rev_key = "descriptor_rev_covloss" if "descriptor_rev_covloss" in stage_ms else "descriptor_rev"
+        w_key = "gemm_w" if "gemm_w" in stage_ms else "gemm_w_covloss"
         dom = max((k for k in stage_ms if k in ab), key=lambda k: stage_ms[k])
         dom_s = stage_ms[dom] * 1e-3
         # HBM traffic of the dominant kernel: PMC counters cannot be read inside this run (rocprofv3 --pmc
@@ -444,16 +449,17 @@ def main():
             # against the HBM roofline with their algorithmic bytes, the GEMMs against the fp64 MFMA peak
             **{k + "_us": round(v * 1e3, 2) for k, v in stage_ms.items()},
             "desc_fwd_GBs": round(ab["list_forward"] / (stage_ms["list_forward"] * 1e-3) / 1e9, 1) if stage_ms.get("list_forward") else None,
-            "desc_rev_GBs": round(ab["descriptor_rev"] / (stage_ms["descriptor_rev"] * 1e-3) / 1e9, 1) if stage_ms.get("descriptor_rev") else None,
-            "desc_hbm_frac": round((ab["list_forward"] + ab["descriptor_rev"]) /
-                                   ((stage_ms.get("list_forward", 0) + stage_ms.get("descriptor_rev", 0)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-            if stage_ms.get("list_forward") and stage_ms.get("descriptor_rev") else None,
+            "desc_rev_GBs": round(ab[rev_key] / (stage_ms[rev_key] * 1e-3) / 1e9, 1) if stage_ms.get(rev_key) else None,
+            "desc_hbm_frac": round((ab["list_forward"] + ab[rev_key]) /
+                                   ((stage_ms.get("list_forward", 0) + stage_ms.get(rev_key, 0)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if stage_ms.get("list_forward") and stage_ms.get(rev_key) else None,
             "desc_valu_frac": (pmc or {}).get("desc_valu_frac"),
             "desc_valu_note": (pmc or {}).get("desc_valu_note"),
             "knm_TFs": round(af["gemm_knm"] / (stage_ms["gemm_knm"] * 1e-3) / 1e12, 2) if stage_ms.get("gemm_knm") else None,
-            "wcov_TFs": round(af["gemm_w_covloss"] / (stage_ms["gemm_w_covloss"] * 1e-3) / 1e12, 2) if stage_ms.get("gemm_w_covloss") else None,
+            "wcov_TFs": round(af[w_key] / (stage_ms[w_key] * 1e-3) / 1e12, 2) if stage_ms.get(w_key) else None,
+            "gemm_phase_us": round(sum(stage_ms.get(k, 0.0) for k in ("gemm_knm", "gemm_w", "gemm_w_covloss")) * 1e3, 2),
             "knm_frac": round(af["gemm_knm"] / (stage_ms["gemm_knm"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4) if stage_ms.get("gemm_knm") else None,
-            "wcov_frac": round(af["gemm_w_covloss"] / (stage_ms["gemm_w_covloss"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4) if stage_ms.get("gemm_w_covloss") else None,
+            "wcov_frac": round(af[w_key] / (stage_ms[w_key] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4) if stage_ms.get(w_key) else None,
             "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
             "gemm_TFLOPs": {k: round(af[k] / (stage_ms[k] * 1e-3) / 1e12, 2) for k in af if stage_ms.get(k)},
             "hbm_GBs": {k: round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) for k in ab if stage_ms.get(k)},
