@@ -464,14 +464,16 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     // slots; what lies beyond the count is masked after the load): one cold miss less on the chain
     // (frames of a few thousand atoms are bound by this chain; large ones by bytes, and the slots beyond the count are
     // a third of the row: there the count is read first)
-    const bool spec = f.N <= 16384;
+    // (training rows: only the neighbours of the column's species carry a gradient — their slots are picked out after the
+    // list's code words are known, not the whole row on speculation)
+    const bool spec = f.N <= 16384 && !f.row_cols;
     double2 g0 = make_double2(0.0, 0.0), g1 = make_double2(0.0, 0.0);
     if (spec && lane < f.maxnn) {
         const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + lane) * 4);
         g0 = row[0]; g1 = row[1];
     }
     const int n = f.nn[i];
-    if (!spec && lane < n) {
+    if (!spec && lane < n && !f.row_cols) {
         const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + lane) * 4);
         g0 = row[0]; g1 = row[1];
     }
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
         const int t = t0 + lane;
         if (t < n && (want < 0 || ((f.nbr_code[(size_t)i * f.maxnn + t] >> 24) & 0xff) == want)) {
             double2 b0 = g0, b1 = g1;
-            if (t0 > 0) {
+            if (t0 > 0 || (!spec && want >= 0)) {
                 const double2 *row = (const double2 *)(f.G + by * f.g_stride + ((size_t)i * f.maxnn + t) * 4);
                 b0 = row[0]; b1 = row[1];
             }

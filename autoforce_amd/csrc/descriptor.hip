@@ -1146,9 +1146,13 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
     double *R = dcl + ST * NSLOT;                 // shared scratch region (a.rsz doubles)
     int *sl = (int *)(R + a.rsz);                 // [CH] species slot per tile row
     const int gi = a.first + (active ? ia : 0) * a.stride;
-    const int nn = active ? a.nn[gi] : 0;
     // batch entry (training rows): column, seed scale and output bases
     const int bq = ROWS ? a.rows_cols[blockIdx.y] : 0;
+    // training rows: k(i, q) is identically zero for an atom of another species than the column's — the wave has no
+    // pair gradient to hand over (the last kernel only reads the slots written by atoms of the column's species) and
+    // goes straight to the tail, where it contributes zeros to the own-force and virial sums
+    const bool off_species = ROWS && active && a.slot[gi] != a.rows_colslot[bq];
+    const int nn = (active && !off_species) ? a.nn[gi] : 0;
     const double aw_q = (ROWS && active) ? rows_aw[(size_t)ia * a.rows_ld + bq] : 1.0;
     double *Gb = a.G, *Fnbr_b = a.Fnbr, *Fself_b = a.Fself, *vir_b = a.vir_part;
     if constexpr (ROWS) {
