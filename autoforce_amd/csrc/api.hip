@@ -1592,11 +1592,17 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         }
     }
     if (h->warm && h->pin && !cov) {
+        static const bool tl = getenv("SGPR_COMPUTE_TIMELINE") != nullptr;  // diagnostic: host-side timeline of the warm path
+        auto nowus = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+        double tls[6] = {0, 0, 0, 0, 0, 0};
+        if (tl) tls[0] = nowus();
         double *pi = h->pin, *po = h->pin + n_in;
         memcpy(pi, positions, sizeof(double) * 3 * N);
         memcpy(pi + 3 * (size_t)N, cell, sizeof(double) * 9);
         // positions and cell travel as ONE copy (a second 72-byte copy is a whole DMA command of its own)
+        if (tl) tls[1] = nowus();
         HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
+        if (tl) tls[2] = nowus();
         // single rank: the last kernel writes the packed results straight into the page-locked buffer (host memory
         // mapped into the device's address space: posted PCIe writes inside the kernel) — no device-to-host copy
         // command behind the step, one synchronisation point less on the way out (option "zero_copy_out")
@@ -1605,6 +1611,7 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         if (!rf) rf = reduce_packed(h, h->d_packed.p, h->stream);
         if (rf) return rf;
         if (!direct) HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+        if (tl) tls[3] = nowus();
         if (h->spin_wait) {  // option "spin_wait": poll the stream instead of a blocking wait
             hipError_t q;
             while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {}
@@ -1612,11 +1619,23 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         } else
             HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
+        if (tl) tls[4] = nowus();
         if (po[4 * (size_t)N + 10] == 0.0) {
             if (forces) memcpy(forces, po, sizeof(double) * 3 * N);
             if (beta) memcpy(beta, po + 3 * (size_t)N, sizeof(double) * N);
             if (energy) *energy = po[4 * (size_t)N];
             if (stress) sgpr_stress_from_virial(po + 4 * (size_t)N + 1, cell, stress);
+            if (tl) {
+                tls[5] = nowus();
+                static double acc[5] = {0, 0, 0, 0, 0};
+                static int cnt = 0;
+                for (int k = 0; k < 5; k++) acc[k] += tls[k + 1] - tls[k];
+                if (++cnt % 200 == 0) {
+                    fprintf(stderr, "[sgpr timeline] warm sgpr_compute, mean of 200 (us): copy in %.1f | H2D enqueue %.1f | kernels enqueue %.1f | wait %.1f | copy out %.1f\n",
+                            acc[0] / 200, acc[1] / 200, acc[2] / 200, acc[3] / 200, acc[4] / 200);
+                    for (double &v : acc) v = 0.0;
+                }
+            }
             return SGPR_OK;
         }
         h->warm = false;  // a capacity overflowed (or the cell is degenerate): the checked path sorts it out

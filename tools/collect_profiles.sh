@@ -4,12 +4,17 @@
 tag=$1; note=$2
 cd $GRAFT_REPO_ROOT
 bash tools/prof.sh ${tag}_final > gpurun_out/${tag}_final_kstats.txt 2>&1
-bash tools/pmc.sh ${tag}_pmc_fetch FETCH_SIZE > gpurun_out/${tag}_pmc_fetch.txt 2>&1
-bash tools/pmc.sh ${tag}_pmc_write WRITE_SIZE > gpurun_out/${tag}_pmc_write.txt 2>&1
+bash tools/pmc.sh ${tag}_pmc_fetch FETCH_SIZE --no-big-wall > gpurun_out/${tag}_pmc_fetch.txt 2>&1
+bash tools/pmc.sh ${tag}_pmc_write WRITE_SIZE --no-big-wall > gpurun_out/${tag}_pmc_write.txt 2>&1
 f=$(ls gpurun_out/${tag}_pmc_fetch/*/*counter_collection.csv | head -1)
 w=$(ls gpurun_out/${tag}_pmc_write/*/*counter_collection.csv | head -1)
-python3 tools/pmc_json.py $f $w gpurun_out/${tag}_pmc_traffic_lips4096_m512.json "$note" > /dev/null
-bash tools/pmc_mfma.sh ${tag}_pmc_mfma bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_pmc_mfma_summary.txt 2>&1
+bash tools/pmc.sh ${tag}_pmc_sq "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY" > gpurun_out/${tag}_pmc_sq.txt 2>&1
+bash tools/pmc.sh ${tag}_pmc_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" > gpurun_out/${tag}_pmc_lds.txt 2>&1
+q=$(ls gpurun_out/${tag}_pmc_sq/*/*counter_collection.csv | head -1)
+qt=$(ls gpurun_out/${tag}_pmc_sq/*/*kernel_trace.csv | head -1)
+python3 tools/pmc_json.py $f $w gpurun_out/${tag}_pmc_traffic_lips4096_m512.json "$note" $q $qt > /dev/null
+cp gpurun_out/${tag}_pmc_sq.txt gpurun_out/${tag}_pmc_sq_summary.txt; tail -n +2 gpurun_out/${tag}_pmc_lds.txt >> gpurun_out/${tag}_pmc_sq_summary.txt
+bash tools/pmc_mfma.sh ${tag}_pmc_mfma bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-big-wall > gpurun_out/${tag}_pmc_mfma_summary.txt 2>&1
 cp $(ls gpurun_out/${tag}_final/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats_lips4096_m512.csv
 cat gpurun_out/${tag}_final_kstats.txt | tail -12
 cat gpurun_out/${tag}_pmc_mfma_summary.txt | tail -8

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """profiles/rNN_pmc_traffic_*.json from two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE):
-median per-launch bytes per kernel.  usage: pmc_json.py <fetch.csv> <write.csv> <out.json> [source note]"""
+median per-launch bytes per kernel.  usage: pmc_json.py <fetch.csv> <write.csv> <out.json> [source note] [sq.csv kernel_trace.csv]
+With the SQ pass (SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_ANY, SQ_INSTS_VALU, ... of tools/collect_profiles.sh) and its kernel
+trace: per-kernel issue statistics, and `desc_valu_frac` = the share of the SIMDs' cycles in which the two descriptor
+kernels (list + forward, reverse) had a vector instruction executing."""
 import csv, json, statistics as st, sys
 from collections import defaultdict
 
@@ -48,5 +51,50 @@ out = {
     "kernels": {k: {"fetch": fetch[k], "write": write.get(k, 0.0), "fetch_x2_plus_write": 2 * fetch[k] + write.get(k, 0.0)}
                 for k in fetch},
 }
+if len(sys.argv) > 6:
+    # SQ_ACTIVE_INST_* count quad-cycles summed over all waves (MI355X_MICROARCH.md): x4 = SIMD cycles with such an
+    # instruction executing; the chip has 256 CUs x 4 SIMDs; kernel cycles = duration x the clock the pass held
+    # (GRBM_GUI_ACTIVE is not in this pass: 2.4 GHz nominal is used and stated)
+    sq = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(sys.argv[5])):
+        name = r["Kernel_Name"].replace("void ", "")
+        for pat, stage in STAGE:
+            if name.startswith(pat):
+                sq[stage][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                break
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[6])):
+        name = r["Kernel_Name"].replace("void ", "")
+        for pat, stage in STAGE:
+            if name.startswith(pat):
+                dur[stage].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                break
+    CLK, SIMDS = 2.4e9, 1024
+    issue = {}
+    for stage, c in sq.items():
+        if stage not in dur or len(dur[stage]) < 10:
+            continue
+        med = {k: st.median(v) for k, v in c.items()}
+        cyc = st.median(dur[stage]) * 1e-9 * CLK * SIMDS
+        waves = None
+        issue[stage] = {
+            "duration_us_in_this_pass": round(st.median(dur[stage]) * 1e-3, 2),
+            "valu_busy_frac": round(4 * med.get("SQ_ACTIVE_INST_VALU", 0.0) / cyc, 3),
+            "issue_busy_frac": round(4 * med.get("SQ_ACTIVE_INST_ANY", 0.0) / cyc, 3) if "SQ_ACTIVE_INST_ANY" in med else None,
+            "wave_wait_mem_frac": round(med.get("SQ_WAIT_ANY", 0.0) / max(med.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
+            "wave_wait_issue_frac": round(med.get("SQ_WAIT_INST_ANY", 0.0) / max(med.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
+            "insts_valu": med.get("SQ_INSTS_VALU"), "insts_salu": med.get("SQ_INSTS_SALU"), "insts_lds": med.get("SQ_INSTS_LDS"),
+            "lds_bank_conflict_frac": round(med["SQ_LDS_BANK_CONFLICT"] / max(med.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0), 3)
+            if "SQ_LDS_BANK_CONFLICT" in med else None,
+        }
+    out["issue"] = issue
+    dk = [k for k in ("list_forward", "descriptor_rev") if k in issue]
+    if dk:
+        tot = sum(issue[k]["duration_us_in_this_pass"] for k in dk)
+        out["desc_valu_frac"] = round(sum(issue[k]["valu_busy_frac"] * issue[k]["duration_us_in_this_pass"] for k in dk) / tot, 3)
+        out["desc_issue_frac"] = round(sum((issue[k]["issue_busy_frac"] or 0.0) * issue[k]["duration_us_in_this_pass"] for k in dk) / tot, 3)
+        out["desc_valu_note"] = ("SQ pass of tools/collect_profiles.sh: 4 x SQ_ACTIVE_INST_VALU / (kernel duration x 2.4 GHz x 1024 SIMDs), "
+                                 "time-weighted over nl_fwd and desc_rev; desc_issue_frac the same with SQ_ACTIVE_INST_ANY: these kernels "
+                                 "are bound by instruction issue and dependent latencies, not by HBM bytes")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

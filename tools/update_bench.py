@@ -45,7 +45,14 @@ tm("add_1inducing trial (add, refit, energy_of x2, [pop, refit])", lambda: post.
 tm("add_data (1 frame: rows for m columns + refit)", lambda: post.add_data([frames[nfr]]))
 tm("pop_1data (+ refit)", post.pop_1data)
 tm("add_1atoms_fast trial (push, refit, 2 products, [pop, refit])", lambda: post.add_1atoms_fast(frames[nfr], 1e9, 1e9))
-tm("make_munu(algo=3) (noise search: 1 force-only factor + ~15 resolves)", lambda: post.make_munu(algo=3, noise_f=0.05))
+tm("make_munu(algo=3) (noise search: 1 force-only factor + batched scans)", lambda: post.make_munu(algo=3, noise_f=0.05))
+# downsize(lii=True) at the size limit: the m LCEs with the smallest K_mm row sums, in argsort order (a permutation)
+post.add_inducing(X[m])
+tm("downsize(lii=True) m+1 -> m (select through the kept reflectors + refit)", lambda: post.downsize(1e9, m, first=True, lii=True))
+print("   ", mdl.solve_info())
+post.add_inducing(X[m])
+tm("remove an LCE in the middle (+ refit)", lambda: (post.select_inducing([i for i in range(len(post.X)) if i != 7])))
+print("   ", mdl.solve_info())
 os.environ["SGPR_SOLVE_TIMING"] = "1"
 if os.environ.get("SGPR_PROFILE_OPT"):
     import cProfile, pstats
