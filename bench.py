@@ -463,10 +463,10 @@ def main():
             "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
             "gemm_TFLOPs": {k: round(af[k] / (stage_ms[k] * 1e-3) / 1e12, 2) for k in af if stage_ms.get(k)},
             "hbm_GBs": {k: round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) for k in ab if stage_ms.get(k)},
-            "step_bytes_this_formulation": sum(ab.values()),
+            "step_bytes_this_formulation": sum(v for k, v in ab.items() if k in stage_ms),
             "step_bytes_survey_formula": survey_step_bytes(cnt, nn_mean, dims["D"] * dims["S"] ** 2, m),
             "step_GBs_survey_formula": survey_step_bytes(cnt, nn_mean, dims["D"] * dims["S"] ** 2, m) / (ms_per_step * 1e-3) / 1e9,
-            "pass_GBs_packed": sum(ab.values()) / (sum(stage_ms[k] for k in ab if k in stage_ms) * 1e-3) / 1e9,
+            "pass_GBs_packed": sum(v for k, v in ab.items() if k in stage_ms) / (sum(stage_ms[k] for k in ab if k in stage_ms) * 1e-3) / 1e9,
         }
         result = {
             "metric": "MD-step atoms*steps/sec (SGPR predict: NL + descriptors + K_nm + E/F/stress + covloss)",
