@@ -291,13 +291,25 @@ int sgpr_sync_check(sgpr_model *h, void *stream);
  *                           environment variable SGPR_QR_KEEP sets the initial value.
  *  "skin_milliangstrom"     Verlet skin of the neighbour candidates (default 500 = 0.5 A).  The reference asks ASE
  *                           for a list with skin 0 at every step (descriptor/atoms.py:349-355); here candidate
- *                           lists of |r| < rc + skin are kept and rebuilt ON THE DEVICE whenever an atom has moved
- *                           more than skin/2 since the last build or the cell changed, and every step filters them
- *                           to |r| < rc: the same pairs in the same order as a from-scratch list, bit for bit.
- *                           0 = rebuild every step
+ *                           lists of |r| < rc + skin are kept and rebuilt ON THE DEVICE whenever an atom's
+ *                           displacement since the last build — measured against the affine image of its build-time
+ *                           position when the cell has changed (NPT: cl/md.py:147-150) — exceeds
+ *                           (sigma_min(h0^-1 h) (rc + skin) - rc) / 2 (= skin/2 at constant cell), and every step
+ *                           filters them to |r| < rc: the same pairs in the same order as a from-scratch list, bit
+ *                           for bit.  0 = rebuild every step
  *  "ignore_unknown_species" = 0/1  atoms and LCE neighbours outside the species table are invisible
  *                           (descriptor/sesoap.py:343-346) instead of SGPR_E_SPECIES
  *  "overlap" = 0/1          covloss product on a side stream (measured slower; default 0)
+ *  "cov_in_rev" = 0/1       covloss tiles in the reverse kernel's launch instead of grouped with the W product
+ *                           (measured slower at 4096 atoms: default 0).  Environment: SGPR_COV_IN_REV
+ *  "zero_copy_out" = 1/0    single-rank sgpr_compute: the step's last kernel writes its results into mapped
+ *                           page-locked host memory instead of a device buffer that is copied back (default 1).
+ *                           Environment: SGPR_ZERO_COPY
+ *  "lone_atom_weight" = k   k(x, x') of two lone atoms (no neighbour inside the cutoff) of one species: the
+ *                           reference adds that term once per kernel OBJECT (similarity/similarity.py:38-40, :94-103)
+ *                           and sums its kernels (regression/gppotential.py:63-84) — 1 for the wildcard kernel
+ *                           (default), S for the list of S fixed-species kernels of calculator/active.py:31-38.
+ *                           Set before the inducing set.
  *  "spin_wait" = 1/0        sgpr_compute polls its stream for the end of a step instead of a blocking wait
  *                           (default 1: one host thread spins for the ~0.1 ms of a step, 16 us less wall time per
  *                           call on a 4096-atom frame; 0: hipStreamSynchronize).  Environment: SGPR_SPIN_WAIT */
