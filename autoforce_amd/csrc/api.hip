@@ -406,7 +406,13 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
             if (*f.flag) {
                 atomicAdd(f.rebuilds, 1);
                 if (f.cell0 && f.cell) {
-                    for (int k = 0; k < 9; k++) { f.cell0[k] = f.cell[k]; f.cell0[9 + k] = f.grid->inv[k]; }
+                    // (all eighteen values in registers before the first store: store-by-store the compiler must assume
+                    // aliasing and serialises eighteen memory round trips on this one lane)
+                    double cv[18];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) { cv[k] = f.cell[k]; cv[9 + k] = f.grid->inv[k]; }
+#pragma unroll
+                    for (int k = 0; k < 18; k++) f.cell0[k] = cv[k];
                 }
             }
             const int mx = (int)fmax(fmax(wsum[0], wsum[1]), fmax(wsum[2], wsum[3]));

@@ -150,9 +150,19 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         char *cache = (char *)a.grid + 256;
         const NlGrid *g_prev = (const NlGrid *)(cache + 256 * (a.parity ^ 1));
         const double *c_prev = (const double *)(cache + 256 * (a.parity ^ 1) + 128);
-        const NlGrid gp = *g_prev;  // requested together with the two cells, not behind their comparison
-        bool same = a.force == 0;
-        for (int k = 0; k < 9; k++) same = same && a.cell[k] == c_prev[k];
+        // EVERYTHING this lane compares is requested first and compared without short-circuits: `same && cell[k] ==
+        // prev[k]` compiled to nine load -> wait -> branch round trips one behind the other (ISA), i.e. nine cold misses
+        // in a row on the one lane the other 255 wait for at the barrier
+        const NlGrid gp = *g_prev;
+        double cc[9], cp[9], c0[18];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { cc[k] = a.cell[k]; cp[k] = c_prev[k]; }
+#pragma unroll
+        for (int k = 0; k < 18; k++) c0[k] = a.cell0[k];
+        int same_i = a.force == 0, cell_same_i = 1;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { same_i &= (cc[k] == cp[k]) ? 1 : 0; cell_same_i &= (cc[k] == c0[k]) ? 1 : 0; }
+        const bool same = same_i != 0, cell_same = cell_same_i != 0;
         if (same) g = gp;
         else nl_make_grid(a.cell, a.pbc, a.rc, g, wg == 0 ? a.stat : nullptr);
         // Candidates under a CHANGED cell (NPT: cl/md.py:147-150 strains the cell every step).  With A = h0^-1 h
@@ -160,17 +170,15 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         // candidates (|r0| >= rc + skin) has |r| >= sigma_min(A) (rc + skin) - |u_i| - |u_j|, so the lists stay
         // complete while every |u_i| <= (sigma_min(A) (rc + skin) - rc) / 2; sigma_min(A) >= 1 - |A - I|_F.
         // Same cell bit for bit: A = I and the bound is skin / 2.  Open directions keep the strict rule.
-        bool cell_same = true;
-        for (int k = 0; k < 9; k++) cell_same = cell_same && a.cell[k] == a.cell0[k];
         double thr = 0.5 * (a.rc_list - a.rc_phys);
         for (int k = 0; k < 9; k++) Aff[k] = (k % 4 == 0) ? 1.0 : 0.0;
         if (!cell_same) {
             if (a.pbc[0] && a.pbc[1] && a.pbc[2]) {
-                const double *iv = a.cell0 + 9;
+                const double *iv = c0 + 9;
                 double fro = 0.0;
                 for (int r = 0; r < 3; r++)
                     for (int c = 0; c < 3; c++) {
-                        const double v = iv[3 * r] * a.cell[c] + iv[3 * r + 1] * a.cell[3 + c] + iv[3 * r + 2] * a.cell[6 + c];
+                        const double v = iv[3 * r] * cc[c] + iv[3 * r + 1] * cc[3 + c] + iv[3 * r + 2] * cc[6 + c];
                         Aff[3 * r + c] = v;
                         const double d = v - (r == c ? 1.0 : 0.0);
                         fro += d * d;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         if (wg == 0) {
             *a.grid = g;
             *(NlGrid *)(cache + 256 * a.parity) = g;
-            for (int k = 0; k < 9; k++) ((double *)(cache + 256 * a.parity + 128))[k] = a.cell[k];
+            for (int k = 0; k < 9; k++) ((double *)(cache + 256 * a.parity + 128))[k] = cc[k];
             // rebuild decision, part 1: forced, or the cell moved too far from the one the candidates were built
             // in (below); the other parity's flag is cleared for the next step (nobody reads it during this one)
             if (a.force != 0 || !(thr2 > 0.0)) atomicMax(&a.flag[a.parity], 1);

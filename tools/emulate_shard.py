@@ -24,7 +24,8 @@ for world in worlds:
         for _ in range(300):
             _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
         torch.cuda.synchronize()
-        print(f"world={world} rank0 share, graph={graph}: {(time.perf_counter()-t0)/300*1e6:.1f} us/step")
+        rb = C.c_int64(0); _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb)))
+        print(f"world={world} rank0 share, graph={graph}: {(time.perf_counter()-t0)/300*1e6:.1f} us/step (list rebuilds so far: {rb.value})")
     if world > 1:
         mdl.profile(True)
         acc = {}
