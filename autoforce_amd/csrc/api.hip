@@ -266,6 +266,7 @@ struct sgpr_model {
                              // into a second round)
     int gemm_bm_k = 64, gemm_bm_w = 64;  // rows per tile of t_knm  /  t_w, t_cov, t_wcov
     int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
+    int gemm_waves_k = 8;                // waves per K_nm tile (SGPR_GEMM_WAVES=4: the four-wave form)
     std::vector<int4> h_t_w, h_t_cov;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -621,6 +622,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
     if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
@@ -852,6 +854,7 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
     g.tiles = tiles.p; g.ntiles = (int)tiles.n;
     g.bm = (&tiles == &h->t_kmm) ? 64 : h->gemm_bm_k;
     g.kd = h->gemm_kd_k;
+    g.waves = (&tiles == &h->t_knm && h->gemm_bm_k == 32 && h->gemm_kd_k == 16) ? h->gemm_waves_k : 4;
     g.eta = h->eta; g.lone_m1 = h->lone_w - 1.0; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
     g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
@@ -1127,7 +1130,8 @@ static int alloc_work(sgpr_model *h)
         bad |= h->d_K.alloc((size_t)cr * h->m_pad);   // zero-filled: off-species entries are never written
         bad |= h->d_Aw.alloc((size_t)cr * h->m_pad);
         if (build_tiles(h, 0) || build_tiles(h, 1) || build_tiles(h, 2)) bad = 1;
-        h->epart_len = 4 * (int)h->t_knm.n;  // one partial per wave of every K_nm tile
+        h->epart_len = 8 * (int)h->t_knm.n;  // one partial per wave of every K_nm tile (four- or eight-wave form: the
+                                             // unused half of a four-wave tile's eight slots stays zero)
         bad |= h->d_Epart.alloc(std::max(h->epart_len, 1));
     } else
         h->epart_len = 0;

@@ -14,10 +14,11 @@
 // by the allocator (api.hip), so the main loop carries no bounds checks.
 //
 // Tile: 64x64 (TM = 2) or 32x64 (TM = 1) per 256-thread workgroup, 4 waves as 2x2, each wave TM x 2 MFMA tiles;
-// K stages through LDS, fetched two stages ahead through registers.  The three products of a step run on the 32-row
+// K stages through LDS, fetched ahead through registers.  The three products of a step run on the 32-row
 // form with 16-deep stages (KD = 16): THREE stages in 36 KB of XOR-swizzled LDS, one barrier per stage, stores and
-// loads issued in the shadow of the MFMAs, four workgroups per CU; K_mm, the Cholesky trailing update and dense
-// launches keep the 64-row form with two 32-deep stages.  Every form accumulates a dot product over k in the same
+// loads issued in the shadow of the MFMAs, four (W + covloss: four register sets, loads 3.5 stages ahead) or two
+// (K_nm: the eight-wave form of gemm_tile.inc, six sets, 5.5 stages ahead) workgroups per CU; K_mm, the Cholesky
+// trailing update and dense launches keep the 64-row form with two 32-deep stages.  Every form accumulates a dot product over k in the same
 // order: the results do not depend on the tile shape (tests/test_hip_paths.py::test_gemm_tile_shapes_agree_bit_for_bit).
 // Measured alternatives on the 4096 x 512 x 320 K_nm product: LDS-free fragment-shaped direct loads 35 us (TA-bound:
 // each quad of lanes touches four cache lines); a 16-row panel against 256 columns per workgroup (one wave per SIMD)
@@ -33,6 +34,15 @@ __global__ __launch_bounds__(256, KD == 16 ? 4 : 2) void gemm_nt_kernel(GemmArgs
     __shared__ double As[L::NBUF * L::ASZ];
     __shared__ double Bs[L::NBUF * L::BSZ];
     gemm_tile_body<EPI, TM, KD>(g, (int)blockIdx.x, As, Bs);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel8(GemmArgs g)
+{
+    using L = GemmLds<EPI, 1, 16>;
+    __shared__ double As[L::NBUF * L::ASZ];
+    __shared__ double Bs[L::NBUF * L::BSZ];
+    gemm_tile_body8<EPI>(g, (int)blockIdx.x, As, Bs);
 }
 
 void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st)
@@ -65,6 +75,11 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
     g.rows_pad = (g.row_tiles + 7) / 8 * 8;
     dim3 grid(p.tiles ? p.ntiles : g.rows_pad * g.col_tiles), block(256);
     if (p.tiles && p.ntiles <= 0) return;
+    if (p.waves == 8 && p.bm == 32 && p.tiles && p.kd == 16 && (epi == EPI_KERNEL || epi == EPI_STORE)) {
+        if (epi == EPI_KERNEL) hipLaunchKernelGGL(gemm_nt_kernel8<EPI_KERNEL>, grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL(gemm_nt_kernel8<EPI_STORE>, grid, dim3(512), 0, st, g);
+        return;
+    }
     if (epi == EPI_STORE && p.bm == 32 && p.tiles && p.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_STORE, 1, 16>), grid, block, 0, st, g);
     else if (epi == EPI_ROWSQ && p.bm == 32 && p.tiles && p.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_ROWSQ, 1, 16>), grid, block, 0, st, g);
     else if (epi == EPI_STORE && p.bm == 32 && p.tiles) hipLaunchKernelGGL((gemm_nt_kernel<EPI_STORE, 1>), grid, block, 0, st, g);

@@ -205,24 +205,26 @@ def test_candidate_lists_are_reused_without_changing_anything(name):
     fast.close(); slow.close()
 
 
-@pytest.mark.parametrize("shape", ["64,64;32,32", "32,32;32,32", "32,32;16,16"])
+@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4"])
 def test_gemm_tile_shapes_agree_bit_for_bit(shape, monkeypatch):
     """The three products of a step (K_nm, W, covloss) run on 32x64 tiles with 16-deep LDS stages; the 64-row form and the
     32-deep stages stay compiled in for K_mm, dense launches and the forked path.  Every form accumulates a dot product
     over k in the same order (one MFMA k-step of 4 after the other), so K_nm, forces, stress and beta must not move
-    by a single bit when the tile tables are built for another shape (diagnostic overrides SGPR_GEMM_BM / SGPR_GEMM_KD)."""
+    by a single bit when the tile tables are built for another shape (diagnostic overrides SGPR_GEMM_BM / SGPR_GEMM_KD),
+    nor when a K_nm tile is shared by four waves (two 16 x 16 blocks each) instead of eight (SGPR_GEMM_WAVES)."""
     rng = np.random.default_rng(31)
     species = [3, 15, 16]
     numbers, pos, cell = random_frame(rng, 300, 16.0, species)
     pbc = [True] * 3
     outs = []
-    for bm, kd in ((None, None), shape.split(";")):
+    for bm, kd, waves in ((None, None, None), shape.split(";")):
         if bm is None:
-            monkeypatch.delenv("SGPR_GEMM_BM", raising=False)
-            monkeypatch.delenv("SGPR_GEMM_KD", raising=False)
+            for k in ("SGPR_GEMM_BM", "SGPR_GEMM_KD", "SGPR_GEMM_WAVES"):
+                monkeypatch.delenv(k, raising=False)
         else:
             monkeypatch.setenv("SGPR_GEMM_BM", bm)
             monkeypatch.setenv("SGPR_GEMM_KD", kd)
+            monkeypatch.setenv("SGPR_GEMM_WAVES", waves)
         mdl, nl = build(3, 3, 4, 6.0, species, numbers, pos, cell, pbc, 90, seed=5)
         mu = np.random.default_rng(9).normal(size=len(mdl.X))
         mdl.solve(np.random.default_rng(2).normal(size=(40, len(mdl.X))), np.random.default_rng(3).normal(size=40))
