@@ -166,7 +166,12 @@ struct sgpr_model {
     DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
     DevBuf<double> d_rows_bG, d_rows_bF, d_rows_bV;     // (batch of columns: G, [Fnbr | Fself], virial partials)
     DevBuf<double> d_rows_kepart;                       // (K_e: per-chunk column sums)
-    DevBuf<int> d_rows_cols;
+    DevBuf<int> d_rows_cols, d_rows_rowof, d_rows_qoff;
+    DevBuf<double> d_rows_vpart;
+    bool rows16 = true;                                 // SGPR_ROWS16=0: one column per wave for every rows call
+    int rows16_mb = 6144;                               // hand-over buffer of the sixteen-column form (SGPR_ROWS16_MB)
+    int rows16_min = 1;                                 // fewest columns of a call that take it (SGPR_ROWS16_MIN; 1: a column has the same bits whatever call computed it)
+    const char *info_rows = "none yet";                 // form of the last rows call (sgpr_solve_info)
     std::vector<int> rows_cols;
     // resident training set (data.inc): the design matrix [K_e; K_f; K_v] of the stored frames, column-major in the
     // caller's column order, design[c * design_rcap + r]; rows in frame-major blocks (e, 3N f, nv v)
@@ -267,6 +272,8 @@ struct sgpr_model {
     int gemm_bm_k = 64, gemm_bm_w = 64;  // rows per tile of t_knm  /  t_w, t_cov, t_wcov
     int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
     int gemm_waves_k = 8;                // waves per K_nm tile (SGPR_GEMM_WAVES=4: the four-wave form)
+    int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
+    bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
     std::vector<int4> h_t_w, h_t_cov;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -623,6 +630,14 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
+    if (const char *e = getenv("SGPR_TILE_BALANCE")) h->tile_balance = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_ROWS16")) h->rows16 = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_ROWS16_MB")) h->rows16_mb = std::max(1, atoi(e));
+    if (const char *e = getenv("SGPR_ROWS16_MIN")) h->rows16_min = std::max(1, atoi(e));
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && ncu >= 8) h->cus_per_xcd = ncu / 8;
+    }
     if (getenv("SGPR_STAMPS")) { h->d_stamps.alloc(8 * 4096); h->d_stamps2.alloc(8 * 8192); }
     if (const char *e = getenv("SGPR_QR_KEEP")) h->qr_keep_mode = std::min(std::max(atoi(e), 0), 2);
     *out = h;
@@ -702,6 +717,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                             &h->d_rows_bG, &h->d_rows_bF, &h->d_rows_bV, &h->d_rows_kepart, &h->d_design, &h->d_qr_A, &h->d_qr_work};
     for (auto b : db) b->release();
     h->d_rows_cols.release();
+    h->d_rows_rowof.release(); h->d_rows_qoff.release(); h->d_rows_vpart.release();
     if (h->pin) (void)hipHostFree(h->pin);
     {
         DevBuf<double> *sd[] = {&h->sc_s2A, &h->sc_s2x, &h->sc_s2work, &h->sc_mv_v, &h->sc_mv_o, &h->sc_ra_y, &h->sc_ra_t, &h->sc_vs_t,
@@ -740,6 +756,31 @@ extern "C" void sgpr_destroy(sgpr_model *h)
 // (cols = inducing, k = inducing range, clipped at the column tile when choli is lower-triangular);
 // 3: K_mm.  Entries are dealt to list positions so that position % 8 == row tile % 8 (XCD affinity);
 // holes are padding entries with kend = 0.
+// Order of one XCD's share of a tile table.  The dispatcher hands workgroup p to XCD p % 8 and, while every CU still has a
+// free slot, the XCD's j-th workgroup to its CU j % 32 (read off the HW_ID stamps of the grouped launch: the tiles at
+// table positions p, p + 256, p + 512, p + 768 share a CU).  A plain longest-first order therefore stacks the long
+// reductions: CU c gets sorted[c], sorted[c + 32], ... — at 4096 / 512 between 20 and 28 stages per CU around a mean of
+// 23.6.  Here every round of 32 goes to the CUs in the order of their load so far, the shortest tile of the round to the
+// most loaded CU (22 - 24 stages per CU).  Only the rounds that fill the free slots of an empty chip are placed; the rest
+// (and a last partial round) stay longest-first and run wherever a slot frees up.
+static void balance_xcd_share(std::vector<int4> &b, int ncu, int slots)
+{
+    std::stable_sort(b.begin(), b.end(), [](const int4 &p, const int4 &q) { return p.w - p.z > q.w - q.z; });
+    if (ncu <= 1) return;
+    std::vector<long long> load(ncu, 0);
+    std::vector<int> order(ncu);
+    for (int r = 0; r < slots && (size_t)(r + 1) * ncu <= b.size(); r++) {
+        for (int c = 0; c < ncu; c++) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return load[p] > load[q]; });
+        std::vector<int4> round(b.begin() + (size_t)r * ncu, b.begin() + (size_t)(r + 1) * ncu);  // descending
+        for (int k = 0; k < ncu; k++) {
+            const int4 t = round[ncu - 1 - k];  // ascending: the shortest to the most loaded
+            b[(size_t)r * ncu + order[k]] = t;
+            load[order[k]] += t.w - t.z;
+        }
+    }
+}
+
 static int build_tiles(sgpr_model *h, int kind)
 {
     const int KTc = 32;
@@ -806,8 +847,7 @@ static int build_tiles(sgpr_model *h, int kind)
             if (t.w > t.z) bk[t.x % 8].push_back(make_int4(t.x | (1 << 16), t.y, t.z, t.w));
         // longest reductions first (LPT): row tiles come in species order and the species with the most
         // inducing points — the deepest reductions — would otherwise form the tail of the launch
-        for (auto &b : bk)
-            std::stable_sort(b.begin(), b.end(), [](const int4 &p, const int4 &q) { return p.w - p.z > q.w - q.z; });
+        for (auto &b : bk) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, 4);
         size_t dp = 0;
         for (auto &b : bk) dp = std::max(dp, b.size());
         std::vector<int4> both(dp * 8, make_int4(0, 0, 0, 0));
@@ -817,8 +857,7 @@ static int build_tiles(sgpr_model *h, int kind)
             std::vector<std::vector<int4>> bc(8);
             for (const int4 &t : h->h_t_cov)
                 if (t.w > t.z) bc[t.x % 8].push_back(t);
-            for (auto &b : bc)
-                std::stable_sort(b.begin(), b.end(), [](const int4 &p, const int4 &q) { return p.w - p.z > q.w - q.z; });
+            for (auto &b : bc) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, 4);
             size_t dc = 0;
             for (auto &b : bc) dc = std::max(dc, b.size());
             std::vector<int4> only(dc * 8, make_int4(0, 0, 0, 0));

@@ -102,6 +102,51 @@ struct Harm {
         }
     }
 
+    // Y and its gradient with respect to (x, y, z), forward mode; prepare() must have run.  The recurrence state is
+    // q[l][m](z, rho) and A + iB = (x + iy)^m: dq/dz and dq/drho follow the same recurrences, dA/dx = m A[m-1],
+    // dA/dy = -m B[m-1], dB/dx = m B[m-1], dB/dy = m A[m-1], and rho = x^2 + y^2 + z^2 brings 2 (x, y, z) dq/drho.
+    // (The reverse-mode twin is backward(); the training-rows kernel needs the Jacobian itself, rows16.inc.)
+    __device__ __forceinline__ void eval_grad(double *Y, double *Yx, double *Yy, double *Yz) const
+    {
+        double qz[L1][L1], qr[L1][L1];
+#pragma unroll
+        for (int l = 0; l <= LMAX; l++)
+#pragma unroll
+            for (int m = 0; m <= LMAX; m++) { qz[l][m] = 0.0; qr[l][m] = 0.0; }
+#pragma unroll
+        for (int l = 1; l <= LMAX; l++) {
+#pragma unroll
+            for (int m = 0; m <= l - 2; m++) {
+                qz[l][m] = hc->al[l][m] * (q[l - 1][m] + z * qz[l - 1][m] + rho * hc->bl[l][m] * qz[l - 2][m]);
+                qr[l][m] = hc->al[l][m] * (z * qr[l - 1][m] + hc->bl[l][m] * (q[l - 2][m] + rho * qr[l - 2][m]));
+            }
+            qz[l][l - 1] = hc->cl[l] * q[l - 1][l - 1];  // q[l-1][l-1] is a constant
+        }
+#pragma unroll
+        for (int l = 0; l <= LMAX; l++) {
+            {
+                const double dz = qz[l][0] + 2.0 * z * qr[l][0];
+                Y[l * l] = q[l][0];
+                Yx[l * l] = 2.0 * x * qr[l][0];
+                Yy[l * l] = 2.0 * y * qr[l][0];
+                Yz[l * l] = dz;
+            }
+#pragma unroll
+            for (int m = 1; m <= l; m++) {
+                const double qq = SQRT2 * q[l][m], qrr = SQRT2 * qr[l][m], dz = SQRT2 * (qz[l][m] + 2.0 * z * qr[l][m]);
+                const int kc = l * l + 2 * m - 1, ks = l * l + 2 * m;
+                Y[kc] = qq * A[m];
+                Y[ks] = qq * B[m];
+                Yx[kc] = qq * m * A[m - 1] + 2.0 * x * qrr * A[m];
+                Yy[kc] = -qq * m * B[m - 1] + 2.0 * y * qrr * A[m];
+                Yz[kc] = dz * A[m];
+                Yx[ks] = qq * m * B[m - 1] + 2.0 * x * qrr * B[m];
+                Yy[ks] = qq * m * A[m - 1] + 2.0 * y * qrr * B[m];
+                Yz[ks] = dz * B[m];
+            }
+        }
+    }
+
     // sum_k Y_k w[k] without materialising Y; prepare() must have run.
     __device__ __forceinline__ double dot(const double *w) const
     {
@@ -1691,3 +1736,5 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
     }
     DISPATCH_LNS(BWD, a, st, cov);
 }
+
+#include "rows16.inc"

@@ -145,6 +145,29 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
                                double *virial /*[9][workgroups]*/, hipStream_t st, const RowsBatch *rows = nullptr,
                                const struct GemmParams *cov = nullptr /*covloss tiles (EPI_ROWSQ, 32-row, 16-deep) to run in the same launch*/);
 
+// Training rows, sixteen columns per workgroup pass (rows16.inc): chunk c of every species block of the sorted inducing
+// set per launch, `nch` chunks; pair gradients to G[ch][Nall][gnn][3][16], own sums to Fself[ch][Nall][3][16],
+// virial sums to vir[ch][Nall][9][16].  Returns -6 when the instantiation is not compiled (N1 * LL > 64 or more than
+// four species slots): the caller keeps the one-column-per-wave form.  Lists of at most 64 neighbours.
+struct Rows16Params {
+    const double *aw;   // [N][ld]  d k / d dot (K_nm pass with unit weights)
+    const double *k;    // [N][ld]  k
+    double eta;
+    int ld;
+    const double *pm;   // [m][Dpad]
+    int nch;                         // chunks in this launch (<= 32)
+    int gnn;                         // list slots per atom in G (>= the longest list of the frame)
+    short chunk[32];                 // chunk numbers
+    unsigned short cmask[32][4];     // columns asked for, per chunk and species block
+    int qoff[SGPR_MAX_S + 1];
+    double *G, *Fself, *vir;
+    size_t g_stride, f_stride, v_stride;
+};
+int launch_rows16(const DescParams &p, const int *slot, const int *nn, const int *nbr_j, const int *nbr_shift,
+                  const PackEntry *pack, const double *Pn, const double *norm, const double *C, const int *shear,
+                  const double *prec, const int *aux, const unsigned short *T, int t_stride, const int *cidx,
+                  const unsigned long long *hm, int hmw, const Rows16Params &rp, hipStream_t st);
+
 // Unpack packed rows [n][Dpad] -> dense reference layout [n][S][S][D]
 void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpad, const PackEntry *pack,
                                const double *Pp, double *Pdense, hipStream_t st);
