@@ -166,6 +166,9 @@ struct sgpr_model {
     DevBuf<double> d_rows_ones, d_rows_out, d_rows_ke;  // sgpr_kernel_rows / _columns scratch
     DevBuf<double> d_rows_bG, d_rows_bF, d_rows_bV;     // (batch of columns: G, [Fnbr | Fself], virial partials)
     DevBuf<double> d_rows_kepart;                       // (K_e: per-chunk column sums)
+    DevBuf<double> sc_dense_part;                       // partial sums of a dense Q^T application (qr_keep_apply_all)
+    DevBuf<double> sc_ea_y;                             // energy_rows_append: the targets on the device
+    DevBuf<int64_t> sc_ea_rows;                         //                     rows of the frames' energies
     DevBuf<int> d_rows_cols, d_rows_rowof, d_rows_qoff;
     DevBuf<double> d_rows_vpart;
     bool rows16 = true;                                 // SGPR_ROWS16=0: one column per wave for every rows call
@@ -223,14 +226,15 @@ struct sgpr_model {
                                            // v [ldr], sc, alpha
         // what came after the full factorisation, in order (each one an orthogonal map of the rows):
         //   kind 0  ONE flat reflector over rows [k0, R): the column appended at position k0
-        //   kind 1  the panels of a column SELECTION (sgpr_select_inducing: downsize(lii) / popfirst /
-        //           remove at an index, gppotential.py:815-842, :1037-1046): the QR of R1[:, idx] over the leading
-        //           `rows` rows, kept with its own reflectors in `pstore`
+        //   kind 1  a column SELECTION (sgpr_select_inducing: downsize(lii) / popfirst / remove at an index,
+        //           gppotential.py:815-842, :1037-1046): the QR of R1[:, idx] over the leading `rows` rows, kept as the
+        //           explicit matrix E = Q2^T (`rows` x `rows`, E[c * ld + r]): the identity rode along behind the targets.
+        //           Applying it is two launches; its ~64 panel levels, one launch each, made every later refit 0.8 ms
+        //           longer per selection in the chain (config 5 selects once per model update)
         struct Op {
-            int kind = 0, k0 = 0, flat_ix = 0, rows = 0;
+            int kind = 0, k0 = 0, flat_ix = 0, rows = 0, ld = 0;
             char snap = 0;                 // flat: ysnap[flat_ix] holds Q^T Y from before it
-            std::vector<TsqrPanel> panels;
-            DevBuf<double> pstore;
+            DevBuf<double> pstore;         // selection: E
         };
         std::vector<Op> ops;
         bool selected = false;             // a selection since the last refit (diagnostics)
@@ -727,6 +731,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
         DevBuf<int> *si[] = {&h->sc_s2so, &h->sc_ai_eslot, &h->sc_ai_oslot, &h->sc_ai_onn, &h->sc_ai_info, &h->sc_sel_idx,
                              &h->sc_sel_map, &h->sc_chol_info};
         h->sc_sel_A.release(); h->sc_sel_work.release(); h->d_design_alt.release();
+        h->sc_dense_part.release(); h->sc_ea_y.release(); h->sc_ea_rows.release();
         for (auto b : si) b->release();
         h->sc_ai_ptr.release();
         h->sc_erow.release();
