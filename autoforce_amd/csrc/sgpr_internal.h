@@ -229,7 +229,8 @@ size_t tsqr_keep_doubles(int rows, int cols, int band); // ... of every panel of
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /*[cols] or NULL: factor only*/,
                             double *work, hipStream_t st, int band = 0, double *keep = nullptr,
                             std::vector<TsqrPanel> *panels = nullptr,
-                            int extra = 0 /*columns behind the targets that are carried along: Q^T applied to them*/);
+                            int extra = 0 /*columns behind the targets that are carried along: Q^T applied to them*/,
+                            int band_off = 0 /*band > 0: column c is zero below row band * (c + 1) + band_off*/);
 int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_mat, double *x, double *work, int batch,
                             hipStream_t st, int band);
 void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st);

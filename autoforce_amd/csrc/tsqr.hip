@@ -609,7 +609,7 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
 }
 
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band,
-                            double *keep, std::vector<TsqrPanel> *panels, int extra)
+                            double *keep, std::vector<TsqrPanel> *panels, int extra, int band_off)
 {
     if (cols > 2048 || rows < cols || ldr < rows) return -1;
     tsqr_attrs();
@@ -623,7 +623,7 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
     if (panels) panels->clear();
     for (int k0 = 0; k0 < cols; k0 += TNB) {
         const int nb = std::min(TNB, cols - k0);
-        const int row_end = band > 0 ? std::min(rows, band * (k0 + nb)) : rows;
+        const int row_end = band > 0 ? std::min(rows, band * (k0 + nb) + band_off) : rows;
         const int ntrail = cols + 1 + extra - (k0 + nb);  // the other columns, the targets, `extra` columns that follow Q^T
         TsqrPanel rec;
         tsqr_panel(At + (size_t)k0 * ldr, ldr, k0, nb, row_end, At + (size_t)(k0 + nb) * ldr, ntrail, work, keep,
