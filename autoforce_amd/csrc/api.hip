@@ -276,6 +276,8 @@ struct sgpr_model {
     int gemm_bm_k = 64, gemm_bm_w = 64;  // rows per tile of t_knm  /  t_w, t_cov, t_wcov
     int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
     int gemm_waves_k = 8;                // waves per K_nm tile (SGPR_GEMM_WAVES=4: the four-wave form)
+    bool gemm_k64 = false, gemm_w64 = false;  // 64 x 64 tiles on eight waves for K_nm / for W + covloss: by size
+    bool gemm_64_forced = false;              //   (decide_tile_heights) unless SGPR_GEMM_64="k,w" says so
     int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
     bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
     std::vector<int4> h_t_w, h_t_cov;
@@ -634,6 +636,10 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
+    if (const char *e = getenv("SGPR_GEMM_64")) {
+        int k = 0, w = 0;
+        if (sscanf(e, "%d,%d", &k, &w) == 2) { h->gemm_k64 = k != 0; h->gemm_w64 = w != 0; h->gemm_64_forced = true; }
+    }
     if (const char *e = getenv("SGPR_TILE_BALANCE")) h->tile_balance = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ROWS16")) h->rows16 = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ROWS16_MB")) h->rows16_mb = std::max(1, atoi(e));
@@ -786,6 +792,38 @@ static void balance_xcd_share(std::vector<int4> &b, int ncu, int slots)
     }
 }
 
+// number of working tiles of product `kind` (0 K_nm, 1 W, 2 covloss) at `bm` rows per tile: the loop of build_tiles
+static size_t count_tiles(const sgpr_model *h, int kind, int bm)
+{
+    const int nrows = h->cnt, ncols = kind == 1 ? h->Dpad : h->m;
+    const int nrt = (nrows + bm - 1) / bm, nct = (ncols + 63) / 64;
+    size_t n = 0;
+    for (int rt = 0; rt < nrt; rt++) {
+        const int r0 = rt * bm, r1 = std::min(nrows, r0 + bm) - 1;
+        int sa = 0, sb = 0;
+        while (sa + 1 < h->S && h->aoff[sa + 1] <= r0) sa++;
+        while (sb + 1 < h->S && h->aoff[sb + 1] <= r1) sb++;
+        const int qlo = h->qoff[sa], qhi = h->qoff[sb + 1];
+        if (kind == 1) { n += qhi > qlo ? nct : 0; continue; }
+        for (int ct = 0; ct < nct; ct++)
+            if (ct * 64 < qhi && std::min(ncols, ct * 64 + 64) > qlo) n++;
+    }
+    return n;
+}
+
+// Tile heights of the three products of a step.  32 x 64 tiles fill the chip at a few thousand atoms (416 K_nm tiles on
+// 256 CUs at 4096 / 512); once a CU holds several of them, 64 x 64 tiles on eight waves move two thirds of the bytes
+// for the same flops and win: K_nm -5 % at 8000 / 512, -7 % at 15625 / 512, -10 % at 32768 / 1024 (+1..4 % at
+// 4096 / 512: fewer tiles than CUs), W + covloss -5.5 % at 32768 / 1024, -1.5 % at 15625 / 1024, +3 % at 4096 / 512.
+// SGPR_GEMM_64="k,w" (0 / 1 each) overrides.
+static void decide_tile_heights(sgpr_model *h)
+{
+    if (h->gemm_64_forced) return;
+    const size_t ncu = (size_t)h->cus_per_xcd * 8;
+    h->gemm_k64 = count_tiles(h, 0, 32) >= 3 * ncu;
+    h->gemm_w64 = count_tiles(h, 1, 32) + count_tiles(h, 2, 32) >= 24 * ncu;
+}
+
 static int build_tiles(sgpr_model *h, int kind)
 {
     const int KTc = 32;
@@ -804,6 +842,8 @@ static int build_tiles(sgpr_model *h, int kind)
         int kk = 0, kw = 0;
         if (sscanf(e, "%d,%d", &kk, &kw) == 2) { h->gemm_kd_k = kk == 16 ? 16 : 32; h->gemm_kd_w = kw == 16 ? 16 : 32; }
     }
+    if (kind == 0 && h->gemm_k64) bm = 64;
+    if ((kind == 1 || kind == 2) && h->gemm_w64) bm = 64;
     if (kind == 0) h->gemm_bm_k = bm;
     if (kind == 1 || kind == 2) h->gemm_bm_w = bm;
     const int nrt = (nrows + bm - 1) / bm, nct = (ncols + 63) / 64;
@@ -852,7 +892,7 @@ static int build_tiles(sgpr_model *h, int kind)
             if (t.w > t.z) bk[t.x % 8].push_back(make_int4(t.x | (1 << 16), t.y, t.z, t.w));
         // longest reductions first (LPT): row tiles come in species order and the species with the most
         // inducing points — the deepest reductions — would otherwise form the tail of the launch
-        for (auto &b : bk) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, 4);
+        for (auto &b : bk) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? 2 : 4);
         size_t dp = 0;
         for (auto &b : bk) dp = std::max(dp, b.size());
         std::vector<int4> both(dp * 8, make_int4(0, 0, 0, 0));
@@ -862,7 +902,7 @@ static int build_tiles(sgpr_model *h, int kind)
             std::vector<std::vector<int4>> bc(8);
             for (const int4 &t : h->h_t_cov)
                 if (t.w > t.z) bc[t.x % 8].push_back(t);
-            for (auto &b : bc) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, 4);
+            for (auto &b : bc) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? 2 : 4);
             size_t dc = 0;
             for (auto &b : bc) dc = std::max(dc, b.size());
             std::vector<int4> only(dc * 8, make_int4(0, 0, 0, 0));
@@ -898,7 +938,7 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
     g.tiles = tiles.p; g.ntiles = (int)tiles.n;
     g.bm = (&tiles == &h->t_kmm) ? 64 : h->gemm_bm_k;
     g.kd = h->gemm_kd_k;
-    g.waves = (&tiles == &h->t_knm && h->gemm_bm_k == 32 && h->gemm_kd_k == 16) ? h->gemm_waves_k : 4;
+    g.waves = &tiles != &h->t_knm ? 4 : h->gemm_k64 ? 8 : (h->gemm_bm_k == 32 && h->gemm_kd_k == 16) ? h->gemm_waves_k : 4;
     g.eta = h->eta; g.lone_m1 = h->lone_w - 1.0; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
     g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
@@ -1173,6 +1213,7 @@ static int alloc_work(sgpr_model *h)
     if (h->m > 0) {
         bad |= h->d_K.alloc((size_t)cr * h->m_pad);   // zero-filled: off-species entries are never written
         bad |= h->d_Aw.alloc((size_t)cr * h->m_pad);
+        decide_tile_heights(h);
         if (build_tiles(h, 0) || build_tiles(h, 1) || build_tiles(h, 2)) bad = 1;
         h->epart_len = 8 * (int)h->t_knm.n;  // one partial per wave of every K_nm tile (four- or eight-wave form: the
                                              // unused half of a four-wave tile's eight slots stays zero)
@@ -1416,6 +1457,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     gw.lda = h->m_pad; gw.ldb = h->m_pad; gw.ldc = h->Dpad;
     gw.A = h->d_Aw.p; gw.B = h->d_PmT.p; gw.C = h->d_W.p;
     gw.tiles = h->t_w.p; gw.ntiles = (int)h->t_w.n; gw.bm = h->gemm_bm_w; gw.kd = h->gemm_kd_w;
+    gw.waves = gc.waves = (h->gemm_w64 && h->gemm_bm_w == 64) ? 8 : 4;
     gc.M = cnt; gc.N = h->m; gc.K = h->m_pad;
     gc.lda = h->m_pad; gc.ldb = h->m_pad; gc.ldc = 0;
     gc.A = h->d_K.p; gc.B = h->d_choli.p; gc.C = nullptr;

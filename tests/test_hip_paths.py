@@ -205,22 +205,25 @@ def test_candidate_lists_are_reused_without_changing_anything(name):
     fast.close(); slow.close()
 
 
-@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4"])
+@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4", "r64"])
 def test_gemm_tile_shapes_agree_bit_for_bit(shape, monkeypatch):
     """The three products of a step (K_nm, W, covloss) run on 32x64 tiles with 16-deep LDS stages; the 64-row form and the
     32-deep stages stay compiled in for K_mm, dense launches and the forked path.  Every form accumulates a dot product
     over k in the same order (one MFMA k-step of 4 after the other), so K_nm, forces, stress and beta must not move
     by a single bit when the tile tables are built for another shape (diagnostic overrides SGPR_GEMM_BM / SGPR_GEMM_KD),
-    nor when a K_nm tile is shared by four waves (two 16 x 16 blocks each) instead of eight (SGPR_GEMM_WAVES)."""
+    nor when a K_nm tile is shared by four waves (two 16 x 16 blocks each) instead of eight (SGPR_GEMM_WAVES), nor on the
+    64 x 64 eight-wave tiles that large frames take ("r64": SGPR_GEMM_64 forces them here)."""
     rng = np.random.default_rng(31)
     species = [3, 15, 16]
     numbers, pos, cell = random_frame(rng, 300, 16.0, species)
     pbc = [True] * 3
     outs = []
-    for bm, kd, waves in ((None, None, None), shape.split(";")):
+    for bm, kd, waves in ((None, None, None), shape.split(";") if shape != "r64" else ("r64", "", "")):
         if bm is None:
-            for k in ("SGPR_GEMM_BM", "SGPR_GEMM_KD", "SGPR_GEMM_WAVES"):
+            for k in ("SGPR_GEMM_BM", "SGPR_GEMM_KD", "SGPR_GEMM_WAVES", "SGPR_GEMM_64"):
                 monkeypatch.delenv(k, raising=False)
+        elif bm == "r64":
+            monkeypatch.setenv("SGPR_GEMM_64", "1,1")
         else:
             monkeypatch.setenv("SGPR_GEMM_BM", bm)
             monkeypatch.setenv("SGPR_GEMM_KD", kd)
