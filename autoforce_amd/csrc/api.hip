@@ -172,7 +172,7 @@ struct sgpr_model {
     DevBuf<int> d_rows_cols, d_rows_rowof, d_rows_qoff;
     DevBuf<double> d_rows_vpart;
     bool rows16 = true;                                 // SGPR_ROWS16=0: one column per wave for every rows call
-    int rows16_mb = 6144;                               // hand-over buffer of the sixteen-column form (SGPR_ROWS16_MB)
+    int rows16_mb = 16384;                              // hand-over buffer of the sixteen-column form (SGPR_ROWS16_MB)
     int rows16_min = 1;                                 // fewest columns of a call that take it (SGPR_ROWS16_MIN; 1: a column has the same bits whatever call computed it)
     const char *info_rows = "none yet";                 // form of the last rows call (sgpr_solve_info)
     std::vector<int> rows_cols;
@@ -1697,13 +1697,16 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         memcpy(pi + 3 * (size_t)N, cell, sizeof(double) * 9);
         // positions and cell travel as ONE copy (a second 72-byte copy is a whole DMA command of its own)
         if (tl) tls[1] = nowus();
-        HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
+        static const bool zin = getenv("SGPR_ZERO_COPY_IN") && atoi(getenv("SGPR_ZERO_COPY_IN")) != 0;  // experiment
+        const bool in_direct = zin && h->pin_dev;
+        if (!in_direct) HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
         if (tl) tls[2] = nowus();
         // single rank: the last kernel writes the packed results straight into the page-locked buffer (host memory
         // mapped into the device's address space: posted PCIe writes inside the kernel) — no device-to-host copy
         // command behind the step, one synchronisation point less on the way out (option "zero_copy_out")
         const bool direct = h->zero_copy_out && !h->comm && h->world == 1 && h->pin_dev;
-        int rf = enqueue_step(h, h->d_pos_in.p, h->d_pos_in.p + 3 * (size_t)N, direct ? h->pin_dev + n_in : h->d_packed.p, h->stream);
+        const double *pos_src = in_direct ? h->pin_dev : h->d_pos_in.p;
+        int rf = enqueue_step(h, pos_src, pos_src + 3 * (size_t)N, direct ? h->pin_dev + n_in : h->d_packed.p, h->stream);
         if (!rf) rf = reduce_packed(h, h->d_packed.p, h->stream);
         if (rf) return rf;
         if (!direct) HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
