@@ -47,7 +47,9 @@ struct TsqrLeaf {
     // a batch of independent problems of the same shape (blockIdx.y): doubles between their matrices / work arrays
     size_t bs_mat, bs_work;
     int src_in_work;    // level >= 1: src is the stacked R of the level below (work), else the matrix
+    long long *stamps;  // diagnostic (SGPR_TSQR_STAMPS=1): [chunk][8] s_memtime at the phase boundaries of chunk 0..
 };
+#define LEAF_STAMP(K) if (q.stamps && threadIdx.x == 0 && blockIdx.y == 0) q.stamps[blockIdx.x * 8 + (K)] = (long long)__builtin_amdgcn_s_memtime();
 
 // wave64 sum on the DPP network (no LDS round trips): quads, half rows, rows, then the four row sums through
 // scalar registers; the result is wave-uniform
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int c = tid & 31, rg = tid >> 5, r0 = rg * TRG;
     const int chunk = blockIdx.x;
+    LEAF_STAMP(0)
     const int nr = min(TCH, q.n - chunk * TCH);
     const size_t off_m = blockIdx.y * q.bs_mat, off_w = blockIdx.y * q.bs_work;
     q.src += q.src_in_work ? off_w : off_m;
@@ -137,6 +140,7 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
         if (lane < 32) pn[0][wave] = sp;
     }
     __syncthreads();
+    LEAF_STAMP(1)
     for (int j = 0; j < q.nb; j++) {
         const int jb = j & 1;
         // the scalar chain (norm -> alpha -> 2 / v.v) does not feed the products below: they run on the RAW column x
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
         }
         __syncthreads();
     }
+    LEAF_STAMP(2)
     // V (zero above the diagonal, v_jj on it) -> LDS: for the Gram product, and for the coalesced way out
     {
         const double d = s_vjj[c];
@@ -245,6 +250,7 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
         for (int reg = 0; reg < 4; reg++) G[((wave >> 1) * 16 + l4 + 4 * reg) * (TNB + 1) + (wave & 1) * 16 + l15] = w[reg];
     }
     __syncthreads();
+    LEAF_STAMP(3)
     // T = [T11 T12; 0 T22] in 16 x 16 blocks.  Diagonal blocks: T[t][t] = scal_t, T[t][j] = -scal_j sum_{l=t}^{j-1}
     // T[t][l] (v_l . v_j) — row t only depends on itself: lane t of each half keeps it in registers (120 multiply-adds,
     // unrolled).  Then T12 = -T11 (V1^T V2) T22 by 256 threads.
@@ -283,6 +289,7 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
         }
     }
     __syncthreads();
+    LEAF_STAMP(4)
     double *T = q.T + (size_t)chunk * TNB * TNB;
     for (int e = tid; e < TNB * TNB; e += TLT) T[e] = Ts[(e / TNB) * (TNB + 1) + e % TNB];
     // R_i (upper triangular, alpha on the diagonal): row g is slot 0 of group g, row g + 16 its slot 1
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
             q.Rfinal[(size_t)c * q.ldr + r] = val;
         }
     }
+    LEAF_STAMP(5)
 }
 
 struct TsqrApply {
@@ -584,6 +592,19 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
         lf.Rfinal = panel_cols + k0;
         lf.ldr = ld;
         lf.bs_mat = bs_mat; lf.bs_work = bs_work; lf.src_in_work = l > 0;
+        {
+            static long long *d_st = nullptr;
+            static const bool on = getenv("SGPR_TSQR_STAMPS") != nullptr;
+            if (on && !d_st) (void)hipMalloc((void **)&d_st, sizeof(long long) * 8 * 4096);
+            lf.stamps = on && chunks <= 4096 ? d_st : nullptr;
+            if (on && d_st && l == 0 && k0 >= 512 && k0 < 544) {  // print the previous launch's stamps now and then
+                long long hs[8 * 8];
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(hs, d_st, sizeof(hs), hipMemcpyDeviceToHost);
+                fprintf(stderr, "[tsqr stamps] chunk 0 of the previous leaf: load %lld | steps %lld | V out + Gram %lld | T %lld | T out %lld..end %lld cycles\n",
+                        hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[5] - hs[0]);
+            }
+        }
         hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks, batch), dim3(TLT), lds_leaf_bytes(), st, lf);
         if (rec && rec->nlev < 8) {
             TsqrLevel &lv = rec->lv[rec->nlev++];
