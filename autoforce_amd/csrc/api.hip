@@ -280,6 +280,7 @@ struct sgpr_model {
     bool gemm_64_forced = false;              //   (decide_tile_heights) unless SGPR_GEMM_64="k,w" says so
     int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
     bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
+    bool xcd_quads = true;               // SGPR_XCD_QUADS=0: workgroup b of the descriptor kernels works on atoms 4b .. 4b+3
     std::vector<int4> h_t_w, h_t_cov;
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -641,6 +642,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
         if (sscanf(e, "%d,%d", &k, &w) == 2) { h->gemm_k64 = k != 0; h->gemm_w64 = w != 0; h->gemm_64_forced = true; }
     }
     if (const char *e = getenv("SGPR_TILE_BALANCE")) h->tile_balance = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_XCD_QUADS")) h->xcd_quads = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ROWS16")) h->rows16 = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ROWS16_MB")) h->rows16_mb = std::max(1, atoi(e));
     if (const char *e = getenv("SGPR_ROWS16_MIN")) h->rows16_min = std::max(1, atoi(e));
@@ -1438,6 +1440,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     for (int k = 0; k < SGPR_MAX_S; k++) dp.radii_v[k] = k < h->S ? h->radii[k] : 1.0;
     if (h->d_stamps.p && h->d_pstamps.n < (size_t)16 * N) h->d_pstamps.alloc((size_t)16 * N);
     dp.stamps = h->d_stamps.p ? h->d_pstamps.p : nullptr;
+    dp.xq = h->xcd_quads ? h->gemm_bm_k / 4 : 0;  // the forward pass writes the rows of the K_nm tiles
     int rcd = launch_list_forward(dp, sc, h->d_pos.p, cell_dev, h->d_pack.p, h->d_nn.p, h->d_lnn.p, h->d_nbr_j.p,
                                   h->d_nbr_shift.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p, h->d_prec.p, st);
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
@@ -1492,6 +1495,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         stamp(h, "gemm_covloss", st);
     }
     if (predict) {
+        dp.xq = h->xcd_quads ? h->gemm_bm_w / 4 : 0;  // the reverse pass reads the rows of the W tiles
         rcd = launch_descriptor_backward(dp, h->d_pos.p, cell_dev, h->d_slot.p, h->d_radii.p, h->d_nn.p, h->d_nbr_j.p,
                                          h->d_nbr_shift.p, h->d_pack.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p,
                                          h->d_W.p, h->d_prec.p, gather ? h->d_G.p : nullptr, h->d_aux.p,

@@ -55,6 +55,19 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// Which quad of atoms workgroup b works on.  The dispatcher sends workgroup b to XCD b % 8, and the tile tables of the GEMMs
+// put row tile t on XCD t % 8 (api.hip::build_tiles): with R quads per row tile, the 8R workgroups b = 8R g + 8 s + x take
+// the quads 8R g + R x + s — the rows of a GEMM tile are produced (forward pass -> K_nm) and consumed (W -> reverse pass)
+// on the XCD whose L2 holds them.  A last partial group keeps the identity.
+__device__ __forceinline__ int xcd_quad(int b, int n, int R)
+{
+    if (R <= 0) return b;
+    const int grp = 8 * R, g0 = b / grp * grp;
+    if (g0 + grp > n) return b;
+    const int r = b - g0;
+    return g0 + (r & 7) * R + (r >> 3);
+}
+
 // ---------------------------------------------------------------- solid harmonics
 template <int LMAX>
 struct Harm {
@@ -237,6 +250,7 @@ struct DescArgs {
     const unsigned long long *hm;  // [Nall][hmw] this step's hit mask over the candidates
     int hmw;
     int rsz;                // reverse pass: doubles of the per-wave scratch region
+    int xq;                 // quads of atoms per GEMM row tile (8 or 16; 0: workgroup b works on quad b) — see xcd_quad
     int *shear;             // [N]
     // training rows (sgpr_kernel_rows): blockIdx.y = column of the batch; the reverse-pass seed of column q is
     // W_i = Aw[i][q] * Pm[q][:], formed on the fly (no W array), and every output is strided by the batch index
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     constexpr int UC = ST * N1, CBS = (UC + 15) / 16, RBL = (LL + 15) / 16;
     extern __shared__ double smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ia = blockIdx.x * 4 + wave;
+    const int ia = xcd_quad((int)blockIdx.x, (int)gridDim.x, a.xq) * 4 + wave;
     if (ia >= a.N) return;  // (no workgroup barrier in this kernel)
     const int i = a.first + ia * a.stride;
     double *wbase = smem + (size_t)wave * FL::PW;
@@ -1184,7 +1198,8 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
     // wave index through readfirstlane: everything derived from it (atom index, LDS bases, row
     // addresses) is then scalar and stays out of the VGPR budget
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ia = bx * 4 + wave;
+    const int qd = xcd_quad(bx, nbx, a.xq);  // (the virial partial below stays at the quad's index: same sums as ever)
+    const int ia = qd * 4 + wave;
     const bool active = ia < a.N;
     const int perwave = ST * NSLOT + a.rsz + CH / 2;
     double *dcl = smem + (size_t)wave * perwave;  // [ST][NSLOT] dE/dc of this atom
@@ -1534,7 +1549,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
     }
     __syncthreads();
     if (wave == 0 && lane < 9)
-        vir_b[(size_t)lane * nbx + bx] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
+        vir_b[(size_t)lane * nbx + qd] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
 }
 
 // =========================================================================== unpack (tests)
@@ -1662,6 +1677,7 @@ static DescArgs make_args(const DescParams &p)
     DescArgs a = {};
     a.N = p.N; a.Nall = p.Nall; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
     a.rc = p.rc;
+    a.xq = p.xq;
     a.irc = 1.0 / p.rc;
     for (int k = 0; k < SGPR_MAX_S; k++) { a.radii_v[k] = p.radii_v[k]; a.radii_iv[k] = 1.0 / p.radii_v[k]; }
     return a;

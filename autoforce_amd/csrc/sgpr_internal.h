@@ -104,6 +104,7 @@ struct DescParams {
     double radii_v[SGPR_MAX_S];  // length unit per species slot
     double rc;
     long long *stamps;  // diagnostic build only (SGPR_STAMPS=1 + -DSGPR_PHASE_STAMPS): [2][Nall][8]
+    int xq;             // quads of atoms per row tile of the GEMM that follows / precedes (XCD-aware workgroup -> atoms map), 0: off
 };
 
 // Neighbour lists + forward descriptors of this rank's atoms, one launch (one wave per atom): sweep of
