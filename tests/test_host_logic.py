@@ -164,3 +164,23 @@ def test_watchdog_ends_a_stuck_rank():
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert p.returncode == 3
     assert "rank 1" in p.stderr and "ncclCommInitRank" in p.stderr
+
+
+def test_largest_covloss_is_the_head_of_the_reference_argsort():
+    """update_inducing offers the first atom, in descending order of covloss, that is neither chosen nor ignored
+    (calculator/active.py:851-856 walks a full argsort for it); the masked argmax that replaces the sort picks the same
+    atom — ties to the lowest index, everything excluded -> the tail of the order — on random cases."""
+    from autoforce_amd.calculator import ActiveCalculator
+
+    class Stub:
+        ignore = []
+
+    rng = np.random.default_rng(0)
+    for _ in range(3000):
+        n = int(rng.integers(1, 12))
+        beta = rng.choice([0.0, 0.1, 0.5, 0.5, 0.9, 1.0, np.inf], size=n).astype(float)
+        chosen = [int(c) for c in rng.choice(n, size=int(rng.integers(0, n + 1)), replace=False)]
+        Stub.ignore = [int(c) for c in rng.choice(n, size=int(rng.integers(0, 2)), replace=False)]
+        order = np.argsort(-beta, kind="stable")
+        want = next((int(i) for i in order if int(i) not in chosen and int(i) not in Stub.ignore), int(order[-1]))
+        assert ActiveCalculator._largest_covloss(Stub, beta, chosen) == want
