@@ -42,6 +42,7 @@ SIGNATURES = {
     "sgpr_resolve": (C.c_int, [_vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_resolve_batch": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sgpr_make_vscale": (C.c_int, [_vp, _vp]),
+    "sgpr_data_force_mae": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "sgpr_kernel_rows": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgpr_kernel_columns": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "sgpr_data_push": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),

@@ -167,6 +167,8 @@ struct sgpr_model {
     DevBuf<double> d_rows_bG, d_rows_bF, d_rows_bV;     // (batch of columns: G, [Fnbr | Fself], virial partials)
     DevBuf<double> d_rows_kepart;                       // (K_e: per-chunk column sums)
     DevBuf<double> sc_dense_part;                       // partial sums of a dense Q^T application (qr_keep_apply_all)
+    DevBuf<double> sc_mae_v;                            // sgpr_data_force_mae: the batch of weight vectors
+    DevBuf<int64_t> sc_mae_rows;                        //                      energy row and end of the force rows per frame
     DevBuf<double> sc_ea_y;                             // energy_rows_append: the targets on the device
     DevBuf<int64_t> sc_ea_rows;                         //                     rows of the frames' energies
     DevBuf<int> d_rows_cols, d_rows_rowof, d_rows_qoff;
@@ -740,6 +742,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
                              &h->sc_sel_map, &h->sc_chol_info};
         h->sc_sel_A.release(); h->sc_sel_work.release(); h->d_design_alt.release();
         h->sc_dense_part.release(); h->sc_ea_y.release(); h->sc_ea_rows.release();
+        h->sc_mae_v.release(); h->sc_mae_rows.release();
         for (auto b : si) b->release();
         h->sc_ai_ptr.release();
         h->sc_erow.release();

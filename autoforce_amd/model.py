@@ -390,6 +390,17 @@ class SGPRModel:
         check(_lib.load().sgpr_data_fit_stats(self._h, ptr(v), ptr(Y), ptr(e), ptr(st)))
         return e, st[:7]
 
+    def data_force_mae(self, V, Y):
+        """mean |K_f v - Y_f| over the force rows for every row v of V [count, m] (sgpr_data_force_mae): the objective of
+        the noise search, reduced on the device."""
+        V = f64(V).reshape(-1, self.m)
+        Y = f64(Y).reshape(-1)
+        if len(Y) != self.data_info()[1]:
+            raise ValueError(f"data_force_mae: {len(Y)} targets for {self.data_info()[1]} stored rows")
+        out = np.zeros(len(V))
+        check(_lib.load().sgpr_data_force_mae(self._h, len(V), ptr(V), ptr(Y), ptr(out)))
+        return out
+
     def data_get(self):
         """The resident design matrix [rows, m] (diagnostics / tests)."""
         out = np.zeros((self.data_info()[1], self.m))

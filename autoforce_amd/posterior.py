@@ -434,12 +434,21 @@ class PosteriorPotential:
         _, f, _ = self.targets()
         self._solve(with_energies=False, factor_only=True)  # factors [Kf; Kv | F; V] once; the search only re-solves
         cache = {}
+        # the force-fit MAE of a batch of weight vectors: reduced on the device where the engine offers it (one pass over
+        # the resident matrix per sixteen candidates instead of a matvec and rows x 8 bytes to the host for each)
+        on_device = self.resident and hasattr(self.engine, "data_force_mae")
+        Yt = self._store_targets() if on_device else None
+
+        def maes(mus):
+            if on_device:
+                return [float(v) for v in self.engine.data_force_mae(np.asarray(mus), Yt)]
+            return [float(np.abs(self._matvec(mu)[1] - f).mean()) for mu in mus]
 
         def objective(x):
             x = float(np.clip(x, -14.0, 14.0))
             if x not in cache:
                 mu = self.engine.resolve(noise=_sigmoid(x))
-                cache[x] = float((np.abs(self._matvec(mu)[1] - f).mean() - noise_f) ** 2)
+                cache[x] = float((maes([mu])[0] - noise_f) ** 2)
             return cache[x]
 
         x0 = float(self._noise["all"])
@@ -447,8 +456,8 @@ class PosteriorPotential:
         if hasattr(self.engine, "resolve_many"):
             # the scan is a batch of independent second-stage problems: one set of launches for all of them
             xs = sorted({float(np.clip(x, -14.0, 14.0)) for x in grid + [x0]})
-            for x, mu in zip(xs, self.engine.resolve_many([_sigmoid(x) for x in xs])):
-                cache[x] = float((np.abs(self._matvec(mu)[1] - f).mean() - noise_f) ** 2)
+            for x, mae in zip(xs, maes(self.engine.resolve_many([_sigmoid(x) for x in xs]))):
+                cache[x] = float((mae - noise_f) ** 2)
         f0 = objective(x0)
         vals = [objective(x) for x in grid]
         k = int(np.argmin(vals))
@@ -467,8 +476,8 @@ class PosteriorPotential:
                 xs = [float(np.clip(lo + (hi - lo) * (j + 0.5) / 16.0, -14.0, 14.0)) for j in range(16)]
                 todo = [x for x in xs if x not in cache]
                 if todo and hasattr(self.engine, "resolve_many"):
-                    for x, mu in zip(todo, self.engine.resolve_many([_sigmoid(x) for x in todo])):
-                        cache[x] = float((np.abs(self._matvec(mu)[1] - f).mean() - noise_f) ** 2)
+                    for x, mae in zip(todo, maes(self.engine.resolve_many([_sigmoid(x) for x in todo]))):
+                        cache[x] = float((mae - noise_f) ** 2)
                 cand = min(xs + [best], key=objective)
                 w = (hi - lo) / 16.0
                 best, lo, hi = cand, max(lo, cand - w), min(hi, cand + w)

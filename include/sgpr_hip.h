@@ -183,6 +183,10 @@ int sgpr_data_clear(sgpr_model *h);
 int sgpr_data_info(sgpr_model *h, int32_t *frames, int64_t *rows);
 int sgpr_data_matvec(sgpr_model *h, const double *v, double *out);
 int sgpr_data_fit_stats(sgpr_model *h, const double *v, const double *Y, double *e_pred, double *stats);
+/* mae_out[b] = mean |K_f V[b] - Y_f| over the force rows of the resident matrix, for `count` weight vectors V[count][m]
+ * against the targets Y[rows] (store order): the objective of the noise search of _regression(optimize=True)
+ * (regression/gppotential.py:1265-1300), reduced on the device in a fixed order, sixteen vectors per pass over the matrix. */
+int sgpr_data_force_mae(sgpr_model *h, int count, const double *V, const double *Y, double *mae_out);
 int sgpr_data_get(sgpr_model *h, double *K);
 int sgpr_data_solve(sgpr_model *h, const double *Y, int with_energies, double noise, double *mu_out,
                     double *choli_out, double *ridge_out, double *sigma_out);

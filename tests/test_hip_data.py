@@ -457,6 +457,16 @@ def test_fit_statistics_on_the_device():
     want = [d.sum(), np.abs(d).sum(), (d * d).sum(), y.sum(), (y * y).sum(), np.abs(y).max(), len(d)]
     np.testing.assert_allclose(st, want, rtol=1e-12, atol=1e-10)
     np.testing.assert_array_equal(mdl.M_diag, np.diag(mdl.M))
+    # the objective of the noise search: force rows only (energy and virial rows out), a batch of weight vectors
+    is_f = np.zeros(len(K), bool)
+    a = 0
+    for fr, nv in zip(frames, nvs):
+        is_f[a + 1:a + 1 + 3 * len(fr[0])] = True
+        a += 1 + 3 * len(fr[0]) + nv
+    V = rng.normal(size=(19, mdl.m))  # more than one pass of sixteen
+    want = [np.abs((K @ w - Y)[is_f]).mean() for w in V]
+    np.testing.assert_allclose(mdl.data_force_mae(V, Y), want, rtol=1e-12)
+    np.testing.assert_allclose(mdl.data_force_mae(V[:1], Y), want[:1], rtol=1e-12)
     mdl.close()
 
 
