@@ -489,7 +489,11 @@ class PosteriorPotential:
         keys = sorted(self.mean.weights)
         nat = np.array([fr.natoms for fr in self.data], float)
         A = np.array([[fr.counts().get(z, 0) for z in keys] for fr in self.data], float) / nat[:, None]
-        b = (np.array([fr.energy for fr in self.data]) - self._matvec(mu)[0]) / nat
+        if on_device and hasattr(self.engine, "data_fit_stats"):
+            e_fit = self.engine.data_fit_stats(mu, Yt)[0]  # the energy rows of K mu alone: n numbers, not every row, come back
+        else:
+            e_fit = self._matvec(mu)[0]
+        b = (np.array([fr.energy for fr in self.data]) - e_fit) / nat
         w0 = np.array([self.mean.weights[z] for z in keys])
         w = w0 + np.linalg.lstsq(A, b - A @ w0, rcond=None)[0]
         for z, val in zip(keys, w):
