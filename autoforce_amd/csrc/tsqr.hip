@@ -307,6 +307,203 @@ __global__ __launch_bounds__(TLT) void tsqr_leaf_kernel(TsqrLeaf q)
     LEAF_STAMP(5)
 }
 
+__global__ __launch_bounds__(TLT) void tsqr_leaf_wave_kernel(TsqrLeaf q)
+{
+    extern __shared__ double lds[];
+    double *sm = lds;                     // [TNB][TLD]  the chunk on its way in, V (masked) on its way out
+    double *G = lds + TNB * TLD;          // [TNB][TNB + 1]:  V^T V
+    double *Ts = G + TNB * (TNB + 1);     // [TNB][TNB + 1]
+    __shared__ __attribute__((aligned(16))) double vbuf[2][TCH], pn[2][8];   // vbuf[.][16 g + k] = row g + 16 k
+    __shared__ double part[16][TNB + 1], rowj[TNB], s_alpha[TNB], s_scal[TNB], s_vjj[TNB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c = tid & 31, rg = tid >> 5, r0 = rg * TRG;  // (the way in: as the other form)
+    const int chunk = blockIdx.x;
+    LEAF_STAMP(0)
+    const int nr = min(TCH, q.n - chunk * TCH);
+    const size_t off_m = blockIdx.y * q.bs_mat, off_w = blockIdx.y * q.bs_work;
+    q.src += q.src_in_work ? off_w : off_m;
+    q.V += off_w; q.T += off_w;
+    if (q.Rnext) q.Rnext += off_w;
+    q.Rfinal += off_m;
+    {
+        // coalesced in (thread: 16 consecutive rows of its column), interleaved out.  Branch-free: a dead pair reads
+        // the chunk's first element instead; a pair cut by the end of the matrix reads one element of padding — ldr
+        // is a multiple of 64 — and drops it.
+        const double *col = q.src + chunk * q.chunk_stride + (size_t)(c < q.nb ? c : 0) * q.ld;
+#pragma unroll
+        for (int k = 0; k < TRG; k += 2) {
+            const bool ok0 = c < q.nb && r0 + k < nr, ok1 = c < q.nb && r0 + k + 1 < nr;
+            const double2 v = *(const double2 *)(col + (ok0 ? r0 + k : 0));
+            *(double2 *)&sm[c * TLD + r0 + k] = make_double2(ok0 ? v.x : 0.0, ok1 ? v.y : 0.0);
+        }
+    }
+    for (int e = tid; e < TNB * (TNB + 1); e += TLT) Ts[e] = 0.0;
+    if (tid < TNB) { s_alpha[tid] = 0.0; s_scal[tid] = 0.0; s_vjj[tid] = 0.0; }
+    __syncthreads();
+    // ---- register layout of THIS form: wave w owns the columns w, w + 8, w + 16, w + 24 (cyclic: the waves stay equally
+    // loaded while the active columns shrink), lane l the rows l, l + 64, l + 128, l + 192 of each.  A column step:
+    //   every wave reads v_j and 2 / v.v from LDS; the owner wave of column j + 1 updates THAT column first, takes its norm by
+    //   a wave reduction, runs the scalar chain once (not in every wave) and publishes v_(j+1) at once; then every wave:
+    //   g_c = v_j . a_c by a wave reduction per own column c > j + 1, a_c -= (2 / v.v) g_c v_j                  [barrier]
+    // One barrier per step (v_j alternates between two buffers), no partial sums through LDS, the reductions on the DPP
+    // network, the pivot's chain hidden behind the other waves' updates (look-ahead of one column).  (The other form keeps sixteen row groups per column across the waves: two barriers and ~240 instructions
+    // per wave and step, 2770 cycles; stamps in tools/README.md.)
+    const int wv = tid >> 6, ln = tid & 63;
+    double a[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[i][k] = sm[(wv + 8 * i) * TLD + ln + 64 * k];
+    __shared__ double sscal[2];
+    // publish column j of the owner wave (its values x, rows l + 64 k of lane l): v_j, 2 / v.v, and the scalars kept for T and R
+    auto publish = [&](int j, const double (&col)[4]) {
+        const int jb = j & 1;
+        double x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = ln + 64 * k >= j ? col[k] : 0.0;  // zero above the diagonal
+        const double s2 = wave_sum64((x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]));
+        const double akk = lane_f64(x[0], j);  // (j < 32: row j is slot 0 of lane j)
+        double nrm = 0.0, sc = 0.0;
+        if (s2 > TSQR_TINY2) {  // (see the other form: rank-deficient chunks)
+            double rs = __builtin_amdgcn_rsq(s2);
+            rs = rs * (1.5 - 0.5 * s2 * rs * rs);
+            nrm = s2 * rs;
+            nrm = nrm + 0.5 * rs * (s2 - nrm * nrm);
+            const double d = nrm * (nrm + fabs(akk));
+            double rd = __builtin_amdgcn_rcp(d);
+            rd = rd * (2.0 - d * rd);
+            sc = rd * (2.0 - d * rd);
+        }
+        const double alpha = akk > 0.0 ? -nrm : nrm;
+        const double vjj = akk - alpha;
+        if (ln == j) x[0] = vjj;  // the pivot entry of v_j
+#pragma unroll
+        for (int k = 0; k < 4; k++) vbuf[jb][ln + 64 * k] = x[k];
+        if (ln == 0) { sscal[jb] = sc; s_alpha[j] = alpha; s_scal[j] = sc; s_vjj[j] = vjj; }
+    };
+    if (wv == 0) publish(0, a[0]);
+    __syncthreads();
+    LEAF_STAMP(1)
+    for (int j = 0; j < q.nb; j++) {
+        const int jb = j & 1;
+        const double sc = sscal[jb];
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = vbuf[jb][ln + 64 * k];
+        // the NEXT pivot column first: its owner updates it and publishes v_(j+1) at once, while the other waves (and this one,
+        // afterwards) are still busy with step j — the owner's chain (update, norm, scalars) is off the step's critical path
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (wv + 8 * i == j + 1 && j + 1 < q.nb) {  // (wave-uniform)
+                const double g = wave_sum64((v[0] * a[i][0] + v[1] * a[i][1]) + (v[2] * a[i][2] + v[3] * a[i][3]));
+                const double f = sc * g;
+#pragma unroll
+                for (int k = 0; k < 4; k++) a[i][k] -= f * v[k];
+                publish(j + 1, a[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (wv + 8 * i > j + 1) {  // (wave-uniform)
+                const double g = wave_sum64((v[0] * a[i][0] + v[1] * a[i][1]) + (v[2] * a[i][2] + v[3] * a[i][3]));
+                const double f = sc * g;
+#pragma unroll
+                for (int k = 0; k < 4; k++) a[i][k] -= f * v[k];
+            }
+        }
+        __syncthreads();
+    }
+    LEAF_STAMP(2)
+    // V (zero above the diagonal, v_jj on it) -> LDS: for the Gram product, and for the coalesced way out
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int cc = wv + 8 * i;
+        const double d = s_vjj[cc];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = ln + 64 * k;
+            sm[cc * TLD + r] = (cc < q.nb && r >= cc) ? (r == cc ? d : a[i][k]) : 0.0;
+        }
+    }
+    __syncthreads();
+    {
+        double *V = q.V + (size_t)chunk * TNB * TCH + c * TCH + r0;
+#pragma unroll
+        for (int k = 0; k < TRG; k += 2) *(double2 *)(V + k) = *(const double2 *)&sm[c * TLD + r0 + k];
+    }
+    if (wave < 4) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const double *pa = sm + ((wave >> 1) * 16 + l15) * TLD + l4, *pb = sm + ((wave & 1) * 16 + l15) * TLD + l4;
+        v4d acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll 4
+        for (int k = 0; k < TCH; k += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k + 4 * u], pb[k + 4 * u], acc[u], 0, 0, 0);
+        }
+        const v4d w = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) G[((wave >> 1) * 16 + l4 + 4 * reg) * (TNB + 1) + (wave & 1) * 16 + l15] = w[reg];
+    }
+    __syncthreads();
+    LEAF_STAMP(3)
+    // T = [T11 T12; 0 T22] in 16 x 16 blocks.  Diagonal blocks: T[t][t] = scal_t, T[t][j] = -scal_j sum_{l=t}^{j-1}
+    // T[t][l] (v_l . v_j) — row t only depends on itself: lane t of each half keeps it in registers (120 multiply-adds,
+    // unrolled).  Then T12 = -T11 (V1^T V2) T22 by 256 threads.
+    if (tid < TNB) {
+        const int t = tid & 15, base = tid & 16;
+        double Tr[16];
+#pragma unroll
+        for (int l = 0; l < 16; l++) Tr[l] = l == t ? s_scal[base + t] : 0.0;
+#pragma unroll
+        for (int j = 1; j < 16; j++) {
+            double s2[2] = {0.0, 0.0};
+#pragma unroll
+            for (int l = 0; l < j; l++) s2[l & 1] += Tr[l] * G[(base + j) * (TNB + 1) + base + l];
+            const double v = -s_scal[base + j] * (s2[0] + s2[1]);
+            if (j > t) Tr[j] = v;
+        }
+#pragma unroll
+        for (int l = 0; l < 16; l++) Ts[(base + t) * (TNB + 1) + base + l] = Tr[l];
+    }
+    __syncthreads();
+    {
+        double *Xs = &part[0][0];  // [16][16]: (V1^T V2) T22
+        const int ia = (tid >> 4) & 15, ib = tid & 15;
+        if (tid < 256) {
+            double x = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) x += G[ia * (TNB + 1) + 16 + l] * Ts[(16 + l) * (TNB + 1) + 16 + ib];
+            Xs[ia * 16 + ib] = x;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            double y = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) y += Ts[ia * (TNB + 1) + l] * Xs[l * 16 + ib];
+            Ts[ia * (TNB + 1) + 16 + ib] = -y;
+        }
+    }
+    __syncthreads();
+    LEAF_STAMP(4)
+    double *T = q.T + (size_t)chunk * TNB * TNB;
+    for (int e = tid; e < TNB * TNB; e += TLT) T[e] = Ts[(e / TNB) * (TNB + 1) + e % TNB];
+    // R_i (upper triangular, alpha on the diagonal): rows 0..31 are slot 0 of lanes 0..31
+    if (ln < TNB) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cc = wv + 8 * i, r = ln;
+            const double val = cc < q.nb ? (r < cc ? a[i][0] : (r == cc ? s_alpha[cc] : 0.0)) : 0.0;
+            if (q.Rnext) {
+                const int rho = chunk * TNB + r;
+                q.Rnext[(size_t)(rho / TCH) * TNB * TCH + cc * TCH + rho % TCH] = val;
+            } else if (cc < q.nb && r <= cc) {
+                q.Rfinal[(size_t)cc * q.ldr + r] = val;
+            }
+        }
+    }
+    LEAF_STAMP(5)
+}
+
 struct TsqrApply {
     double *A;        // trailing columns: A[c * ldr + physical row]
     int ldr, ntrail;
@@ -553,6 +750,7 @@ static void tsqr_attrs()
     static bool done = false;
     if (done) return;
     (void)hipFuncSetAttribute((const void *)tsqr_leaf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_bytes());
+    (void)hipFuncSetAttribute((const void *)tsqr_leaf_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_leaf_bytes());
     (void)hipFuncSetAttribute((const void *)tsqr_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_apply_bytes());
     done = true;
 }
@@ -608,7 +806,11 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
                         hs[1] - hs[0], hs[2] - hs[1], hs[3] - hs[2], hs[4] - hs[3], hs[5] - hs[4], hs[5] - hs[0]);
             }
         }
-        hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks, batch), dim3(TLT), lds_leaf_bytes(), st, lf);
+        {
+            static const bool rows_form = getenv("SGPR_TSQR_LEAF") && atoi(getenv("SGPR_TSQR_LEAF")) == 1;  // the row-group form
+            if (rows_form) hipLaunchKernelGGL(tsqr_leaf_kernel, dim3(chunks, batch), dim3(TLT), lds_leaf_bytes(), st, lf);
+            else hipLaunchKernelGGL(tsqr_leaf_wave_kernel, dim3(chunks, batch), dim3(TLT), lds_leaf_bytes(), st, lf);
+        }
         if (rec && rec->nlev < 8) {
             TsqrLevel &lv = rec->lv[rec->nlev++];
             lv.V = Vl[l]; lv.T = Tl[l]; lv.n = n; lv.chunks = chunks; lv.stride = stride;
