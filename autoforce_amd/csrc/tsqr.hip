@@ -663,11 +663,15 @@ __global__ void qr_gather_r_kernel(int cols, const double *At, int ldr, double *
 // 32 x 32 diagonal block (lane = row, its row of the block in registers, the pivots passed through readlane: no
 // barriers inside), then all 1024 threads take the block's contribution out of the rows above (one 32-term dot per
 // row).  Two workgroup barriers per 32 columns instead of two per column.
-__global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const double *A, const double *y, double *x, size_t bs_work = 0)
+__global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const double *A, int ld, const double *y, double *x,
+                                                           size_t bs_mat = 0)
 {
+    // R COLUMN-major: element (i, c) at A[c * ld + i] — the factored matrix itself (its transposed storage), no gathered copy:
+    // a thread's row i of the 32-column block is 32 loads that are contiguous ACROSS the threads (the row-major copy made
+    // every one of them a cache line of its own: 17 us per block of 32 at m = 1024, 0.54 ms per solve)
     __shared__ double zs[2048];
     __shared__ double xb[32];
-    A += blockIdx.x * bs_work; y += blockIdx.x * bs_work; x += (size_t)blockIdx.x * cols;  // (a batch: one workgroup per problem)
+    A += blockIdx.x * bs_mat; y += blockIdx.x * bs_mat; x += (size_t)blockIdx.x * cols;  // (a batch: one workgroup per problem)
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < cols; i += 1024) zs[i] = y[i];
     __syncthreads();
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const doub
             const int i = b0 + (on ? lane : 0);
             double rr[32];
 #pragma unroll
-            for (int k = 0; k < 32; k++) rr[k] = (on && k < nbk) ? A[(size_t)i * cols + b0 + k] : (k == lane ? 1.0 : 0.0);
+            for (int k = 0; k < 32; k++) rr[k] = (on && k < nbk) ? A[(size_t)(b0 + k) * ld + i] : (k == lane ? 1.0 : 0.0);
             double zi = on ? zs[i] : 0.0;
 #pragma unroll
             for (int k = 31; k >= 0; k--) {
@@ -691,9 +695,9 @@ __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const doub
         }
         __syncthreads();
         for (int i = tid; i < b0; i += 1024) {
-            const double *r = A + (size_t)i * cols + b0;
+            const double *r = A + (size_t)b0 * ld + i;
             double s4[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int k = 0; k < nbk; k++) s4[k & 3] += r[k] * xb[k];
+            for (int k = 0; k < nbk; k++) s4[k & 3] += r[(size_t)k * ld] * xb[k];
             zs[i] -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
         }
         if (tid < nbk) x[b0 + tid] = xb[tid];
@@ -858,8 +862,8 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
         if (panels) panels->push_back(rec);
     }
     if (x) {
-        hipLaunchKernelGGL(qr_gather_r_kernel<true>, dim3((cols + 255) / 256, cols), dim3(256), 0, st, cols, At, ldr, Rc, cols, z);
-        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, Rc, z, x);
+        (void)Rc; (void)z;
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, At, ldr, At + (size_t)cols * ldr, x);
     }
     return 0;
 }
@@ -888,12 +892,10 @@ int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_m
                    batch, bs_mat, bs_work);
     }
     {
-        // R and z of every problem, then the back substitutions side by side: one workgroup each (one after the other they
-        // were two thirds of a sixteen-problem scan: 16 x 0.4 ms behind 3 ms of shared factorisation launches)
-        double *Rc = work + scratch, *z = Rc + (size_t)cols * cols;
-        hipLaunchKernelGGL(qr_gather_r_kernel<true>, dim3((cols + 255) / 256, cols, batch), dim3(256), 0, st, cols, At, ldr, Rc, cols, z,
-                           bs_mat, bs_work);
-        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(batch), dim3(1024), 0, st, cols, Rc, z, x, bs_work);
+        // the back substitutions side by side, one workgroup per problem, straight from the factored matrices (one after
+        // the other they were two thirds of a sixteen-problem scan: 16 x 0.4 ms behind 3 ms of shared factorisation launches)
+        (void)scratch;
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(batch), dim3(1024), 0, st, cols, At, ldr, At + (size_t)cols * ldr, x, bs_mat);
     }
     return 0;
 }
