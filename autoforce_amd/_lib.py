@@ -63,6 +63,11 @@ SIGNATURES = {
     "sgpr_bind_system": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
     "sgpr_packed_len": (_i64, [C.c_int]),
     "sgpr_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sgpr_step_dev_next": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgpr_md_begin": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl]),
+    "sgpr_md_run": (C.c_int, [_vp, C.c_int, _vp, _dbl, C.c_int, _vp, _vp, _vp]),
+    "sgpr_md_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "sgpr_md_end": (C.c_int, [_vp]),
     "sgpr_sync_check": (C.c_int, [_vp, _vp]),
     "sgpr_comm_unique_id": (C.c_int, [_vp]),
     "sgpr_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),

@@ -97,6 +97,21 @@ struct DevBuf {
     }
 };
 
+// device-resident molecular dynamics (sgpr_md_*): positions / velocities / results of the last three evaluations in
+// rings (sorted atom order), see FinNext
+struct MdState {
+    bool active = false;
+    int N = 0;
+    long long t = 0;               // evaluations completed (= index of the configuration to evaluate next)
+    double hdt = 0.0, c1 = 1.0, dt = 0.0;
+    DevBuf<double> X, V, P, KE, mass, sig, noise, noise_raw, cell;
+    DevBuf<int> halt;
+    int *halt_host = nullptr, *halt_host_dev = nullptr;
+    double *scal = nullptr, *scal_dev = nullptr;
+    size_t scal_rows = 0;
+    std::vector<double> mass_sorted;
+};
+
 struct sgpr_model {
     int lmax, nmax, S, device;
     double eta, rc;
@@ -160,6 +175,13 @@ struct sgpr_model {
     DevBuf<unsigned long long> d_hm;
     int hmw = 1;
     const int *step_flag = nullptr;  // the rebuild flag of the step being enqueued
+    // the last kernel of a step as the first of the next (finalize_next_kernel): what it pre-binned
+    bool pre_valid = false;
+    const double *pre_pos = nullptr, *pre_cell = nullptr;
+    unsigned pre_step = 0;
+    bool fuse_next = true;           // option "fuse_next" (SGPR_FUSE_NEXT=0 at creation): off = every step bins for itself
+    bool bin_identity = false;       // the positions handed to the binning kernel are in sorted order already (MD state)
+    MdState md;
     bool gather_ok = true;   // false: bin capacity / list length beyond the reverse-index format -> scatter form
     DevBuf<double> d_prec, d_G;
     DevBuf<double> d_gpart;
@@ -324,8 +346,51 @@ __global__ void transpose_kernel(int rows, int cols, const double *A, int lda, d
 // reproducible sums, no hand-shake with the packer workgroups.  (An earlier two-level form — every
 // block reduces a slice, release fence, ticket, last arriver combines — spent most of its 8 us in that
 // dependent chain.)
+// The last kernel of step s can also be the first of step s + 1 (finalize_next_kernel): when the next positions are
+// already on the device — the next frame of a resident batch (mode 1), or the outcome of the integrator, which is run
+// HERE, one wave per atom, right behind the force sum (mode 2: BAOAB Langevin / velocity Verlet as
+// workloads.langevin_nvt; the reference drives ase.md.langevin through cl/md.py:117-128) — the wave that finished
+// atom i bins it for step s + 1 and takes the rebuild decision (neighbor.hip::nl_bin_kernel, same rules at constant
+// cell).  One launch and one cold-start chain less per step; an MD loop never leaves the device.
+//   Quantities that need ALL atoms of step s (largest covloss, kinetic energy) are reduced by the reducer workgroups of
+// step s + 1's launch (the per-atom values of step s are in memory by then): the covloss gate of the reference's
+// calculate() (calculator/active.py:492-499) therefore fires one launch late — step s + 1 has been computed
+// speculatively by then and is discarded; positions, velocities and results of the last three steps are kept in
+// rings, so the state handed back is exactly step s.  After a halt every later launch of the queue exits at once.
+#define SGPR_MD_SCAL 16   // doubles per step in the host-visible scalar ring: E, virial[9], overflow, max covloss, 2 x kinetic energy
+struct FinNext {
+    int mode;                  // 0 none, 1 frames, 2 md, 3 md tail (only the lagged reductions of the last step)
+    int S, cap, force, step;   // species slots, slots per bin, rebuild regardless, this step's counter
+    int pbc[3];
+    double thr2;               // (skin / 2)^2: an atom farther than that from where the candidates were built -> rebuild
+    const double *pos_in;      // mode 1: positions of the next frame, caller order
+    const int *iperm, *cslot;  // mode 1: caller atom -> sorted index, species slot by caller index
+    double *pos;               // [N][3] sorted working positions (this step's, overwritten with the next step's)
+    int *flags;                // [4] rebuild flags by step counter & 3
+    int *bc_next, *bc_cur;     // bin populations: the next step's (filled here) and this step's (cleared here)
+    int *bin_of, *kslot;
+    BinRec *b_rec;
+    BinAux *b_aux;
+    double *csq_rw;            // covloss partials of this step: cleared behind the read
+    // md
+    const double *x_cur, *v_cur;   // [N][3] sorted: positions of this step, velocities BEFORE its closing half kick
+    double *x_next, *v_next;
+    const double *mass, *sig;      // [N] sorted: mass, c2 sqrt(kT / m)
+    const double *noise;           // [N][3] SORTED order (sorted on upload): the normal deviates of the next step's O (null: none)
+    double hdt, c1;                // dt / 2, exp(-friction dt)
+    int pending;                   // the closing half kick of this step is due (0 only for the very first evaluation)
+    double *ke_cur;                // [N] m v^2 of this step
+    const double *ke_prev, *packed_prev;   // the same / the packed results of step s - 1 (null: no such step in this run)
+    double ediff;                  // halt when the largest covloss of a step reaches it
+    int *halt;                     // device: the first step that halted the run (INT_MAX: running; atomicMin)
+    int *halt_host;                // mapped host memory, polled between chunks of launches: [0] the step whose covloss
+                                   //   reached ediff, [1] the step that overflowed a capacity (INT_MAX: none)
+    double *scal_cur, *scal_prev;  // rows of the scalar ring (mapped host memory)
+};
+
 struct FinArgs {
     int N, cnt, first, stride, maxnn, t_stride, has_beta, nE, nV, bin_cap, t_check, csq_slots;
+    int nbins_clear;            // bin counters to clear (4096: all)
     const int *perm, *slot, *nn, *nbr_j, *aux, *nn_raw;
     const unsigned short *T;
     const double *G;            // gather form: [N][maxnn][4]
@@ -345,6 +410,7 @@ struct FinArgs {
     const double *cell;         // this step's cell and bin grid (its inverse): kept as cell0[0..8], cell0[9..17] on
     const NlGrid *grid;         //   rebuild steps — the reference frame of the affine rebuild rule (neighbor.hip)
     double *cell0;
+    FinNext nx;                 // finalize_next_kernel: what this launch does for the NEXT step
 };
 
 // wave64 sum on the DPP network (quads, half rows, rows) and four scalar row sums: the result is wave-uniform and
@@ -438,7 +504,69 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
             // over ranks by the all-reduce, so every rank learns that the step must be repeated
             const bool ov = mx > f.maxnn || f.stat[1] > f.bin_cap || (f.t_check && f.stat[2] > f.t_stride) || f.stat[3] != 0;
             f.packed[4 * (size_t)f.N + 10] = ov ? 1.0 : 0.0;
-        } else if (q != 10) f.packed[by * f.p_stride + 4 * (size_t)f.N + q] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
+            if (f.nx.mode == 2) {
+                f.nx.scal_cur[10] = ov ? 1.0 : 0.0;
+                if (ov) {  // the lists of this step were clamped: its results and the state integrated from them are void
+                    atomicMin(&f.nx.halt[0], f.nx.step);
+                    f.nx.halt_host[1] = f.nx.step;
+                }
+            }
+        } else if (q != 10) {
+            const double v = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
+            f.packed[by * f.p_stride + 4 * (size_t)f.N + q] = v;
+            if (f.nx.mode == 2) f.nx.scal_cur[q] = v;
+        }
+    }
+}
+
+// lagged reductions of an MD run (finalize_next_kernel): q = 0 the largest covloss of the PREVIOUS step (and the halt
+// decision of the covloss gate, calculator/active.py:492-499), q = 1 its kinetic energy sum m v^2 (fixed order)
+__device__ __forceinline__ void finalize_reduce_prev(const FinArgs &f, int q)
+{
+    __shared__ double wprev[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int N = f.N;
+    double s = 0.0;
+    if (q == 0) {
+        const double *b = f.nx.packed_prev + 3 * (size_t)N;
+        double m8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int k0 = tid; k0 < N; k0 += 2048) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 256 * u;
+                const double v = b[min(k, N - 1)];
+                m8[u] = fmax(m8[u], k < N ? v : 0.0);
+            }
+        }
+        s = fmax(fmax(fmax(m8[0], m8[1]), fmax(m8[2], m8[3])), fmax(fmax(m8[4], m8[5]), fmax(m8[6], m8[7])));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+    } else {
+        const double *src = f.nx.ke_prev;
+        double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int k0 = tid; k0 < N; k0 += 2048) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = k0 + 256 * u;
+                const double v = src[min(k, N - 1)];
+                a8[u] += k < N ? v : 0.0;
+            }
+        }
+        s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        s = fin_wave_sum(s);
+    }
+    if (lane == 0) wprev[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        if (q == 0) {
+            const double bmax = fmax(fmax(wprev[0], wprev[1]), fmax(wprev[2], wprev[3]));
+            f.nx.scal_prev[11] = bmax;
+            if (bmax >= f.nx.ediff) {
+                atomicMin(&f.nx.halt[0], f.nx.step - 1);
+                f.nx.halt_host[0] = f.nx.step - 1;
+            }
+        } else
+            f.nx.scal_prev[12] = (wprev[0] + wprev[1]) + (wprev[2] + wprev[3]);
     }
 }
 
@@ -449,7 +577,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
     if (b >= nA) { finalize_reduce(f, b - nA); return; }
     const int i = b * blockDim.x + tid;
     const size_t by = blockIdx.y;
-    for (int k = i; k < 4096; k += nA * blockDim.x) f.bin_count[k] = 0;
+    for (int k = i; k < f.nbins_clear; k += nA * blockDim.x) f.bin_count[(size_t)k * SGPR_BIN_STRIDE] = 0;
     if (i < f.N) {
         const int c = f.perm[i];
         if (*f.flag) {
@@ -478,7 +606,7 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
 {
     const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
     if (b >= nA) { finalize_reduce(f, b - nA); return; }
-    for (int k = b * 256 + tid; k < 4096; k += nA * 256) f.bin_count[k] = 0;
+    for (int k = b * 256 + tid; k < f.nbins_clear; k += nA * 256) f.bin_count[(size_t)k * SGPR_BIN_STRIDE] = 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int i = b * 4 + wave;
     if (i >= f.N) return;
@@ -530,6 +658,201 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
         const double v = 1.0 - cs;
         packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
     }
+}
+
+// The same gather, and with it the first kernel of the NEXT step (FinNext): a wave takes an atom to its next position —
+// read from the next frame (MODE 1) or integrated (MODE 2) —, bins it there and takes part in the rebuild decision.
+// Grid: ceil(N / 4) gather workgroups, 11 reducers of this step, 2 lagged reducers.
+//   What bounds this kernel is its chain of dependent memory round trips, each of them a cold miss (2 - 3 us per link at
+// 4096 atoms).  The gather alone is two links (row + counts -> sums -> stores), the binning kernel four (index -> position
+// -> returning atomic -> record).  Fused naively they add up (12.4 us against 7.1 + 4.4 as two launches, measured).  So:
+//   * MODE 1: the two jobs of a wave are INDEPENDENT — it sums the forces of sorted atom number w and bins CALLER atom
+//     number w (position and species slot by caller index: no indirection in front of the atomic); the atomic is issued
+//     before the sums, its record is stored after them;
+//   * MODE 2: the position depends on the force, but on nothing else behind an indirection (the noise is sorted on upload);
+//   * the halt word of an MD run is requested with everything else and looked at before the first store.
+template <int MODE>
+__global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
+{
+    const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 13;
+    const FinNext &x = f.nx;
+    const int halt_w = MODE == 2 ? *x.halt : 0x7fffffff;
+    if (b >= nA) {
+        // a run that has halted (covloss gate / capacity overflow at an earlier step): nothing may be touched any more
+        if (halt_w < x.step) return;
+        if (b >= nA + 11) {
+            if (MODE == 2 && x.packed_prev) finalize_reduce_prev(f, b - nA - 11);
+        } else
+            finalize_reduce(f, b - nA);
+        return;
+    }
+    const int s1 = x.step + 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int i = b * 4 + wave;          // sorted atom whose forces this wave sums
+    const bool act = i < f.N;
+    const int ia = act ? i : 0;
+    // ---- requests: ONE round trip.  Every load below is unconditional (clamped indices, the value masked afterwards): a
+    // load inside `if (lane < 3)` or behind `act` becomes a branch with an s_waitcnt vmcnt(0) at its join, and the five
+    // such joins of the first version of this kernel were five cold misses one behind the other (ISA; 12.4 us)
+    const int l3 = lane < 3 ? lane : 2, lg = lane < f.maxnn ? lane : f.maxnn - 1, lc = lane < f.csq_slots ? lane : f.csq_slots - 1;
+    const int rebuilt = *f.flag;
+    const NlGrid g = *f.grid;
+    const double2 *grow = (const double2 *)(f.G + ((size_t)ia * f.maxnn + lg) * 4);
+    double2 g0 = grow[0], g1 = grow[1];
+    const int n_ld = f.nn[ia];
+    double fs = f.Fself[3 * (size_t)ia + l3];
+    const int c = f.perm[ia];
+    const int slot_i = f.slot[ia];
+    // the atom this wave BINS: MODE 1: caller atom number i (sorted index ib = iperm[i]); MODE 2: sorted atom i itself
+    const int ib = MODE == 1 ? x.iperm[ia] : ia;
+    const int slot_b = MODE == 1 ? x.cslot[ia] : slot_i;
+    double xc = 0.0, p0 = 0.0, vc = 0.0, ms = 1.0, sg = 0.0, nz = 0.0, xn = 0.0;
+    if (MODE == 1) xn = x.pos_in[3 * (size_t)ia + l3];
+    if (MODE == 2) {
+        xc = x.x_cur[3 * (size_t)ia + l3];
+        p0 = f.pos0[3 * (size_t)ia + l3];
+        vc = x.v_cur[3 * (size_t)ia + l3];
+        ms = x.mass[ia];
+        sg = x.sig[ia];
+        nz = x.noise ? x.noise[3 * (size_t)ia + l3] : 0.0;   // (wave-uniform condition)
+    }
+    double csv = f.has_beta ? f.csq[(size_t)ia * f.csq_slots + lc] : 0.0;   // (wave-uniform condition)
+    if (lane >= f.csq_slots) csv = 0.0;
+    if (f.has_beta)
+        for (int k = lane + 64; k < f.csq_slots; k += 64) csv += f.csq[(size_t)ia * f.csq_slots + k];  // (more than 64 slots: rare)
+    if (lane >= f.maxnn) { g0 = make_double2(0.0, 0.0); g1 = g0; }
+    if (lane >= 3) fs = 0.0;
+    const int n = act ? n_ld : 0;
+    // second link (beside the atomic below): what hangs on an index that was itself loaded
+    const double vs = f.has_beta ? f.vs_sqrt[slot_i < x.S ? slot_i : 0] : 0.0;
+    if (MODE == 1) {
+        xc = x.pos[3 * (size_t)ib + l3];
+        p0 = f.pos0[3 * (size_t)ib + l3];
+    }
+    if (halt_w < x.step) return;  // (before the first store)
+    for (int k = b * 256 + tid; k < f.nbins_clear; k += nA * 256) x.bc_cur[(size_t)k * SGPR_BIN_STRIDE] = 0;
+    if (b == 0 && tid == 0) {
+        // binning of step s + 1: its flag is flag[(s + 1) & 3] (cleared two binnings ago, read by nobody now); the flag of
+        // step s + 3 is cleared for the binning after the next (neighbor.hip does the same with its cycle)
+        if (x.force) atomicMax(&x.flags[s1 & 3], 1);
+        x.flags[(s1 + 2) & 3] = 0;
+    }
+    if (!act) return;
+    if (f.has_beta)
+        for (int k = lane; k < f.csq_slots; k += 64) x.csq_rw[(size_t)i * f.csq_slots + k] = 0.0;  // (the binning kernel clears these)
+    // bin of a position (lane 0 of the wave), and the atomic that hands out its slot
+    int bin = 0, kb = -1, w0 = 0, w1 = 0, w2 = 0;
+    auto place = [&](double X, double Y, double Z) {
+        int bidx[3], w[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double fr = X * g.inv[k] + Y * g.inv[3 + k] + Z * g.inv[6 + k];
+            w[k] = 0;
+            bidx[k] = 0;
+            if (x.pbc[k] && (g.inv[k] != 0.0 || g.inv[3 + k] != 0.0 || g.inv[6 + k] != 0.0)) {
+                const double fl = floor(fr);
+                w[k] = (int)fl;
+                fr -= fl;
+                const int bb = (int)(fr * g.nb[k]);
+                bidx[k] = bb >= g.nb[k] ? g.nb[k] - 1 : (bb < 0 ? 0 : bb);
+            }
+        }
+        bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
+        w0 = w[0]; w1 = w[1]; w2 = w[2];
+        if (slot_b < x.S) kb = atomicAdd(&x.bc_next[(size_t)bin * SGPR_BIN_STRIDE], 1);
+    };
+    double X = 0.0, Y = 0.0, Z = 0.0;
+    if (MODE == 1) {
+        X = fin_lane(xn, 0); Y = fin_lane(xn, 1); Z = fin_lane(xn, 2);
+        if (lane == 0) place(X, Y, Z);   // (the atomic's round trip runs beside the second link's loads)
+    }
+    // ---- the forces of atom i
+    const double cs = f.has_beta ? fin_wave_sum(csv) : 1.0;
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < n) {
+            double2 b0 = g0, b1 = g1;
+            if (t0 > 0) {
+                const double2 *row = (const double2 *)(f.G + ((size_t)i * f.maxnn + t) * 4);
+                b0 = row[0]; b1 = row[1];
+            }
+            fx += b0.x; fy += b0.y; fz += b1.x;
+        }
+    }
+    fx = fin_wave_sum(fx); fy = fin_wave_sum(fy); fz = fin_wave_sum(fz);
+    const double Fv = fs - (lane == 0 ? fx : lane == 1 ? fy : fz);
+    if (lane < 3) f.packed[3 * (size_t)c + lane] = Fv;
+    if (lane == 3) {
+        const double v = 1.0 - cs;
+        f.packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
+    }
+    // ---- the next step
+    double ke = 0.0;
+    if (MODE == 2 && lane < 3) {
+        // BAOAB, exactly the operations (and their order) of workloads.langevin_nvt: no contraction into fused
+        // multiply-adds, a true division
+#pragma clang fp contract(off)
+        const double kick = __ddiv_rn(x.hdt * Fv, ms);
+        double v = vc;
+        if (x.pending) v = v + kick;       // closes step s: the velocity an observer sees at step s
+        ke = ms * (v * v);
+        const double v2 = v + kick;        // B
+        const double x1 = xc + x.hdt * v2; // A
+        const double v3 = x.c1 * v2 + sg * nz;  // O
+        xn = x1 + x.hdt * v3;              // A
+        x.x_next[3 * (size_t)i + lane] = xn;
+        x.v_next[3 * (size_t)i + lane] = v3;
+    }
+    if (MODE == 2) {
+        const double k3 = fin_lane(ke, 0) + fin_lane(ke, 1) + fin_lane(ke, 2);
+        if (lane == 0) x.ke_cur[i] = k3;
+        X = fin_lane(xn, 0); Y = fin_lane(xn, 1); Z = fin_lane(xn, 2);
+        if (lane == 0) place(X, Y, Z);
+    }
+    if (rebuilt) p0 = xc;  // this step rebuilt the candidates: built at this step's positions
+    if (lane < 3) {
+        x.pos[3 * (size_t)ib + lane] = xn;
+        if (rebuilt) f.pos0[3 * (size_t)ib + lane] = xc;
+    }
+    const double dd = xn - p0;
+    const double d2 = fin_lane(dd, 0) * fin_lane(dd, 0) + fin_lane(dd, 1) * fin_lane(dd, 1) + fin_lane(dd, 2) * fin_lane(dd, 2);
+    if (lane == 0) {
+        if (!(d2 <= x.thr2)) atomicMax(&x.flags[s1 & 3], 1);
+        x.bin_of[ib] = bin;
+        x.kslot[ib] = kb;
+        if (slot_b < x.S) {
+            if (max(max(abs(w0), abs(w1)), abs(w2)) > 32767) atomicMax(&f.stat[3], 1);
+            if (kb < x.cap) {
+                const size_t e = (size_t)bin * x.cap + kb;
+                BinRec r;
+                r.x = X; r.y = Y; r.z = Z; r.idx = ib; r.pad = 0;
+                x.b_rec[e] = r;
+                BinAux ax;
+                ax.w0 = (short)w0; ax.w1 = (short)w1; ax.w2 = (short)w2; ax.slot = (short)slot_b;
+                x.b_aux[e] = ax;
+            } else
+                atomicMax(&f.stat[1], kb + 1);
+        }
+    }
+}
+
+// normal deviates of an MD run, caller order -> sorted order (so that the integrator reads them without an indirection)
+__global__ void md_sort_rows_kernel(int N, int rows, const int *perm, const double *in, double *out)
+{
+    const size_t n3 = (size_t)3 * N, tot = n3 * rows;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / n3, w = e - r * n3;
+        const int i = (int)(w / 3), k = (int)(w - 3 * (size_t)i);
+        out[e] = in[r * n3 + 3 * (size_t)perm[i] + k];
+    }
+}
+
+// the lagged reductions of the LAST step of an MD run (there is no next launch to carry them)
+__global__ __launch_bounds__(256) void finalize_tail_kernel(FinArgs f)
+{
+    if (*f.nx.halt < f.nx.step) return;
+    finalize_reduce_prev(f, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------- host tables
@@ -631,11 +954,12 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     upload_harm_coef(hc);
     h->d_grid.alloc(1024);  // the step's grid (128 B) + two cached {grid, cell} records by step parity (256 B each from 256)
     h->d_stat.alloc(4);
-    h->d_bin_count.alloc(4096);
+    h->d_bin_count.alloc(2 * SGPR_BIN_INTS);  // by step parity (a fused last kernel fills the next step's while this step's is cleared)
     h->d_cell_in.alloc(9);
-    h->d_flag.alloc(4);  // [0..1] rebuild flags by step parity, [2] count of rebuilds, [3] always zero
+    h->d_flag.alloc(8);  // [0..3] rebuild flags by step counter & 3, [4] count of rebuilds, [5] always zero
     h->d_cell0.alloc(18);  // cell at the last rebuild + its inverse
     if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_FUSE_NEXT")) h->fuse_next = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
@@ -1314,7 +1638,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
         for (int i = 0; i < N; i++)
             if (slot[i] < h->S) h->mean_energy += h->mean_w[slot[i]];
     int bad = 0;
-    bad |= h->d_perm.alloc(std::max(N, 1), false);
+    bad |= h->d_perm.alloc(3 * (size_t)std::max(N, 1), false);  // sorted -> caller | caller -> sorted | species slot by caller index
     bad |= h->d_slot.alloc(h->N_rows, false);
     bad |= h->d_aoff.alloc(h->S + 1, false);
     bad |= h->d_lslot.alloc(h->cnt_rows, false);
@@ -1331,7 +1655,9 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     bad |= h->d_gpart.alloc((size_t)12 * ((std::max(N, 1) + 255) / 256));
     if (bad) return fail(SGPR_E_NODEVICE, "hipMalloc failed (system arrays)");
     if (N > 0) {
-        HIPCHK(hipMemcpy(h->d_perm.p, h->perm.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+        std::vector<int> pp(3 * (size_t)N);
+        for (int i = 0; i < N; i++) { pp[i] = h->perm[i]; pp[(size_t)N + h->perm[i]] = i; pp[2 * (size_t)N + i] = slot[i]; }
+        HIPCHK(hipMemcpy(h->d_perm.p, pp.data(), sizeof(int) * pp.size(), hipMemcpyHostToDevice));
         std::vector<int> ss(h->N_rows, -1);
         std::copy(h->slot_sorted.begin(), h->slot_sorted.end(), ss.begin());
         HIPCHK(hipMemcpy(h->d_slot.p, ss.data(), sizeof(int) * h->N_rows, hipMemcpyHostToDevice));
@@ -1371,30 +1697,56 @@ static void stamp(sgpr_model *h, const char *name, hipStream_t st)
 // otherwise from the two force buffers of the scatter form (zero when no reverse pass ran).
 struct FinBatch { int batch; double *G, *F, *virpart; size_t g_stride, f_stride, v_stride, p_stride; const int *cols; };
 
+// what the last kernel of a step does for the NEXT one (FinNext): the host side
+struct StepNext {
+    int mode = 0;                      // 1: the next frame's positions are on the device, 2: integrate (sgpr_md_run)
+    const double *pos_next = nullptr;  // mode 1: caller order
+    FinNext md;                        // mode 2: the integrator's fields (the binning fields are filled in launch_finalize)
+};
+
 static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool beta, double mean_energy,
-                            double *packed_dev, hipStream_t st, const FinBatch *fb = nullptr)
+                            double *packed_dev, hipStream_t st, const FinBatch *fb = nullptr, const StepNext *nx = nullptr,
+                            unsigned step = 0)
 {
     const int N = h->N;
     FinArgs f = {};
     f.N = N; f.cnt = h->cnt; f.first = h->rank; f.stride = h->world; f.maxnn = h->maxnn; f.t_stride = h->t_stride;
-    f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV; f.bin_cap = h->bin_cap;
+    f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV; f.bin_cap = h->bin_cap; f.nbins_clear = 4096;
     f.t_check = (h->world == 1 && h->gather_ok) ? 1 : 0;
     f.perm = h->d_perm.p; f.slot = h->d_slot.p; f.nn = h->d_nn.p; f.nbr_j = h->d_nbr_j.p; f.aux = h->d_aux.p;
     f.nn_raw = h->d_nn_raw.p; f.T = h->d_T.p; f.G = h->d_G.p; f.Fnbr = h->d_F.p; f.Fself = h->d_F.p + 3 * (size_t)N;
     f.csq = h->d_csq.p; f.csq_slots = h->csq_slots; f.vs_sqrt = h->d_vs_sqrt.p; f.Epart = h->d_Epart.p; f.virpart = h->d_virpart.p;
     f.mean_energy = mean_energy; f.packed = packed_dev; f.stat = h->d_stat.p; f.bin_count = h->d_bin_count.p;
     f.flag = h->step_flag ? h->step_flag : h->d_flag.p; f.pos = h->d_pos.p; f.pos0 = h->d_pos0.p;
-    f.rebuilds = h->d_flag.p + 2;
+    f.rebuilds = h->d_flag.p + 4;
     f.cell = h->last_cell; f.grid = (const NlGrid *)h->d_grid.p; f.cell0 = h->d_cell0.p;
     int batch = 1;
+    if (fb) step = h->step_count - 1;  // (the step whose lists the batch re-uses)
     if (fb) {
         // column batches of the training rows re-use the lists of the step that ran just before them: that step's
         // finalize has done the rebuild bookkeeping (pos0, cell0, the rebuild counter) — not again per batch
-        f.flag = h->d_flag.p + 3;
+        f.flag = h->d_flag.p + 5;
         batch = fb->batch;
         f.G = fb->G; f.Fnbr = fb->F; f.Fself = fb->F + 3 * (size_t)N; f.virpart = fb->virpart;
         f.g_stride = fb->g_stride; f.f_stride = fb->f_stride; f.v_stride = fb->v_stride; f.p_stride = fb->p_stride;
         f.row_cols = fb->cols; f.row_colslot = h->d_ind_slot.p; f.nbr_code = h->d_nbr_shift.p;
+    }
+    f.bin_count = h->d_bin_count.p + SGPR_BIN_INTS * (step & 1u);
+    if (nx && nx->mode) {
+        FinNext &x = f.nx;
+        if (nx->mode == 2) x = nx->md;
+        x.mode = nx->mode; x.S = h->S; x.cap = h->bin_cap; x.force = h->skin <= 0.0 ? 1 : 0; x.step = (int)step;
+        for (int k = 0; k < 3; k++) x.pbc[k] = h->pbc[k];
+        x.thr2 = 0.25 * h->skin * h->skin;
+        x.pos_in = nx->pos_next; x.pos = h->d_pos.p; x.flags = h->d_flag.p;
+        x.iperm = h->d_perm.p + N; x.cslot = h->d_perm.p + 2 * (size_t)N;
+        x.bc_cur = h->d_bin_count.p + SGPR_BIN_INTS * (step & 1u); x.bc_next = h->d_bin_count.p + SGPR_BIN_INTS * ((step + 1) & 1u);
+        x.bin_of = h->d_bin_of.p; x.kslot = h->d_kslot.p; x.b_rec = h->d_b_rec.p; x.b_aux = h->d_b_aux.p;
+        x.csq_rw = h->d_csq.p;
+        const dim3 grid((std::max(N, 1) + 3) / 4 + 13);
+        if (nx->mode == 1) hipLaunchKernelGGL(finalize_next_kernel<1>, grid, dim3(256), 0, st, f);
+        else hipLaunchKernelGGL(finalize_next_kernel<2>, grid, dim3(256), 0, st, f);
+        return;
     }
     if (gather)
         hipLaunchKernelGGL(finalize_gather_kernel, dim3((std::max(N, 1) + 3) / 4 + 11, batch), dim3(256), 0, st, f);
@@ -1403,7 +1755,7 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
 }
 
 static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell_dev, double *packed_dev,
-                        hipStream_t st)
+                        hipStream_t st, const StepNext *nx = nullptr)
 {
     const int N = h->N, cnt = h->cnt;
     h->last_cell = cell_dev;
@@ -1429,14 +1781,23 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     // candidate lists: reused while nobody moved more than skin/2 (decided on the device, neighbor.hip); a
     // captured graph cannot alternate the flag parity, so it rebuilds every step
     const double skin = h->use_graph ? 0.0 : h->skin;
-    sc.flag = h->d_flag.p; sc.parity = (int)(h->step_count++ & 1u);
+    const unsigned step = h->step_count++;
+    sc.bin_count = h->d_bin_count.p + SGPR_BIN_INTS * (step & 1u);
+    sc.flag = h->d_flag.p; sc.parity = (int)(step & 1u); sc.fslot = (int)(step & 3u); sc.fclear = (int)((step + 2) & 3u);
     sc.force = (!h->lists_valid || skin <= 0.0) ? 1 : 0;
     sc.skin = skin; sc.pos0 = h->d_pos0.p; sc.cell0 = h->d_cell0.p; sc.ncand = h->d_ncand.p; sc.cand_j = h->d_cand_j.p;
     sc.cand_code = h->d_cand_code.p; sc.cidx = h->d_cidx.p; sc.hm = h->d_hm.p; sc.hmw = h->hmw;
-    h->step_flag = h->d_flag.p + sc.parity;
-    launch_neighbor_bin(np, h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc + skin, sc, h->d_F.p, 3 * N, h->d_csq.p, cnt * h->csq_slots,
-                        st);
-    stamp(h, "neighbor_bin", st);
+    h->step_flag = h->d_flag.p + sc.fslot;
+    // the previous step's last kernel may have binned this step already (finalize_next_kernel): same positions, same cell,
+    // consecutive step counters.  Pre-binned for something else: its bin populations are dropped.
+    const bool pre = h->pre_valid && h->pre_pos == pos_dev && h->pre_cell == cell_dev && h->pre_step == step && !sc.force;
+    if (h->pre_valid && !pre) (void)hipMemsetAsync(sc.bin_count, 0, SGPR_BIN_INTS * sizeof(int), st);
+    h->pre_valid = false;
+    if (!pre) {
+        launch_neighbor_bin(np, h->bin_identity ? nullptr : h->d_perm.p, pos_dev, h->d_pos.p, cell_dev, h->rc + skin, sc, h->d_F.p, 3 * N,
+                            h->d_csq.p, cnt * h->csq_slots, st);
+        stamp(h, "neighbor_bin", st);
+    }
     DescParams dp = {};
     dp.lmax = h->lmax; dp.nmax = h->nmax; dp.S = h->S; dp.N = cnt; dp.Nall = N; dp.first = h->rank;
     dp.stride = h->world; dp.maxnn = h->maxnn; dp.Dc = h->Dc; dp.Dpad = h->Dpad; dp.CS = h->CS; dp.rc = h->rc;
@@ -1508,9 +1869,15 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         stamp(h, cov_rides ? "descriptor_rev_covloss" : "descriptor_rev", st);
     }
     if (forked) (void)hipStreamWaitEvent(st, h->ev_join, 0);
+    // the last kernel also opens the next step when the caller has said where the next positions are (same cell), the frame
+    // is not sharded and nothing of the step ran on a side stream
+    const bool fuse = nx && nx->mode && h->fuse_next && gather && predict && !forked && !h->use_graph && h->comm == nullptr && h->skin > 0.0;
     launch_finalize(h, gather && predict, predict ? h->epart_len : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
-                    packed_dev, st);
-    stamp(h, "finalize", st);
+                    packed_dev, st, nullptr, fuse ? nx : nullptr, step);
+    if (fuse) {
+        h->pre_valid = true; h->pre_pos = nx->pos_next; h->pre_cell = cell_dev; h->pre_step = step + 1;
+    }
+    stamp(h, fuse ? "finalize_bin_next" : "finalize", st);
     return SGPR_OK;
 }
 
@@ -1532,7 +1899,8 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
     }
     for (int attempt = 0; attempt < 12; attempt++) {
         HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 4 * sizeof(int), st));
-        HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 4096 * sizeof(int), st));
+        HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
+        h->pre_valid = false;
         const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st);
         if (rc_) return rc_;
         HIPCHK(hipStreamSynchronize(st));
@@ -1844,6 +2212,256 @@ extern "C" int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const d
     return SGPR_OK;
 }
 
+// sgpr_step_dev with the positions of the NEXT step named: the step's last kernel bins them (one launch and one cold
+// start less per step: DESIGN.md §3).  The next call must pass exactly `positions_next_dev` and the same cell pointer to
+// profit; any other call is served as usual.
+extern "C" int sgpr_step_dev_next(sgpr_model *h, const double *positions_dev, const double *cell_dev, double *packed_dev,
+                                  const double *positions_next_dev, void *stream)
+{
+    if (!h || !positions_dev || !cell_dev || !packed_dev) return fail(SGPR_E_INVALID, "sgpr_step_dev_next: bad arguments");
+    if (h->N <= 0) return fail(SGPR_E_INVALID, "sgpr_step_dev_next: call sgpr_bind_system first");
+    if (!h->warm || h->use_graph || !positions_next_dev) return sgpr_step_dev(h, positions_dev, cell_dev, packed_dev, stream);
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    StepNext nx;
+    nx.mode = 1; nx.pos_next = positions_next_dev;
+    int rc_ = enqueue_step(h, positions_dev, cell_dev, packed_dev, st, &nx);
+    if (!rc_) rc_ = reduce_packed(h, packed_dev, st);
+    return rc_;
+}
+
+// ---------------------------------------------------------------------------- device-resident molecular dynamics
+// The reference integrates in ASE (cl/md.py:117-128: ase.md.langevin.Langevin around ActiveCalculator; velocities
+// from util/aseutil.py:11-20) and crosses into the calculator once per step.  Here the state (positions, velocities)
+// lives in HBM, the integrator is part of the step's last kernel (finalize_next_kernel<2>), and the host reads a few
+// scalars per step; the covloss gate of calculate() (calculator/active.py:492-499) halts the run ON THE DEVICE at the
+// step whose largest covloss reaches `ediff`, with that step's state and results intact for the model update.
+static int md_alloc(sgpr_model *h, int N)
+{
+    MdState &m = h->md;
+    bool bad = false;
+    bad |= m.X.alloc((size_t)9 * N); bad |= m.V.alloc((size_t)9 * N); bad |= m.P.alloc(3 * (size_t)sgpr_packed_len(N));
+    bad |= m.KE.alloc((size_t)3 * N); bad |= m.mass.alloc(N); bad |= m.sig.alloc(N); bad |= m.cell.alloc(9);
+    bad |= m.halt.alloc(4);
+    if (bad) return fail(SGPR_E_NODEVICE, "sgpr_md_begin: device allocation failed");
+    if (!m.halt_host) {
+        if (hipHostMalloc((void **)&m.halt_host, 64, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&m.halt_host_dev, m.halt_host, 0) != hipSuccess)
+            return fail(SGPR_E_NODEVICE, "sgpr_md_begin: no mapped host memory");
+    }
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
+                             const int32_t *pbc, const double *masses, const double *velocities, double dt,
+                             double friction, double kT)
+{
+    if (!h || N <= 0 || !numbers || !positions || !cell || !masses)
+        return fail(SGPR_E_INVALID, "sgpr_md_begin: bad arguments");
+    if (!(dt > 0.0) || friction < 0.0 || kT < 0.0) return fail(SGPR_E_INVALID, "sgpr_md_begin: dt > 0, friction >= 0, kT >= 0");
+    HIPCHK(hipSetDevice(h->device));
+    bool same = (N == h->N && h->rank == 0 && h->world == 1 && (int)h->numbers.size() == N);
+    for (int i = 0; i < N && same; i++) same = h->numbers[i] == numbers[i];
+    for (int k = 0; k < 3 && same; k++) same = h->pbc[k] == (pbc ? (pbc[k] != 0) : 1);
+    int rc_ = same ? SGPR_OK : sgpr_bind_system(h, N, numbers, pbc, 0, 1);
+    if (rc_) return rc_;
+    rc_ = md_alloc(h, N);
+    if (rc_) return rc_;
+    MdState &m = h->md;
+    m.N = N; m.t = 0; m.dt = dt; m.hdt = 0.5 * dt; m.c1 = exp(-friction * dt);
+    const double c2 = sqrt(1.0 - m.c1 * m.c1);
+    std::vector<double> xs((size_t)3 * N), vs((size_t)3 * N, 0.0), ms(N), sg(N);
+    for (int i = 0; i < N; i++) {
+        const int c = h->perm[i];
+        for (int k = 0; k < 3; k++) {
+            xs[3 * (size_t)i + k] = positions[3 * (size_t)c + k];
+            if (velocities) vs[3 * (size_t)i + k] = velocities[3 * (size_t)c + k];
+        }
+        ms[i] = masses[c];
+        if (!(ms[i] > 0.0)) return fail(SGPR_E_INVALID, "sgpr_md_begin: mass of atom %d is not positive", c);
+        sg[i] = friction > 0.0 ? c2 * sqrt(kT / ms[i]) : 0.0;   // (as workloads.langevin_nvt: c2 * np.sqrt(kT / mass))
+    }
+    m.mass_sorted = ms;
+    HIPCHK(hipMemcpy(m.X.p, xs.data(), sizeof(double) * 3 * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.V.p, vs.data(), sizeof(double) * 3 * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.mass.p, ms.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.sig.p, sg.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m.cell.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice));
+    m.active = true;
+    h->pre_valid = false;
+    return SGPR_OK;
+}
+
+// Evaluates `nevals` configurations starting with the current one; after each evaluation but (with `final`) the last
+// the integrator moves on with the next row of `noise` ([nevals][N][3] standard normal deviates, caller atom order; null:
+// velocity Verlet).  Stops at the first evaluation whose largest covloss reaches `ediff` (<= 0: never): *evals_done
+// counts the evaluations whose results stand, the halting one included; the state then IS that configuration (its
+// forces are evaluated again by the next call — after the caller has updated the model).
+// scalars: [nevals][SGPR_MD_SCAL] = E, virial(9), overflow, largest covloss, sum m v^2, 0, 0, 0 per evaluation.
+extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, double ediff, int final_eval, double *scalars,
+                           int *evals_done, int *halt_code)
+{
+    if (!h || nevals <= 0 || !evals_done) return fail(SGPR_E_INVALID, "sgpr_md_run: bad arguments");
+    MdState &m = h->md;
+    if (!m.active || h->N != m.N) return fail(SGPR_E_INVALID, "sgpr_md_run: call sgpr_md_begin first");
+    if (!(h->m > 0 && h->has_mu)) return fail(SGPR_E_NOMODEL, "sgpr_md_run: the model has no weights");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int N = m.N;
+    const size_t plen = (size_t)sgpr_packed_len(N);
+    *evals_done = 0;
+    if (halt_code) *halt_code = 0;
+    // scalar ring in mapped host memory
+    if (m.scal_rows < (size_t)nevals + 1) {
+        if (m.scal) (void)hipHostFree(m.scal);
+        m.scal = nullptr; m.scal_rows = 0;
+        if (hipHostMalloc((void **)&m.scal, sizeof(double) * SGPR_MD_SCAL * ((size_t)nevals + 1), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&m.scal_dev, m.scal, 0) != hipSuccess)
+            return fail(SGPR_E_NODEVICE, "sgpr_md_run: no mapped host memory");
+        m.scal_rows = (size_t)nevals + 1;
+    }
+    memset(m.scal, 0, sizeof(double) * SGPR_MD_SCAL * ((size_t)nevals + 1));
+    if (noise) {
+        if (m.noise.alloc((size_t)nevals * 3 * N) || m.noise_raw.alloc((size_t)nevals * 3 * N))
+            return fail(SGPR_E_NODEVICE, "sgpr_md_run: device allocation failed");
+        HIPCHK(hipMemcpyAsync(m.noise_raw.p, noise, sizeof(double) * (size_t)nevals * 3 * N, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(md_sort_rows_kernel, dim3(1024), dim3(256), 0, st, N, nevals, h->d_perm.p, m.noise_raw.p, m.noise.p);
+    }
+    const int halt_none = 0x7fffffff;
+    {
+        m.halt_host[0] = halt_none; m.halt_host[1] = halt_none;  // (page-locked: the source of the copy outlives the call)
+        HIPCHK(hipMemcpyAsync(m.halt.p, m.halt_host, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    h->bin_identity = true;
+    struct Restore { sgpr_model *h; ~Restore() { h->bin_identity = false; h->pre_valid = false; } } restore{h};
+    // the first evaluation sizes the capacities for this configuration if nothing has yet (synchronised, results discarded)
+    const int s0 = (int)(m.t % 3);
+    if (!h->warm) {
+        const int rc_ = run_checked(h, m.X.p + (size_t)3 * N * s0, m.cell.p, m.P.p + plen * s0, st);
+        if (rc_) return rc_;
+        h->warm = true;
+    }
+    h->lists_valid = false;  // (whatever ran on this handle in between — a model update evaluates other frames)
+    h->pre_valid = false;
+    // (a run that halted has left the bin populations of a step that never ran)
+    HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
+    const unsigned step0 = h->step_count;
+    const bool pend0 = m.t > 0;   // (the closing half kick of the first configuration: due unless it is the start of the trajectory)
+    const int CH = 16;       // evaluations enqueued between two looks at the halt word
+    std::vector<hipEvent_t> evs;
+    int enq = 0;
+    bool halted = false;
+    int rc_ = SGPR_OK;
+    for (int j = 0; j < nevals && !halted && !rc_; j++) {
+        const int sl = (int)((m.t + j) % 3), sn = (sl + 1) % 3, sp = (sl + 2) % 3;
+        StepNext nx;
+        const bool integrate = !(final_eval && j == nevals - 1);
+        nx.mode = 2;
+        nx.pos_next = m.X.p + (size_t)3 * N * sn;
+        FinNext &x = nx.md;
+        memset(&x, 0, sizeof(x));
+        x.x_cur = m.X.p + (size_t)3 * N * sl; x.v_cur = m.V.p + (size_t)3 * N * sl;
+        x.x_next = m.X.p + (size_t)3 * N * sn; x.v_next = m.V.p + (size_t)3 * N * sn;
+        x.mass = m.mass.p; x.sig = m.sig.p; x.noise = noise ? m.noise.p + (size_t)j * 3 * N : nullptr;
+        x.hdt = m.hdt; x.c1 = m.c1; x.pending = (j > 0 || pend0) ? 1 : 0;
+        x.ke_cur = m.KE.p + (size_t)N * sl; x.ke_prev = j > 0 ? m.KE.p + (size_t)N * sp : nullptr;
+        x.packed_prev = j > 0 ? m.P.p + plen * sp : nullptr;
+        x.ediff = ediff > 0.0 ? ediff : 1e300;
+        x.halt = m.halt.p; x.halt_host = m.halt_host_dev;
+        x.scal_cur = m.scal_dev + (size_t)SGPR_MD_SCAL * j; x.scal_prev = m.scal_dev + (size_t)SGPR_MD_SCAL * (j > 0 ? j - 1 : 0);
+        (void)integrate;  // (the last evaluation of a `final` run integrates speculatively too: its outcome is not adopted below)
+        rc_ = enqueue_step(h, x.x_cur, m.cell.p, m.P.p + plen * sl, st, &nx);
+        if (rc_) break;
+        h->lists_valid = true;  // (the first evaluation rebuilt the candidates; an overflow halts the run: FinNext)
+        if (!h->pre_valid) { rc_ = fail(SGPR_E_UNSUPPORTED, "sgpr_md_run: the fused last kernel is not available for this model / frame (sharded, "
+                                        "scatter-form reverse pass, graph capture or a zero skin)"); break; }
+        enq = j + 1;
+        if (enq % CH == 0) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(e, st));
+            evs.push_back(e);
+            if (evs.size() >= 2) {  // wait for the chunk before the last one, then look
+                HIPCHK(hipEventSynchronize(evs[evs.size() - 2]));
+                if (m.halt_host[0] != halt_none || m.halt_host[1] != halt_none) halted = true;
+            }
+        }
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (rc_) { (void)hipStreamSynchronize(st); return rc_; }
+    if (enq > 0) {  // the lagged reductions of the last evaluation enqueued
+        FinArgs f = {};
+        f.N = N;
+        const int sl = (int)((m.t + enq - 1) % 3);
+        f.nx.mode = 3; f.nx.step = (int)(step0 + enq);
+        f.nx.ke_prev = m.KE.p + (size_t)N * sl; f.nx.packed_prev = m.P.p + plen * sl;
+        f.nx.ediff = ediff > 0.0 ? ediff : 1e300; f.nx.halt = m.halt.p; f.nx.halt_host = m.halt_host_dev;
+        f.nx.scal_prev = m.scal_dev + (size_t)SGPR_MD_SCAL * (enq - 1);
+        hipLaunchKernelGGL(finalize_tail_kernel, dim3(2), dim3(256), 0, st, f);
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    int hv[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(hv, m.halt.p, sizeof(hv), hipMemcpyDeviceToHost));
+    int done = enq, code = 0;
+    if (hv[0] != halt_none) {
+        const int k = hv[0] - (int)step0;   // evaluation (relative to this call) that halted the run
+        if (k < 0 || k >= enq) return fail(SGPR_E_INVALID, "sgpr_md_run: inconsistent halt record (%d of %d)", k, enq);
+        code = (m.halt_host[1] != halt_none && m.halt_host[1] == hv[0]) ? 2 : 1;
+        done = k + 1;
+        m.t += k;                           // the state is configuration k, not evaluated (as far as the NEXT call goes)
+        if (code == 2) { h->warm = false; }  // a capacity overflowed: the next call's checked pass grows it
+    } else {
+        // all evaluations stand.  final: the state stays at the last configuration evaluated; else it is the next one
+        const int adv = final_eval ? enq - 1 : enq;
+        m.t += adv;
+    }
+    if (code == 2) done -= 1;  // (the overflowing evaluation's own results are void)
+    if (scalars && done > 0) memcpy(scalars, m.scal, sizeof(double) * SGPR_MD_SCAL * (size_t)done);
+    *evals_done = done;
+    if (halt_code) *halt_code = code;
+    h->lists_valid = false;
+    return SGPR_OK;
+}
+
+// State of the run in caller atom order: positions of the current configuration, its velocities BEFORE the closing half
+// kick (`pending` says whether one is due: v = v_pre + (dt/2) F / m once F is known), and — when the configuration has
+// been evaluated by the last sgpr_md_run (a halted or `final` run) — its packed results [F | beta | E | virial | overflow].
+extern "C" int sgpr_md_state(sgpr_model *h, double *positions, double *velocities_pre, int *pending, double *packed,
+                             int which /*0: the current configuration; -1: the one evaluated before it*/)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_md_state: bad arguments");
+    MdState &m = h->md;
+    if (!m.active) return fail(SGPR_E_INVALID, "sgpr_md_state: call sgpr_md_begin first");
+    if (which != 0 && which != -1) return fail(SGPR_E_INVALID, "sgpr_md_state: which = 0 or -1");
+    if (which == -1 && m.t == 0) return fail(SGPR_E_INVALID, "sgpr_md_state: no earlier configuration");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N = m.N;
+    const int sl = (int)((m.t + which + 3) % 3);
+    std::vector<double> buf((size_t)3 * N);
+    if (positions) {
+        HIPCHK(hipMemcpy(buf.data(), m.X.p + (size_t)3 * N * sl, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; i++)
+            for (int k = 0; k < 3; k++) positions[3 * (size_t)h->perm[i] + k] = buf[3 * (size_t)i + k];
+    }
+    if (velocities_pre) {
+        HIPCHK(hipMemcpy(buf.data(), m.V.p + (size_t)3 * N * sl, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; i++)
+            for (int k = 0; k < 3; k++) velocities_pre[3 * (size_t)h->perm[i] + k] = buf[3 * (size_t)i + k];
+    }
+    if (pending) *pending = (m.t + which) > 0 ? 1 : 0;   // (every configuration but the start of the trajectory)
+    if (packed) HIPCHK(hipMemcpy(packed, m.P.p + (size_t)sgpr_packed_len(N) * sl, sizeof(double) * sgpr_packed_len(N), hipMemcpyDeviceToHost));
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_md_end(sgpr_model *h)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_md_end: bad arguments");
+    h->md.active = false;
+    return SGPR_OK;
+}
+
 extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
 {
     if (!h) return fail(SGPR_E_INVALID, "sgpr_sync_check: bad arguments");
@@ -1883,6 +2501,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "cov_in_rev")) { h->cov_in_rev = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "spin_wait")) { h->spin_wait = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "fuse_next")) { h->fuse_next = value != 0; h->pre_valid = false; h->lists_valid = false; return SGPR_OK; }
     if (!strcmp(name, "zero_copy_out")) { h->zero_copy_out = value != 0; return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
     if (!strcmp(name, "lone_atom_weight")) {
@@ -2020,7 +2639,7 @@ extern "C" int sgpr_get_list_rebuilds(sgpr_model *h, int64_t *count)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     int c = 0;
-    HIPCHK(hipMemcpy(&c, h->d_flag.p + 2, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&c, h->d_flag.p + 4, sizeof(int), hipMemcpyDeviceToHost));
     *count = c;
     return SGPR_OK;
 }

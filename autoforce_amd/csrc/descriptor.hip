@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
                               c2 = (int)floor((double)t2 * r_n2 + 1e-9);
                     nbin_l = ((t0 - c0 * g.nb[0]) * g.nb[1] + (t1 - c1 * g.nb[1])) * g.nb[2] + (t2 - c2 * g.nb[2]);
                     code_l = (c0 & 0xff) | ((c1 & 0xff) << 8) | ((c2 & 0xff) << 16);
-                    cnt_l = min(n.bin_count[nbin_l], cap);
+                    cnt_l = min(n.bin_count[(size_t)nbin_l * SGPR_BIN_STRIDE], cap);
                     // gap between the atom and the bin along each plane normal (bin units -> length)
                     const double g0 = (o0 > 0 ? o0 - tb[0] : o0 < 0 ? tb[0] - o0 - 1.0 : 0.0) * g.w[0];
                     const double g1 = (o1 > 0 ? o1 - tb[1] : o1 < 0 ? tb[1] - o1 - 1.0 : 0.0) * g.w[1];
@@ -1713,7 +1713,7 @@ int launch_list_forward(const DescParams &p, const NlScratch &nl, const double *
     n.grid = nl.grid; n.bin_of = nl.bin_of; n.kslot = nl.kslot; n.bin_count = nl.bin_count; n.cap = nl.cap;
     n.b_rec = nl.b_rec; n.b_aux = nl.b_aux; n.nn = nn; n.nn_local = nn_local; n.nn_raw = nl.nn_raw; n.nbr_j = nbr_j;
     n.nbr_shift = nbr_shift; n.aux = nl.aux; n.T = nl.T; n.t_stride = nl.t_stride; n.stat = nl.stat;
-    n.flag = nl.flag + nl.parity; n.rc_list = p.rc + nl.skin; n.ncand = nl.ncand; n.cand_j = nl.cand_j;
+    n.flag = nl.flag + nl.fslot; n.rc_list = p.rc + nl.skin; n.ncand = nl.ncand; n.cand_j = nl.cand_j;
     n.cand_code = nl.cand_code; n.cidx = nl.cidx; n.hm = nl.hm; n.hmw = nl.hmw;
     DISPATCH_LNS(LISTFWD, a, n, st);
 }

@@ -45,7 +45,7 @@ struct BinArgs {
     double *zero_a; int n_zero_a;   // accumulators to clear for this step
     double *zero_b; int n_zero_b;
     // Verlet candidates: rebuild decision of this step
-    int *flag; int parity, force;
+    int *flag; int parity, force, fslot, fclear;
     double half_skin2;      // (skin / 2)^2
     double rc_list;         // rc + skin: the cutoff the candidates were built with
     double rc_phys;         // rc
@@ -194,9 +194,9 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
             *(NlGrid *)(cache + 256 * a.parity) = g;
             for (int k = 0; k < 9; k++) ((double *)(cache + 256 * a.parity + 128))[k] = cc[k];
             // rebuild decision, part 1: forced, or the cell moved too far from the one the candidates were built
-            // in (below); the other parity's flag is cleared for the next step (nobody reads it during this one)
-            if (a.force != 0 || !(thr2 > 0.0)) atomicMax(&a.flag[a.parity], 1);
-            a.flag[a.parity ^ 1] = 0;
+            // in (below); the flag of the step after the next is cleared (nobody reads it during this one)
+            if (a.force != 0 || !(thr2 > 0.0)) atomicMax(&a.flag[a.fslot], 1);
+            a.flag[a.fclear] = 0;
         }
     }
     const int gsz = gridDim.x * 256, gid = wg * 256 + tid;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
     {   // rebuild decision, part 2: has this atom moved more than half the skin since the candidates were built?
         const double dx = x - (x0 * Aff[0] + y0 * Aff[3] + z0 * Aff[6]), dy = y - (x0 * Aff[1] + y0 * Aff[4] + z0 * Aff[7]),
                      dz = z - (x0 * Aff[2] + y0 * Aff[5] + z0 * Aff[8]);
-        if (!(dx * dx + dy * dy + dz * dz <= thr2)) atomicMax(&a.flag[a.parity], 1);
+        if (!(dx * dx + dy * dy + dz * dz <= thr2)) atomicMax(&a.flag[a.fslot], 1);
     }
     int bidx[3], w[3];
 #pragma unroll
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void nl_bin_kernel(BinArgs a)
         a.kslot[i] = -1;
         return;
     }
-    const int k = atomicAdd(&a.bin_count[bin], 1);
+    const int k = atomicAdd(&a.bin_count[(size_t)bin * SGPR_BIN_STRIDE], 1);
     a.kslot[i] = k;
     if (max(max(abs(w[0]), abs(w[1])), abs(w[2])) > 32767) atomicMax(&a.stat[3], 1);  // atoms > 32767 cells away
     if (k < a.cap) {
@@ -267,7 +267,7 @@ void launch_neighbor_bin(const NlParams &p, const int *perm, const double *pos_i
     a.grid = s.grid; a.pos = pos; a.bin_count = s.bin_count; a.b_rec = s.b_rec; a.b_aux = s.b_aux;
     a.slot = s.slot; a.bin_of = s.bin_of; a.kslot = s.kslot; a.stat = s.stat;
     a.zero_a = zero_a; a.n_zero_a = n_zero_a; a.zero_b = zero_b; a.n_zero_b = n_zero_b;
-    a.flag = s.flag; a.parity = s.parity; a.force = s.force; a.half_skin2 = 0.25 * s.skin * s.skin; a.pos0 = s.pos0;
+    a.flag = s.flag; a.parity = s.parity; a.fslot = s.fslot; a.fclear = s.fclear; a.force = s.force; a.half_skin2 = 0.25 * s.skin * s.skin; a.pos0 = s.pos0;
     a.cell0 = s.cell0; a.rc_list = rc; a.rc_phys = rc - s.skin;
     hipLaunchKernelGGL(nl_bin_kernel, dim3((p.N + 255) / 256), dim3(256), 0, st, a);
 }

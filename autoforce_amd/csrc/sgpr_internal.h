@@ -52,6 +52,12 @@ struct NlGrid {
     double w[3];     // bin width along each cell vector's normal (perpendicular height / nb)
 };
 
+// Bin populations sit SGPR_BIN_STRIDE ints apart: one counter per 128-byte line.  Packed, the ~350 counters of a 4096-atom
+// frame are eleven lines, and the returning atomics of the binning (one per atom, device scope: they execute at the
+// memory side, one after the other per line) were most of the binning kernel's 7 us.
+#define SGPR_BIN_STRIDE 32
+#define SGPR_BIN_INTS (4096 * SGPR_BIN_STRIDE)
+
 // binned copy of an atom: one 32-B record + one 8-B record per candidate of the list sweep
 struct BinRec { double x, y, z; int idx; int pad; };   // position, sorted atom index
 struct BinAux { short w0, w1, w2, slot; };             // wrap (floor of the fractional coordinates), species slot
@@ -60,7 +66,7 @@ struct NlScratch {
     NlGrid *grid;
     int *bin_of;       // [N]
     int *kslot;        // [N] slot of the atom in its bin
-    int *bin_count;    // [4096] atoms per bin; zero on entry (finalize re-zeroes it)
+    int *bin_count;    // [4096 * SGPR_BIN_STRIDE] atoms per bin, one counter per 128-byte line; zero on entry (finalize re-zeroes it)
     int cap;           // slots per bin of the binned copies below
     BinRec *b_rec;     // [4096][cap]
     BinAux *b_aux;     // [4096][cap]
@@ -76,8 +82,10 @@ struct NlScratch {
     // Verlet candidates: lists of |r| < rc + skin, rebuilt on the device when an atom moved > skin/2 since the
     // last build or the cell changed (flag[parity] of this step, set by the binning kernel; the other entry is
     // cleared for the next step); every step filters them down to |r| < rc
-    int *flag;         // [2]
-    int parity;        // step counter & 1
+    int *flag;         // [4] by step counter & 3 (a fused last kernel writes the next step's flag while this step's is
+                       //     still being read: finalize_next_kernel, api.hip)
+    int parity;        // step counter & 1 (the two cached grid records of the binning kernel)
+    int fslot, fclear; // this step's flag; the flag cleared by this step's binning (the one two steps ahead)
     int force;         // 1: rebuild regardless (new frame, capacity change, skin = 0)
     double skin;
     double *pos0;      // [N][3] positions at the last rebuild (sorted order)

@@ -480,6 +480,59 @@ class SGPRModel:
                                        C.addressof(E), ptr(F), ptr(stress), ptr(b), ptr(K)))
         return dict(energy=E.value, forces=F, stress=stress, beta=b, cov=K)
 
+    # ------------------------------------------------------------------ device-resident molecular dynamics
+    MD_SCALARS = 16  # per evaluation: E, virial[9], overflow word, largest covloss, sum m v^2, 3 spare
+
+    def md_begin(self, numbers, positions, cell, pbc, masses, velocities=None, dt=1.0, friction=0.0, kT=0.0):
+        """State of an MD run into device memory (cl/md.py:117-128 drives ase.md.langevin around calculate();
+        here the integrator is part of the step's last kernel).  dt, friction and kT in the caller's units
+        (workloads.FS / ase_shim.kB for fs / K)."""
+        numbers = i32(numbers)
+        N = len(numbers)
+        self._md = dict(N=N, numbers=numbers, cell=f64(np.asarray(cell, float).reshape(3, 3)), masses=f64(masses), hdt=0.5 * dt)
+        v = None if velocities is None else f64(velocities).reshape(N, 3)
+        self.generation += 1
+        check(_lib.load().sgpr_md_begin(self._h, N, ptr(numbers), ptr(f64(positions).reshape(N, 3)), ptr(self._md["cell"]),
+                                        ptr(i32(np.asarray(pbc, bool).astype(np.int32))), ptr(self._md["masses"]), ptr(v),
+                                        float(dt), float(friction), float(kT)))
+
+    def md_run(self, nevals, noise=None, ediff=0.0, final=False):
+        """Evaluate `nevals` configurations starting with the current one, integrating between them on the device
+        (noise: [nevals, N, 3] standard normal deviates or None).  Returns (scalars [done, 16], halt code): code 1 =
+        the last row's largest covloss reached ediff and the state is that configuration (calculator/active.py:492-499),
+        2 = a neighbour capacity overflowed at evaluation `done` (repeat the call)."""
+        N = self._md["N"]
+        if noise is not None:
+            noise = f64(noise).reshape(-1, N, 3)
+            assert len(noise) >= nevals, "one row of noise per evaluation"
+        sc = np.zeros((nevals, self.MD_SCALARS))
+        done, code = C.c_int(0), C.c_int(0)
+        self.generation += 1
+        check(_lib.load().sgpr_md_run(self._h, int(nevals), ptr(noise), float(ediff), int(bool(final)), ptr(sc),
+                                      C.addressof(done), C.addressof(code)))
+        return sc[:done.value], code.value
+
+    def md_state(self, which=0, results=False):
+        """Positions, velocities of the current configuration (which = -1: the one before it); with results=True also
+        the forces / covloss / energy / stress of its last evaluation, and the velocities include the closing half kick
+        of that evaluation (what an observer of the trajectory sees, workloads.langevin_nvt)."""
+        N = self._md["N"]
+        x, v = np.empty((N, 3)), np.empty((N, 3))
+        pend = C.c_int(0)
+        packed = np.empty(4 * N + 11) if results else None
+        check(_lib.load().sgpr_md_state(self._h, ptr(x), ptr(v), C.addressof(pend), ptr(packed), int(which)))
+        out = dict(positions=x, velocities_pre=v, pending=bool(pend.value))
+        if results:
+            F = packed[:3 * N].reshape(N, 3).copy()
+            stress = np.zeros(6)
+            check(_lib.load().sgpr_stress_from_virial(ptr(f64(packed[4 * N + 1:4 * N + 10])), ptr(self._md["cell"]), ptr(stress)))
+            out.update(forces=F, beta=packed[3 * N:4 * N].copy(), energy=float(packed[4 * N]), stress=stress)
+            out["velocities"] = v + self._md["hdt"] * F / self._md["masses"][:, None] if pend.value else v.copy()
+        return out
+
+    def md_end(self):
+        check(_lib.load().sgpr_md_end(self._h))
+
     def descriptors(self, N):
         S, D = len(self.species), (self.nmax + 1) ** 2 * (self.lmax + 1)
         out = np.zeros((N, S, S, D))

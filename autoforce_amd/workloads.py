@@ -182,6 +182,62 @@ def langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=
         yield step, E, float((mass * vel ** 2).sum() / (3 * N * kB)), time.time() - t0, pos, vel
 
 
+def langevin_nvt_device(model, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=1e-3, seed=1, vel=None,
+                        ediff=0.0, chunk=256, on_halt=None):
+    """langevin_nvt with the state in device memory (SGPRModel.md_begin / md_run): same scheme, same random stream
+    (one rng.normal(size=(N, 3)) per step, drawn here and uploaded a chunk at a time), so positions and velocities equal
+    the host loop's bit for bit.  Yields (step, energy, temperature, largest covloss) per evaluation.  With ediff > 0 an
+    evaluation whose largest covloss reaches it stops the run ON THE DEVICE; on_halt(model, state) — the model update of
+    calculator/active.py:477-484 — is called with that configuration and its results, and the evaluation is repeated
+    with whatever model on_halt left behind (an on_halt that leaves the covloss above ediff must raise ediff itself:
+    it receives and may return the threshold)."""
+    from .ase_shim import kB
+    rng = np.random.default_rng(seed)
+    N = len(numbers)
+    mass = np.array([MASS[int(z)] for z in numbers])
+    kT = kB * temperature
+    if vel is None:
+        vel = rng.normal(size=(N, 3)) * np.sqrt(kT / mass[:, None])
+        vel -= (mass[:, None] * vel).sum(0) / mass.sum()
+    model.md_begin(numbers, pos, cell, pbc, mass, vel, dt=dt_fs * FS, friction=friction, kT=kT)
+    done = 0                      # evaluations accepted so far (evaluation k = the configuration after k steps)
+    rows = np.empty((0, N, 3))    # deviates drawn and not yet consumed: rows[0] moves the current configuration on
+    skip_gate = False
+    while done <= steps:
+        n = 1 if skip_gate else min(chunk, steps + 1 - done)
+        final = done + n == steps + 1
+        need = n - 1 if final else n
+        if len(rows) < need:  # (numpy fills an (r, N, 3) request like r requests of (N, 3): the host loop's stream)
+            rows = np.concatenate([rows, rng.normal(size=(need - len(rows), N, 3))])
+        noise = rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))])
+        sc, code = model.md_run(n, noise, ediff=0.0 if skip_gate else ediff, final=final)
+        accepted = len(sc) - 1 if code == 1 else len(sc)
+        if accepted:
+            skip_gate = False   # (code 2 with nothing accepted: a capacity was outgrown, the same call again re-sizes it)
+        for r in sc[:accepted]:
+            yield done, float(r[0]), float(r[12] / (3 * N * kB)), float(r[11])
+            done += 1
+        rows = rows[accepted:]
+        if code == 1:
+            if on_halt is None:
+                raise RuntimeError("the covloss gate fired and no on_halt handler is installed")
+            on_halt(model, model.md_state(results=True))
+            skip_gate = True   # the repeated evaluation stands whatever its covloss (active.py:477-484 updates once per step)
+    # (the state stays readable: SGPRModel.md_state; md_begin starts the next run)
+
+
+def fit_to_teacher(model, numbers, pos, cell, pbc, noise=0.05, device=0):
+    """Weights of `model` fitted to the PairTeacher's energy and forces on one frame (its inducing set as it is): a
+    model whose forces hold the atoms together, for MD loops that have to run for hundreds of steps."""
+    teacher = PairTeacher(sorted(set(int(z) for z in numbers)), device=device)
+    at = type("A", (), dict(numbers=np.asarray(numbers), positions=np.asarray(pos, float), cell=np.asarray(cell, float), pbc=pbc))()
+    teacher.calculate(at)
+    mu = model.fit([dict(numbers=numbers, positions=pos, cell=cell, pbc=pbc, energy=teacher.results["energy"],
+                         forces=teacher.results["forces"])], noise=noise)
+    teacher.close()
+    return mu
+
+
 def inducing_from_frame(model, numbers, pos, cell, pbc, m, seed, noise=0.05):
     """m LCEs drawn species-proportionally from a frame (+ noise), using the MODEL's own device
     neighbour list (the product path; no oracle involved)."""

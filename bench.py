@@ -94,6 +94,8 @@ def algorithmic_bytes(N, nn, D, m, cs):
         # (the covloss tiles ride in the reverse kernel's launch: K and choli read once more, row sums out)
         "descriptor_rev_covloss": 2 * 8 * N * D + 8 * N * cs + N * nn * 32 + N * nn * 32 + 24 * N + 8 * N * m + 8 * m * m,
         "finalize": N * nn * 32 + 24 * N + 32 * N,
+        # the last kernel also opens the next step: next positions in, sorted copy + bin record out
+        "finalize_bin_next": N * nn * 32 + 24 * N + 32 * N + N * (24 + 24 + 40),
     }
 
 
@@ -197,6 +199,8 @@ def main():
     ap.add_argument("--walk-frames", type=int, default=64, help="frames of the walk (traversed forth and back)")
     ap.add_argument("--skin", type=float, default=0.5, help="Verlet skin of the neighbour candidates, A (0 = rebuild every step)")
     ap.add_argument("--overlap", type=int, default=0, help="1: covloss GEMM on a side stream next to the reverse pass")
+    ap.add_argument("--fuse-next", type=int, default=1, help="0: every step bins for itself (sgpr_step_dev), 6 launches per step")
+    ap.add_argument("--md-steps", type=int, default=400, help="steps of the device-resident Langevin loop behind `md_loop` (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-big-wall", action="store_true", help="skip the calculate() wall time of the 16384-atom / 1024 frame")
     ap.add_argument("--collective", default="native", choices=["native", "torch"],
@@ -282,18 +286,42 @@ def main():
     counter = [0]
 
     def step():
-        # with a communicator attached the step ends with the all-reduce of `packed`, same stream
+        # with a communicator attached the step ends with the all-reduce of `packed`, same stream.
+        # The frames are resident, so the step can name the one that follows: its last kernel then bins it and the next
+        # step starts with the list filter (single rank; 5 launches per step instead of 6)
         k = counter[0] % nframes
         counter[0] += 1
-        _lib.check(lib.sgpr_step_dev(h, frame_ptr[k], cell_d.data_ptr(), packed.data_ptr(), sp))
+        if world == 1 and args.fuse_next:
+            _lib.check(lib.sgpr_step_dev_next(h, frame_ptr[k], cell_d.data_ptr(), packed.data_ptr(), frame_ptr[(k + 1) % nframes], sp))
+        else:
+            _lib.check(lib.sgpr_step_dev(h, frame_ptr[k], cell_d.data_ptr(), packed.data_ptr(), sp))
         if world > 1 and not native:
             t = packed.cpu()
             dist.all_reduce(t)
             packed.copy_(t)
 
+    warm_batches = []
     with Watchdog("warm-up steps (the first collective of every rank)", seconds=300, rank=rank):
         for _ in range(max(args.warmup, 2)):
             step()
+        _lib.check(lib.sgpr_sync_check(h, sp))
+        # ... and on until the step time has settled: batches of 20 steps until three in a row agree within 2 % (clocks,
+        # caches and the first list rebuilds of a fresh process take tens of steps; --warmup is the minimum).  Every rank
+        # runs the same number of batches (the decision is rank 0's).
+        for _ in range(40):
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize(dev)
+            warm_batches.append((time.perf_counter() - tb) / 20)
+            stop = len(warm_batches) >= 3 and max(warm_batches[-3:]) <= 1.02 * min(warm_batches[-3:])
+            if world > 1:
+                t = torch.tensor([1 if stop else 0])
+                dist.broadcast(t, src=0)
+                stop = bool(t.item())
+            if stop:
+                break
         _lib.check(lib.sgpr_sync_check(h, sp))
 
     def fence():
@@ -305,7 +333,7 @@ def main():
     fence()
     rb0 = C.c_int64(0)
     _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb0)))
-    with Watchdog("timed steps", seconds=600, rank=rank):
+    with Watchdog("timed steps", seconds=max(600, int(0.05 * args.steps)), rank=rank):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -400,6 +428,48 @@ def main():
         if not args.no_big_wall:
             calc_wall_big = calculate_wall_big(local_rank, args.walk_sigma or 1e-3)
 
+    # ---- an MD LOOP: step k + 1 starts from the forces of step k.  Langevin NVT (600 K, 1 fs, friction as cl/md.py:31)
+    # with positions and velocities in device memory (sgpr_md_*): the wall time of K dependent steps, noise upload
+    # included.  (The bench model's weights are random: scaled by 0.01 for this loop so that the forces are of the size a
+    # fitted model gives — the work per step does not depend on their values.)
+    md_loop = None
+    if world == 1 and args.md_steps > 0:
+        from autoforce_amd.ase_shim import kB
+        from autoforce_amd.workloads import FS, MASS, fit_to_teacher
+        snap = mdl.snapshot_weights()
+        choli0 = mdl.choli
+        fit_to_teacher(mdl, numbers, pos, cell, pbc, device=local_rank)
+        mdl.set_weights(mdl.mu, choli=mdl.choli, vscale=mdl.make_vscale())
+        mrng = np.random.default_rng(11)
+        mass = np.array([MASS[int(z)] for z in numbers])
+        v0 = mrng.normal(size=(N, 3)) * np.sqrt(kB * 600.0 / mass[:, None])
+        K = args.md_steps
+        mdl.md_begin(numbers, pos, cell, pbc, mass, v0, dt=1.0 * FS, friction=1e-3, kT=kB * 600.0)
+        mdl.md_run(20, mrng.normal(size=(20, N, 3)))  # (sizes the capacities, first rebuild)
+        noise = mrng.normal(size=(K, N, 3))
+        rbm0 = mdl.list_rebuilds()
+        rows, resizes = [], 0
+        tm = time.perf_counter()
+        while sum(len(r) for r in rows) < K and resizes <= 8:
+            d0 = sum(len(r) for r in rows)
+            sc, code = mdl.md_run(K - d0, noise[d0:])
+            rows.append(sc)
+            resizes += code == 2   # a neighbour capacity outgrown on the way: the next call re-sizes and goes on
+        tmd = time.perf_counter() - tm
+        sc = np.concatenate(rows)
+        T_md = sc[:, 12] / (3 * N * kB)
+        md_loop = {"steps": int(len(sc)), "capacity_resizes": int(resizes), "ms_per_step": tmd / max(len(sc), 1) * 1e3,
+                   "atom_steps_per_s": N * len(sc) / tmd, "list_rebuilds": int(mdl.list_rebuilds() - rbm0),
+                   "temperature_K_mean": float(T_md.mean()) if len(sc) else None,
+                   "energy_first_last": [float(sc[0, 0]), float(sc[-1, 0])] if len(sc) else None,
+                   "largest_covloss_first_last": [float(sc[0, 11]), float(sc[-1, 11])] if len(sc) else None,
+                   "what": "sgpr_md_run: BAOAB Langevin 600 K, 1 fs, friction 1e-3 (cl/md.py:31), state resident in HBM, "
+                           "integrator + binning of the next step inside the step's last kernel (5 launches per step); wall "
+                           "time of K dependent steps including the upload of their K x N x 3 normal deviates; the host reads "
+                           "16 scalars per step; weights fitted to workloads.PairTeacher on the start frame (a model whose "
+                           "forces hold the lattice together; the work per step does not depend on the weights)"}
+        mdl.set_weights(snap["mu"], choli=choli0, vscale=snap["vscale"] or None)
+
     result = None
     if rank == 0:
         cnt = (N - rank + world - 1) // world
@@ -469,7 +539,10 @@ def main():
             "pass_GBs_packed": sum(v for k, v in ab.items() if k in stage_ms) / (sum(stage_ms[k] for k in ab if k in stage_ms) * 1e-3) / 1e9,
         }
         result = {
-            "metric": "MD-step atoms*steps/sec (SGPR predict: NL + descriptors + K_nm + E/F/stress + covloss)",
+            "metric": "MD-step atoms*steps/sec (SGPR predict: NL + descriptors + K_nm + E/F/stress + covloss); `value`: steps "
+                      "over frames resident in HBM, enqueued back to back; `md_loop`: a Langevin loop on the device, every step "
+                      "from the forces of the one before; `value_calculate_wall`: SURVEY 8(d)'s t_step = wall of one "
+                      "synchronised ActiveCalculator.calculate()",
             "value": value,
             "unit": "atom*steps/s",
             "n_gpus": world,
@@ -484,7 +557,7 @@ def main():
             "config": {
                 "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
-                "packed_row": Dc, "graph": bool(args.graph),
+                "packed_row": Dc, "graph": bool(args.graph), "launches_per_step": 5 if (world == 1 and args.fuse_next) else 6,
                 "input": (f"closed Gaussian random walk, sigma {args.walk_sigma} A per component per step, {nframes} frames "
                           f"resident in HBM" if nframes > 1 else "static frame"),
                 "neighbor_skin_A": args.skin,
@@ -496,6 +569,10 @@ def main():
             "roofline": roof,
             "per_rank": per_rank,
             "allreduce_us": allreduce_us,
+            "value_calculate_wall": None if calc_wall is None else calc_wall["atom_steps_per_s"],
+            "value_md_loop": None if md_loop is None else md_loop["atom_steps_per_s"],
+            "md_loop": md_loop,
+            "warmup_batches_ms": [round(1e3 * b, 4) for b in warm_batches],
             "calculate_wall": calc_wall,
             "calculate_wall_ms": None if calc_wall is None else calc_wall["median_ms"],
             "calculate_wall_16384": calc_wall_big,

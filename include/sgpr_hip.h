@@ -268,6 +268,52 @@ int64_t sgpr_packed_len(int N);
 int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell_dev,
                   double *packed_dev, void *stream);
 /*
+ * sgpr_step_dev with the DEVICE positions of the step that follows named (same cell buffer): the last kernel of this
+ * step bins them and takes the rebuild decision of the next step's neighbour candidates, so the next call — which must
+ * pass exactly `positions_next_dev` — starts with the list filter instead of a binning launch (6 -> 5 launches per
+ * step).  A call that passes anything else is served as usual.  positions_next_dev = NULL: sgpr_step_dev.
+ * (The reference asks ASE for a fresh list inside every calculate(), descriptor/atoms.py:348-363, :402.)
+ */
+int sgpr_step_dev_next(sgpr_model *h, const double *positions_dev, const double *cell_dev,
+                       double *packed_dev, const double *positions_next_dev, void *stream);
+
+/*
+ * Device-resident molecular dynamics.  The reference integrates in ASE — ase.md.langevin.Langevin around the
+ * calculator (cl/md.py:117-128), velocities from util/aseutil.py:11-20 — and crosses into calculate() once per step,
+ * whose covloss gate (calculator/active.py:492-499, :842-885: update when the largest covloss reaches ediff) decides
+ * whether the model is edited.  Here positions and velocities live in device memory, the integrator (BAOAB Langevin;
+ * friction = 0: velocity Verlet) is part of the step's last kernel, and the gate halts the run on the device.
+ *
+ * sgpr_md_begin   binds the system (single process), uploads positions[N][3], velocities[N][3] (NULL: zero) and
+ *                 masses[N] (caller atom order), fixes dt, friction (per unit time) and kT (energy units):
+ *                 c1 = exp(-friction dt), sigma_i = sqrt(1 - c1^2) sqrt(kT / m_i).
+ * sgpr_md_run     evaluates `nevals` configurations starting with the current one.  After every evaluation (with
+ *                 final_eval != 0: every one but the last) the state moves on:
+ *                     v += (dt/2) F/m;  x += (dt/2) v;  v = c1 v + sigma xi;  x += (dt/2) v;  [evaluate]  v += (dt/2) F/m
+ *                 with xi the next row of noise[nevals][N][3] (standard normal deviates, caller atom order; NULL: none).
+ *                 scalars[nevals][16] (may be NULL) receives per evaluation: E, virial[9] (row-major), the capacity
+ *                 overflow word, the largest covloss, sum_i m_i v_i^2 (velocities AFTER the closing half kick), 0, 0, 0.
+ *                 The run stops at the first evaluation whose largest covloss is >= ediff (ediff <= 0: never):
+ *                 *evals_done then counts that evaluation as the last one, *halt_code = 1, and the state IS that
+ *                 configuration — the next sgpr_md_run evaluates it again, with whatever model the caller has installed
+ *                 meanwhile, exactly as the reference recomputes the results after an update
+ *                 (calculator/active.py:477-484).  *halt_code = 2: a neighbour capacity overflowed at evaluation
+ *                 *evals_done (not counted); the next call re-sizes and repeats it.
+ * sgpr_md_state   positions[N][3], velocities_pre[N][3] (before the closing half kick; *pending says whether one is
+ *                 due) of the current configuration (which = 0) or of the one before it (which = -1), and the packed
+ *                 results (sgpr_step_dev layout, length sgpr_packed_len(N)) of that configuration's last evaluation;
+ *                 any pointer may be NULL.
+ * Same-seed runs are bit-reproducible; with the same noise rows the trajectory equals the host-side loop around
+ * sgpr_compute bit for bit (tests/test_hip_md.py).
+ */
+int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
+                  const int32_t *pbc, const double *masses, const double *velocities, double dt, double friction,
+                  double kT);
+int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, double ediff, int final_eval, double *scalars,
+                int *evals_done, int *halt_code);
+int sgpr_md_state(sgpr_model *h, double *positions, double *velocities_pre, int *pending, double *packed, int which);
+int sgpr_md_end(sgpr_model *h);
+/*
  * Multi-GPU (one process per GPU, atoms sharded as in sgpr_bind_system): the reference combines the
  * ranks' partial sums with four MPI all-reduces per step (calculator/active.py:562,601,602,777,
  * util/parallel.py); here ONE RCCL all-reduce of the packed buffer over xGMI, issued by the library
@@ -316,6 +362,9 @@ int sgpr_sync_check(sgpr_model *h, void *stream);
  *                           and sums its kernels (regression/gppotential.py:63-84) — 1 for the wildcard kernel
  *                           (default), S for the list of S fixed-species kernels of calculator/active.py:31-38.
  *                           Set before the inducing set.
+ *  "fuse_next" = 1/0        the last kernel of a step may open the next one (sgpr_step_dev_next, sgpr_md_run;
+ *                           default 1; 0: every step bins for itself — sgpr_md_run then returns SGPR_E_UNSUPPORTED).
+ *                           Environment: SGPR_FUSE_NEXT
  *  "spin_wait" = 1/0        sgpr_compute polls its stream for the end of a step instead of a blocking wait
  *                           (default 1: one host thread spins for the ~0.1 ms of a step, 16 us less wall time per
  *                           call on a 4096-atom frame; 0: hipStreamSynchronize).  Environment: SGPR_SPIN_WAIT */

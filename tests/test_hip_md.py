@@ -1,0 +1,183 @@
+"""GPU tests of the fused last kernel (finalize + binning of the next step) and of the device-resident MD loop built on
+it: the resident-frames form against plain steps bit for bit, the device integrator against the host loop
+(workloads.langevin_nvt around the same library) bit for bit with the same noise stream, the covloss gate halting
+on the device exactly where the host loop's calculator would update (calculator/active.py:492-499), and velocity
+Verlet conserving energy."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _PredictCalc:
+    """The library behind the three ASE getters (what ActiveCalculator.calculate does on a prediction-only step)."""
+    implemented_properties = ["energy", "forces", "stress", "free_energy"]
+
+    def __init__(self, mdl):
+        self.mdl, self.calls, self.betas = mdl, 0, []
+        self._key, self.results = None, {}
+
+    def get_property(self, name, atoms=None):
+        key = atoms.positions.tobytes()
+        if key != self._key:
+            out = self.mdl.predict(atoms.numbers, atoms.positions, atoms.cell, atoms.pbc)
+            self.results = dict(energy=out["energy"], forces=out["forces"], stress=out["stress"], free_energy=out["energy"])
+            self.betas.append(float(out["beta"].max()))
+            self._key = key
+            self.calls += 1
+        return self.results[name]
+
+
+def _model(side=8, m=48, scale=0.02, seed=1):
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.workloads import inducing_from_frame, lips
+    numbers, pos, cell, pbc = lips(side, seed=0)
+    species = sorted(set(int(z) for z in numbers))
+    mdl = SGPRModel(3, 3, 4, 6.0, species=species)
+    n2, p2, c2, b2 = lips(side, seed=seed)
+    mdl.set_inducing(inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=seed))
+    rng = np.random.default_rng(2)
+    mdl.solve(rng.normal(size=(64, m)), rng.normal(size=64))
+    mdl.set_weights(scale * rng.normal(size=m), choli=mdl.choli, vscale=mdl.make_vscale())
+    return mdl, (numbers, pos, cell, pbc)
+
+
+def test_resident_frames_with_the_next_step_binned_by_the_last_kernel():
+    """sgpr_step_dev_next over a batch of resident frames (the bench's timed region) against sgpr_step_dev on the same
+    frames: every packed result bit for bit, one binning launch for the whole batch, and a call that breaks the chain
+    (other positions than announced) is served correctly."""
+    import ctypes as C
+    import torch
+    from autoforce_amd import _lib
+    mdl, (numbers, pos, cell, pbc) = _model()
+    lib = _lib.load()
+    N = len(numbers)
+    rng = np.random.default_rng(5)
+    frames = [pos]
+    for _ in range(40):
+        frames.append(frames[-1] + 0.012 * rng.normal(size=pos.shape))
+    mdl.predict(numbers, pos, cell, pbc)  # binds, sizes the capacities
+    r0 = mdl.list_rebuilds()
+    dev = torch.device("cuda:0")
+    fr = torch.tensor(np.stack(frames), device=dev)
+    cl = torch.tensor(cell, device=dev)
+    plen = 4 * N + 11
+    out_a = torch.zeros((len(frames), plen), dtype=torch.float64, device=dev)
+    out_b = torch.zeros_like(out_a)
+    h = mdl.handle
+    st = None
+    for k in range(len(frames)):
+        _lib.check(lib.sgpr_step_dev(h, fr[k].data_ptr(), cl.data_ptr(), out_a[k].data_ptr(), st))
+    _lib.check(lib.sgpr_sync_check(h, st))
+    r1 = mdl.list_rebuilds()
+    mdl.profile(True)
+    for k in range(len(frames)):
+        nxt = fr[k + 1].data_ptr() if k + 1 < len(frames) else None
+        _lib.check(lib.sgpr_step_dev_next(h, fr[k].data_ptr(), cl.data_ptr(), out_b[k].data_ptr(), nxt, st))
+        if k == 20:  # a step in the middle of the chain: its last kernel has binned the next frame, no binning launch of its own
+            _lib.check(lib.sgpr_sync_check(h, st))
+            stages = list(mdl.stage_times())
+            assert "finalize_bin_next" in stages and "neighbor_bin" not in stages, stages
+    _lib.check(lib.sgpr_sync_check(h, st))
+    mdl.profile(False)
+    a, b = out_a.cpu().numpy(), out_b.cpu().numpy()
+    assert np.array_equal(a, b), np.abs(a - b).max()
+    r2 = mdl.list_rebuilds()
+    assert r2 - r1 <= (r1 - r0) + 2 and r2 - r1 < len(frames) // 2, (r0, r1, r2)  # the same walk: the same (few) rebuilds, now decided in the fused kernel
+    # the chain broken on purpose: frame 3 announced, frame 7 passed
+    _lib.check(lib.sgpr_step_dev_next(h, fr[2].data_ptr(), cl.data_ptr(), out_b[2].data_ptr(), fr[3].data_ptr(), st))
+    _lib.check(lib.sgpr_step_dev_next(h, fr[7].data_ptr(), cl.data_ptr(), out_b[7].data_ptr(), fr[8].data_ptr(), st))
+    _lib.check(lib.sgpr_step_dev_next(h, fr[8].data_ptr(), cl.data_ptr(), out_b[8].data_ptr(), None, st))
+    _lib.check(lib.sgpr_sync_check(h, st))
+    b = out_b.cpu().numpy()
+    assert np.array_equal(a[[2, 7, 8]], b[[2, 7, 8]])
+    mdl.close()
+
+
+def test_device_langevin_equals_the_host_loop_bit_for_bit():
+    from autoforce_amd.workloads import langevin_nvt, langevin_nvt_device
+    mdl, (numbers, pos, cell, pbc) = _model()
+    steps = 70  # (several chunks of launches, candidate rebuilds included: thermal motion crosses skin / 2 within ~40 fs)
+    calc = _PredictCalc(mdl)
+    host = [(s, E, T, w, p.copy(), v.copy()) for s, E, T, w, p, v in
+            langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=0.05, seed=3)]
+    dev = list(langevin_nvt_device(mdl, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=0.05, seed=3, chunk=32))
+    assert len(dev) == len(host) == steps + 1
+    for (s0, E0, T0, _, _, _), (s1, E1, T1, bmax), b0 in zip(host, dev, calc.betas):
+        assert s0 == s1
+        assert E0 == E1, (s0, E0, E1)             # same positions -> the same step, bit for bit
+        assert abs(T0 - T1) <= 1e-12 * T0          # (the sum over atoms runs in another order)
+        assert bmax == b0
+    # the state the device ends in = the host loop's last yield
+    st = mdl.md_state(results=True)
+    assert np.array_equal(st["positions"], host[-1][4])
+    assert np.array_equal(st["velocities"], host[-1][5])
+    assert mdl.list_rebuilds() > 1
+    mdl.close()
+
+
+def test_velocity_verlet_is_second_order_and_repeats():
+    """friction = 0: velocity Verlet.  The total energy error over the same physical time falls fourfold when the step is
+    halved (a first-order slip — a force that does not belong to its positions, a half kick applied twice — would halve
+    it at best), the potential energy itself moves far more than the total, and a repeated run gives the same bits."""
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS
+    mdl, (numbers, pos, cell, pbc) = _model(scale=0.05)
+    N = len(numbers)
+    mass = np.array([MASS[int(z)] for z in numbers])
+    rng = np.random.default_rng(0)
+    vel = rng.normal(size=(N, 3)) * np.sqrt(kB * 300.0 / mass[:, None])
+
+    def run(dt_fs, n):
+        mdl.md_begin(numbers, pos, cell, pbc, mass, vel, dt=dt_fs * FS, friction=0.0, kT=0.0)
+        sc, code = mdl.md_run(n + 1, None, final=True)
+        assert code == 0 and len(sc) == n + 1
+        return sc, mdl.md_state(results=True)
+
+    sc1, _ = run(1.0, 30)
+    sc2, st2 = run(0.5, 60)
+    sc4, _ = run(0.25, 120)
+    err = [np.abs(sc[:, 0] + 0.5 * sc[:, 12] - (sc[0, 0] + 0.5 * sc[0, 12])).max() for sc in (sc1, sc2, sc4)]
+    assert 2.8 < err[0] / err[1] < 5.5 and 2.8 < err[1] / err[2] < 5.5, err
+    assert np.ptp(sc4[:, 0]) > 30 * err[2], (np.ptp(sc4[:, 0]), err)
+    sc2b, st2b = run(0.5, 60)
+    assert np.array_equal(sc2, sc2b) and np.array_equal(st2["positions"], st2b["positions"])
+    assert np.array_equal(st2["velocities"], st2b["velocities"])
+    mdl.close()
+
+
+def test_covloss_gate_halts_on_the_device_at_the_step_the_host_would_update():
+    """ediff between the largest covloss of the first and of a later configuration: the run must stop exactly at the
+    first evaluation that reaches it, with that configuration, its forces and its covloss intact, and go on — through
+    the same trajectory — once the handler has dealt with it."""
+    from autoforce_amd.workloads import langevin_nvt, langevin_nvt_device
+    mdl, (numbers, pos, cell, pbc) = _model()
+    steps = 45
+    calc = _PredictCalc(mdl)
+    # (the generator hands out its own velocity array and goes on updating it in place: copies)
+    host = [(s, E, T, w, p.copy(), v.copy()) for s, E, T, w, p, v in
+            langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=900.0, dt_fs=1.0, friction=0.05, seed=4)]
+    b = np.array(calc.betas)
+    later = np.nonzero(b > b[:3].max())[0]
+    assert len(later), "the covloss never exceeds its starting value on this walk; pick another seed"
+    k_halt = int(later[0])
+    ediff = 0.5 * (b[:k_halt].max() + b[k_halt])
+    seen = []
+
+    def on_halt(model, state):
+        seen.append(state)
+
+    dev = list(langevin_nvt_device(mdl, numbers, pos, cell, pbc, steps, temperature=900.0, dt_fs=1.0, friction=0.05, seed=4,
+                                   ediff=ediff, chunk=64, on_halt=on_halt))
+    # every later evaluation above the (unchanged) threshold halts as well: the first one is what is pinned here
+    assert len(seen) >= 1
+    st = seen[0]
+    assert np.array_equal(st["positions"], host[k_halt][4])
+    assert np.array_equal(st["velocities"], host[k_halt][5])
+    assert st["beta"].max() == b[k_halt] >= ediff
+    ref = mdl.predict(numbers, host[k_halt][4], cell, pbc)
+    # (predict() just rebuilt the lists of that frame from scratch: same bits)
+    assert np.array_equal(st["forces"], ref["forces"]) and st["energy"] == ref["energy"]
+    # the trajectory is the host's, halts or not
+    assert [d[1] for d in dev] == [h[1] for h in host]
+    mdl.close()

@@ -8,7 +8,9 @@ import csv, json, statistics as st, sys
 from collections import defaultdict
 
 STAGE = [("nl_bin_kernel", "neighbor_bin"), ("nl_fwd_kernel", "list_forward"), ("desc_rev_kernel", "descriptor_rev"),
-         ("finalize_gather_kernel", "finalize"),
+         ("finalize_gather_kernel", "finalize"), ("finalize_next_kernel", "finalize_bin_next"),
+         ("gemm_nt_kernel8<1", "gemm_knm"), ("gemm_nt_kernel8<(GemmEpilogue)1", "gemm_knm"),
+         ("gemm_nt_kernel8r64<1", "gemm_knm"), ("gemm_nt_kernel8r64<(GemmEpilogue)1", "gemm_knm"),
          ("nl_build_kernel", "neighbor_build"), ("desc_fwd_kernel", "descriptor_fwd"),
          ("gemm_nt_kernel<1", "gemm_knm"), ("gemm_nt_kernel<(GemmEpilogue)1", "gemm_knm"),
          ("gemm_nt_kernel<4", "gemm_w_covloss"), ("gemm_nt_kernel<(GemmEpilogue)4", "gemm_w_covloss"),
