@@ -404,6 +404,106 @@ class ActiveCalculator(Calculator):
             d = np.diff(timings)
             self.log(("timings:" + len(d) * " {:0.2g}").format(*d) + f" total: {d.sum():0.2g}")
 
+    # ------------------------------------------------------------------ MD with the state in device memory
+    def md_on_device_ok(self):
+        """The device loop replaces calculate() only where calculate() does nothing the device cannot see: a
+        single process, no periodic test, no meta-dynamics hook, no force veto, one bead."""
+        eng = self.engine
+        return (hasattr(eng, "md_run") and self._dist()[1] == 1 and not self.test and self.meta is None
+                and "forces" not in self._veto and self.nbeads == 1 and eng.m > 0 and eng.mu is not None)
+
+    def _md_gate(self, numbers):
+        """The smallest covloss at which calculate() would do more than log (update_lce, active.py:806-839): below
+        ediff_lb nothing happens unless a species of the frame has fewer than two inducing LCEs."""
+        if not self.active:
+            return 0.0  # evaluate only: never halt
+        if any(self.model.indu_counts[int(z)] < 2 for z in set(int(z) for z in numbers)):
+            return EPS
+        return float(min(self._ediff_lb.values))
+
+    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256):
+        """`steps` steps of Langevin NVT (friction = 0: NVE) from atoms.positions / velocities, as cl/md.py:117-128 sets
+        it up around this calculator — but the state stays in device memory between model updates: the integrator runs
+        inside the step's last kernel (SGPRModel.md_run), the host reads 16 scalars per step and writes the same log
+        line calculate() would ("energy temperature covloss", active.py:518-523), and a step whose largest covloss
+        reaches the sampling threshold stops the device, is handed to calculate() — which updates the model exactly as
+        it does inside an ASE loop — and the run goes on from there with the new model.  Yields (step, energy,
+        temperature, updated) per step; atoms.positions / velocities are current at every yield that follows an update
+        and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no."""
+        from .ase_shim import kB
+        from .workloads import FS, MASS, langevin_nvt
+        numbers, pos, cell, pbc = self._system(atoms)
+        N = len(numbers)
+        rng = np.random.default_rng(1) if rng is None else rng
+        if getattr(atoms, "_masses", "ase") is None:  # (the stand-in Atoms without masses; ase.Atoms knows its own)
+            masses = np.array([MASS[int(z)] for z in numbers])
+            atoms._masses = masses.copy()
+        else:
+            masses = np.asarray(atoms.get_masses(), float)
+        vel = atoms.get_velocities()
+        vel = np.zeros((N, 3)) if vel is None else np.asarray(vel, float)
+        first_on_host = self._needs_seed() or not self.md_on_device_ok()
+        if first_on_host:
+            # (an empty model is seeded by its first calculate(); then the device loop can take over)
+            atoms.calc = self
+            atoms.get_forces()
+            if not self.md_on_device_ok():
+                for st, E, T, _, p, v in langevin_nvt(self, numbers, pos, cell, pbc, steps, temperature_K, dt_fs, friction, vel=vel,
+                                                      rng=rng):
+                    atoms.positions, atoms._velocities = p, v
+                    yield st, E, T, bool(self.updated)
+                return
+        eng = self.engine
+        kT = kB * temperature_K
+        eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=friction, kT=kT)
+        # (skip_gate: the configuration has been through calculate() — logged, counted, the model updated if need be —
+        # and is evaluated once more on the device, whatever its covloss, to move on from it)
+        done, rows, skip_gate = 0, np.empty((0, N, 3)), first_on_host
+        while done <= steps:
+            n = 1 if skip_gate else min(chunk, steps + 1 - done)
+            final = done + n == steps + 1
+            need = n - 1 if final else n
+            if len(rows) < need:
+                rows = np.concatenate([rows, rng.normal(size=(need - len(rows), N, 3))])
+            noise = rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))])
+            gate = 0.0 if skip_gate else self._md_gate(numbers)
+            sc, code = eng.md_run(n, noise, ediff=gate, final=final)
+            accepted = len(sc) - 1 if code == 1 else len(sc)
+            lines = []
+            for r in sc[:accepted]:
+                upd = False
+                if skip_gate:      # (the configuration calculate() has just dealt with, evaluated again with the new model:
+                    skip_gate, upd = False, bool(self.updated)   # its line is written, its step counted)
+                else:
+                    lines.append((self.step, "{} {} {} {}".format(float(r[0]), float(r[13] / (3 * N * kB)), float(r[11]), "")))
+                    self.step += 1
+                yield done, float(r[0]), float(r[12] / (3 * N * kB)), upd
+                done += 1
+            self._log_lines(lines)
+            rows = rows[accepted:]
+            if code == 1:
+                st = eng.md_state(results=True)
+                atoms.positions = st["positions"]
+                atoms._velocities = st["velocities_pre"]   # what the integrator holds when it asks for forces
+                atoms.calc = self
+                self.results = {}
+                self.calculate(atoms)        # update_results + update + the log line, as inside an ASE loop
+                skip_gate = True
+        st = eng.md_state(results=True)
+        atoms.positions, atoms._velocities = st["positions"], st["velocities"]
+
+    def _log_lines(self, lines):
+        """A batch of per-step lines in one open (a device loop produces them by the hundred)."""
+        if not lines:
+            return
+        if self.logfile and self.rank == 0:
+            stamp = datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")
+            with open(self.logfile, "a") as f:
+                f.write("".join("{}{} {} {}\n".format(self._logpref, stamp, st, m) for st, m in lines))
+        if self.stdout and self.rank == 0:
+            for _, m in lines:
+                print(m)
+
     def veto(self):
         """active.py:537-546."""
         if self.size[0] < 2 or "forces" not in self._veto:

@@ -379,7 +379,7 @@ struct FinNext {
     const double *noise;           // [N][3] SORTED order (sorted on upload): the normal deviates of the next step's O (null: none)
     double hdt, c1;                // dt / 2, exp(-friction dt)
     int pending;                   // the closing half kick of this step is due (0 only for the very first evaluation)
-    double *ke_cur;                // [N] m v^2 of this step
+    double *ke_cur;                // [N][2] m v^2 of this step: after the closing half kick | before it
     const double *ke_prev, *packed_prev;   // the same / the packed results of step s - 1 (null: no such step in this run)
     double ediff;                  // halt when the largest covloss of a step reaches it
     int *halt;                     // device: the first step that halted the run (INT_MAX: running; atomicMin)
@@ -523,10 +523,10 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
 // decision of the covloss gate, calculator/active.py:492-499), q = 1 its kinetic energy sum m v^2 (fixed order)
 __device__ __forceinline__ void finalize_reduce_prev(const FinArgs &f, int q)
 {
-    __shared__ double wprev[4];
+    __shared__ double wprev[4], wprev2[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int N = f.N;
-    double s = 0.0;
+    double s = 0.0, s2 = 0.0;
     if (q == 0) {
         const double *b = f.nx.packed_prev + 3 * (size_t)N;
         double m8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -542,20 +542,23 @@ __device__ __forceinline__ void finalize_reduce_prev(const FinArgs &f, int q)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
     } else {
-        const double *src = f.nx.ke_prev;
-        double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const double2 *src = (const double2 *)f.nx.ke_prev;
+        double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, b8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int k0 = tid; k0 < N; k0 += 2048) {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int k = k0 + 256 * u;
-                const double v = src[min(k, N - 1)];
-                a8[u] += k < N ? v : 0.0;
+                const double2 v = src[min(k, N - 1)];
+                a8[u] += k < N ? v.x : 0.0;
+                b8[u] += k < N ? v.y : 0.0;
             }
         }
         s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
         s = fin_wave_sum(s);
+        s2 = ((b8[0] + b8[1]) + (b8[2] + b8[3])) + ((b8[4] + b8[5]) + (b8[6] + b8[7]));
+        s2 = fin_wave_sum(s2);
     }
-    if (lane == 0) wprev[wave] = s;
+    if (lane == 0) { wprev[wave] = s; wprev2[wave] = s2; }
     __syncthreads();
     if (tid == 0) {
         if (q == 0) {
@@ -565,8 +568,10 @@ __device__ __forceinline__ void finalize_reduce_prev(const FinArgs &f, int q)
                 atomicMin(&f.nx.halt[0], f.nx.step - 1);
                 f.nx.halt_host[0] = f.nx.step - 1;
             }
-        } else
+        } else {
             f.nx.scal_prev[12] = (wprev[0] + wprev[1]) + (wprev[2] + wprev[3]);
+            f.nx.scal_prev[13] = (wprev2[0] + wprev2[1]) + (wprev2[2] + wprev2[3]);
+        }
     }
 }
 
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
         f.packed[3 * (size_t)f.N + c] = f.has_beta ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
     }
     // ---- the next step
-    double ke = 0.0;
+    double ke = 0.0, kp = 0.0;
     if (MODE == 2 && lane < 3) {
         // BAOAB, exactly the operations (and their order) of workloads.langevin_nvt: no contraction into fused
         // multiply-adds, a true division
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
         double v = vc;
         if (x.pending) v = v + kick;       // closes step s: the velocity an observer sees at step s
         ke = ms * (v * v);
+        kp = ms * (vc * vc);               // ... and the one the calculator is handed with the positions (its log line)
         const double v2 = v + kick;        // B
         const double x1 = xc + x.hdt * v2; // A
         const double v3 = x.c1 * v2 + sg * nz;  // O
@@ -806,7 +812,8 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
     }
     if (MODE == 2) {
         const double k3 = fin_lane(ke, 0) + fin_lane(ke, 1) + fin_lane(ke, 2);
-        if (lane == 0) x.ke_cur[i] = k3;
+        const double p3 = fin_lane(kp, 0) + fin_lane(kp, 1) + fin_lane(kp, 2);
+        if (lane == 0) *(double2 *)(x.ke_cur + 2 * (size_t)i) = make_double2(k3, p3);
         X = fin_lane(xn, 0); Y = fin_lane(xn, 1); Z = fin_lane(xn, 2);
         if (lane == 0) place(X, Y, Z);
     }
@@ -2241,7 +2248,7 @@ static int md_alloc(sgpr_model *h, int N)
     MdState &m = h->md;
     bool bad = false;
     bad |= m.X.alloc((size_t)9 * N); bad |= m.V.alloc((size_t)9 * N); bad |= m.P.alloc(3 * (size_t)sgpr_packed_len(N));
-    bad |= m.KE.alloc((size_t)3 * N); bad |= m.mass.alloc(N); bad |= m.sig.alloc(N); bad |= m.cell.alloc(9);
+    bad |= m.KE.alloc((size_t)6 * N); bad |= m.mass.alloc(N); bad |= m.sig.alloc(N); bad |= m.cell.alloc(9);
     bad |= m.halt.alloc(4);
     if (bad) return fail(SGPR_E_NODEVICE, "sgpr_md_begin: device allocation failed");
     if (!m.halt_host) {
@@ -2297,7 +2304,8 @@ extern "C" int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const
 // velocity Verlet).  Stops at the first evaluation whose largest covloss reaches `ediff` (<= 0: never): *evals_done
 // counts the evaluations whose results stand, the halting one included; the state then IS that configuration (its
 // forces are evaluated again by the next call — after the caller has updated the model).
-// scalars: [nevals][SGPR_MD_SCAL] = E, virial(9), overflow, largest covloss, sum m v^2, 0, 0, 0 per evaluation.
+// scalars: [nevals][SGPR_MD_SCAL] = E, virial(9), overflow, largest covloss, sum m v^2 (closed | before the closing half
+// kick), 0, 0 per evaluation.
 extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, double ediff, int final_eval, double *scalars,
                            int *evals_done, int *halt_code)
 {
@@ -2364,7 +2372,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         x.x_next = m.X.p + (size_t)3 * N * sn; x.v_next = m.V.p + (size_t)3 * N * sn;
         x.mass = m.mass.p; x.sig = m.sig.p; x.noise = noise ? m.noise.p + (size_t)j * 3 * N : nullptr;
         x.hdt = m.hdt; x.c1 = m.c1; x.pending = (j > 0 || pend0) ? 1 : 0;
-        x.ke_cur = m.KE.p + (size_t)N * sl; x.ke_prev = j > 0 ? m.KE.p + (size_t)N * sp : nullptr;
+        x.ke_cur = m.KE.p + (size_t)2 * N * sl; x.ke_prev = j > 0 ? m.KE.p + (size_t)2 * N * sp : nullptr;
         x.packed_prev = j > 0 ? m.P.p + plen * sp : nullptr;
         x.ediff = ediff > 0.0 ? ediff : 1e300;
         x.halt = m.halt.p; x.halt_host = m.halt_host_dev;
@@ -2394,11 +2402,14 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         f.N = N;
         const int sl = (int)((m.t + enq - 1) % 3);
         f.nx.mode = 3; f.nx.step = (int)(step0 + enq);
-        f.nx.ke_prev = m.KE.p + (size_t)N * sl; f.nx.packed_prev = m.P.p + plen * sl;
+        f.nx.ke_prev = m.KE.p + (size_t)2 * N * sl; f.nx.packed_prev = m.P.p + plen * sl;
         f.nx.ediff = ediff > 0.0 ? ediff : 1e300; f.nx.halt = m.halt.p; f.nx.halt_host = m.halt_host_dev;
         f.nx.scal_prev = m.scal_dev + (size_t)SGPR_MD_SCAL * (enq - 1);
         hipLaunchKernelGGL(finalize_tail_kernel, dim3(2), dim3(256), 0, st, f);
     }
+    // (the last kernel enqueued has binned a step that will not run — or, after a halt, the bins are those of a discarded
+    // speculative step: whoever uses the handle next starts from clean bin populations)
+    HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     int hv[4] = {0, 0, 0, 0};

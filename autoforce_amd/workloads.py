@@ -143,14 +143,14 @@ MASS = {1: 1.008, 3: 6.94, 8: 15.999, 9: 18.998, 11: 22.99, 12: 24.305, 14: 28.0
         40: 91.224, 57: 138.905}
 
 
-def langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=1e-3, seed=1, vel=None):
+def langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=1e-3, seed=1, vel=None, rng=None):
     """BAOAB Langevin dynamics in numpy around any calculator with the ASE surface; parameters as the reference's
     driver (cl/md.py:31,70-74: dt = 1 fs, friction 1e-3 per ASE time unit, T = 600 K; Maxwell-Boltzmann start as
     util/aseutil.py:11-20, or the velocities handed over).  Generator: yields (step, energy, temperature, wall seconds,
     positions, velocities) after every step.  With ASE installed, ase.md.langevin.Langevin drives the same calculator."""
     import time
     from .ase_shim import Atoms, kB
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed) if rng is None else rng
     N = len(numbers)
     mass = np.array([MASS[int(z)] for z in numbers])[:, None]
     kT = kB * temperature

@@ -292,7 +292,8 @@ int sgpr_step_dev_next(sgpr_model *h, const double *positions_dev, const double 
  *                     v += (dt/2) F/m;  x += (dt/2) v;  v = c1 v + sigma xi;  x += (dt/2) v;  [evaluate]  v += (dt/2) F/m
  *                 with xi the next row of noise[nevals][N][3] (standard normal deviates, caller atom order; NULL: none).
  *                 scalars[nevals][16] (may be NULL) receives per evaluation: E, virial[9] (row-major), the capacity
- *                 overflow word, the largest covloss, sum_i m_i v_i^2 (velocities AFTER the closing half kick), 0, 0, 0.
+ *                 overflow word, the largest covloss, sum_i m_i v_i^2 with the velocities AFTER the closing half kick and
+ *                 BEFORE it (what a calculator inside the integrator's step is handed, cl/md.py:117-128), 0, 0.
  *                 The run stops at the first evaluation whose largest covloss is >= ediff (ediff <= 0: never):
  *                 *evals_done then counts that evaluation as the last one, *halt_code = 1, and the state IS that
  *                 configuration — the next sgpr_md_run evaluates it again, with whatever model the caller has installed

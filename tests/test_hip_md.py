@@ -181,3 +181,65 @@ def test_covloss_gate_halts_on_the_device_at_the_step_the_host_would_update():
     # the trajectory is the host's, halts or not
     assert [d[1] for d in dev] == [h[1] for h in host]
     mdl.close()
+
+
+def test_on_the_fly_learning_on_the_device_equals_the_host_loop(tmp_path):
+    """ActiveCalculator.run_md (state on the device, the covloss gate halts it, calculate() updates the model) against
+    the host loop around the same calculator class (workloads.langevin_nvt: one calculate() per step, as an ASE
+    integrator drives it): the same model updates at the same steps, the same log — energies, temperatures,
+    covlosses, sizes — line by line, and the same final state bit for bit."""
+    import re
+    import active_common as ac
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.workloads import langevin_nvt
+    from helpers import PairTeacher
+    steps = 60
+    logs, finals, sizes, upd = [], [], [], []
+    for mode in ("host", "device"):
+        np.random.seed(1234)
+        rng0, numbers, pos, cell = ac.start(0)
+        d = tmp_path / mode
+        d.mkdir()
+        calc = ActiveCalculator(engine=SGPRModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=PairTeacher(rc=4.0),
+                                logfile=str(d / "active.log"), pckl=None, tape=None, **ac.KW)
+        vel = 0.02 * np.random.default_rng(3).normal(size=pos.shape)
+        if mode == "host":
+            out = []
+            for st, E, T, _, p, v in langevin_nvt(calc, numbers, pos, cell, True, steps, 300.0, 1.0, 0.02, vel=vel,
+                                                  rng=np.random.default_rng(9)):
+                out.append((st, E, T, bool(calc.updated)))
+                last = (p.copy(), v.copy())
+        else:
+            at = Atoms(numbers, pos, cell, True, velocities=vel)
+            assert calc.md_on_device_ok() or calc._needs_seed()
+            out = list(calc.run_md(at, steps, 300.0, dt_fs=1.0, friction=0.02, rng=np.random.default_rng(9), chunk=16))
+            last = (at.positions.copy(), at.get_velocities())
+        txt = open(d / "active.log").read().splitlines()
+        logs.append([re.sub(r"^\S+ \S+ ", "", ln) for ln in txt])   # (drop the time stamps)
+        finals.append(last)
+        sizes.append(calc.size)
+        upd.append([o[0] for o in out if o[3]])
+        assert len(out) == steps + 1
+        energies = [o[1] for o in out]
+        if mode == "host":
+            e_host = energies
+        else:
+            first = next((k for k, (a, b) in enumerate(zip(energies, e_host)) if a != b), None)
+            diff = next(((a, b) for a, b in zip(logs[0], logs[1]) if a.split(" ")[:2] != b.split(" ")[:2]), None)
+            assert first is None, (first, upd, sizes, diff)
+        calc.engine.close()
+    assert sizes[0] == sizes[1] and sizes[0][1] > 2
+    assert upd[0] == upd[1] and len(upd[0]) >= 2, upd     # the model was updated several times, at the same steps
+    assert len(upd[0]) < steps // 2                           # ... and most steps ran without the host
+    assert len(logs[0]) == len(logs[1])
+    num = re.compile(r"^(\d+) (\S+) (\S+) (\S+) $")
+    for a, b in zip(logs[0], logs[1]):
+        ma, mb = num.match(a), num.match(b)
+        if ma and mb:   # a step's line: energy and covloss bit for bit, the temperature to the order of its sum
+            assert ma.group(1) == mb.group(1) and ma.group(2) == mb.group(2) and ma.group(4) == mb.group(4), (a, b)
+            assert abs(float(ma.group(3)) - float(mb.group(3))) <= 1e-12 * float(ma.group(3)), (a, b)
+        else:
+            assert a == b
+    assert np.array_equal(finals[0][0], finals[1][0]) and np.array_equal(finals[0][1], finals[1][1])
