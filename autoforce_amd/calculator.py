@@ -428,7 +428,7 @@ class ActiveCalculator(Calculator):
         line calculate() would ("energy temperature covloss", active.py:518-523), and a step whose largest covloss
         reaches the sampling threshold stops the device, is handed to calculate() — which updates the model exactly as
         it does inside an ASE loop — and the run goes on from there with the new model.  Yields (step, energy,
-        temperature, updated) per step; atoms.positions / velocities are current at every yield that follows an update
+        temperature, updated, wall seconds) per step (device steps share the wall time of their batch evenly); atoms.positions / velocities are current at every yield that follows an update
         and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no."""
         from .ase_shim import kB
         from .workloads import FS, MASS, langevin_nvt
@@ -451,37 +451,43 @@ class ActiveCalculator(Calculator):
                 for st, E, T, _, p, v in langevin_nvt(self, numbers, pos, cell, pbc, steps, temperature_K, dt_fs, friction, vel=vel,
                                                       rng=rng):
                     atoms.positions, atoms._velocities = p, v
-                    yield st, E, T, bool(self.updated)
+                    yield st, E, T, bool(self.updated), _
                 return
         eng = self.engine
         kT = kB * temperature_K
         eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=friction, kT=kT)
         # (skip_gate: the configuration has been through calculate() — logged, counted, the model updated if need be —
         # and is evaluated once more on the device, whatever its covloss, to move on from it)
-        done, rows, skip_gate = 0, np.empty((0, N, 3)), first_on_host
-        while done <= steps:
-            n = 1 if skip_gate else min(chunk, steps + 1 - done)
+        done, rows, skip_gate, t_host = 0, np.empty((0, N, 3)), first_on_host, 0.0
+        batch = min(8, chunk)   # evaluations per md_run call: grows while nothing halts the device, shrinks back after a halt
+        while done <= steps:    # (every call uploads its rows of deviates; a halt throws the unused ones' upload away)
+            n = 1 if skip_gate else min(batch, steps + 1 - done)
             final = done + n == steps + 1
             need = n - 1 if final else n
             if len(rows) < need:
                 rows = np.concatenate([rows, rng.normal(size=(need - len(rows), N, 3))])
             noise = rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))])
             gate = 0.0 if skip_gate else self._md_gate(numbers)
+            t_run = time.time()
             sc, code = eng.md_run(n, noise, ediff=gate, final=final)
             accepted = len(sc) - 1 if code == 1 else len(sc)
-            lines = []
+            share = (time.time() - t_run) / max(accepted, 1)
+            lines, out = [], []
             for r in sc[:accepted]:
-                upd = False
+                upd, wall = False, share
                 if skip_gate:      # (the configuration calculate() has just dealt with, evaluated again with the new model:
-                    skip_gate, upd = False, bool(self.updated)   # its line is written, its step counted)
+                    skip_gate, upd, wall = False, bool(self.updated), share + t_host   # its line is written, its step counted)
                 else:
                     lines.append((self.step, "{} {} {} {}".format(float(r[0]), float(r[13] / (3 * N * kB)), float(r[11]), "")))
                     self.step += 1
-                yield done, float(r[0]), float(r[12] / (3 * N * kB)), upd
+                out.append((done, float(r[0]), float(r[12] / (3 * N * kB)), upd, wall))
                 done += 1
             self._log_lines(lines)
+            yield from out
             rows = rows[accepted:]
+            batch = min(8, chunk) if code else min(2 * batch, chunk)
             if code == 1:
+                t_host = time.time()
                 st = eng.md_state(results=True)
                 atoms.positions = st["positions"]
                 atoms._velocities = st["velocities_pre"]   # what the integrator holds when it asks for forces
@@ -489,6 +495,7 @@ class ActiveCalculator(Calculator):
                 self.results = {}
                 self.calculate(atoms)        # update_results + update + the log line, as inside an ASE loop
                 skip_gate = True
+                t_host = time.time() - t_host
         st = eng.md_state(results=True)
         atoms.positions, atoms._velocities = st["positions"], st["velocities"]
 

@@ -18,6 +18,8 @@
 
 #include "../../include/sgpr_hip.h"
 #include "sgpr_internal.h"
+#include <cmath>
+#include <limits>
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *fmt, ...)
@@ -2328,7 +2330,6 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
             return fail(SGPR_E_NODEVICE, "sgpr_md_run: no mapped host memory");
         m.scal_rows = (size_t)nevals + 1;
     }
-    memset(m.scal, 0, sizeof(double) * SGPR_MD_SCAL * ((size_t)nevals + 1));
     if (noise) {
         if (m.noise.alloc((size_t)nevals * 3 * N) || m.noise_raw.alloc((size_t)nevals * 3 * N))
             return fail(SGPR_E_NODEVICE, "sgpr_md_run: device allocation failed");
@@ -2355,12 +2356,31 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
     const unsigned step0 = h->step_count;
     const bool pend0 = m.t > 0;   // (the closing half kick of the first configuration: due unless it is the start of the trajectory)
-    const int CH = 16;       // evaluations enqueued between two looks at the halt word
-    std::vector<hipEvent_t> evs;
+    // The host runs AHEAD of the device by at most `LA` evaluations: before evaluation j is enqueued, evaluation j - LA must
+    // have written its overflow word into the scalar ring (mapped host memory; the ring is filled with NaN first), or
+    // the run must have halted.  A halt therefore leaves at most LA + 1 evaluations in the queue (they exit at once or
+    // recompute a discarded step), where a fixed chunk of 16 left up to 32 (14 ms per halt at 16384 atoms).  LA = 6 at 4096
+    // atoms (the host needs ~25 us to enqueue a step of ~80 us), 2 at 16384 (~0.5 ms per step).
+    const int LA = std::min(6, std::max(2, (int)lround(24576.0 / std::max(N, 1))));   // (fewer for large frames: their steps are long)
+    for (size_t k = 0; k < (size_t)SGPR_MD_SCAL * ((size_t)nevals + 1); k++) m.scal[k] = std::numeric_limits<double>::quiet_NaN();
     int enq = 0;
     bool halted = false;
     int rc_ = SGPR_OK;
     for (int j = 0; j < nevals && !halted && !rc_; j++) {
+        if (j >= LA) {
+            const volatile double *mark = m.scal + (size_t)SGPR_MD_SCAL * (j - LA) + 10;
+            const volatile int *hh = m.halt_host;
+            unsigned spins = 0;
+            while (std::isnan(*mark) && hh[0] == halt_none && hh[1] == halt_none) {
+                if ((++spins & 0x3fffu) == 0) {  // (a dead queue must not hang the host)
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q == hipSuccess && std::isnan(*mark)) { rc_ = fail(SGPR_E_NODEVICE, "sgpr_md_run: the queue drained without evaluation %d reporting", j - LA); break; }
+                    if (q != hipSuccess && q != hipErrorNotReady) { rc_ = fail(SGPR_E_NODEVICE, "sgpr_md_run: %s", hipGetErrorString(q)); break; }
+                }
+            }
+            if (rc_) break;
+            if (hh[0] != halt_none || hh[1] != halt_none) { halted = true; break; }
+        }
         const int sl = (int)((m.t + j) % 3), sn = (sl + 1) % 3, sp = (sl + 2) % 3;
         StepNext nx;
         const bool integrate = !(final_eval && j == nevals - 1);
@@ -2384,18 +2404,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         if (!h->pre_valid) { rc_ = fail(SGPR_E_UNSUPPORTED, "sgpr_md_run: the fused last kernel is not available for this model / frame (sharded, "
                                         "scatter-form reverse pass, graph capture or a zero skin)"); break; }
         enq = j + 1;
-        if (enq % CH == 0) {
-            hipEvent_t e;
-            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            HIPCHK(hipEventRecord(e, st));
-            evs.push_back(e);
-            if (evs.size() >= 2) {  // wait for the chunk before the last one, then look
-                HIPCHK(hipEventSynchronize(evs[evs.size() - 2]));
-                if (m.halt_host[0] != halt_none || m.halt_host[1] != halt_none) halted = true;
-            }
-        }
     }
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     if (rc_) { (void)hipStreamSynchronize(st); return rc_; }
     if (enq > 0) {  // the lagged reductions of the last evaluation enqueued
         FinArgs f = {};
@@ -2428,7 +2437,10 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         m.t += adv;
     }
     if (code == 2) done -= 1;  // (the overflowing evaluation's own results are void)
-    if (scalars && done > 0) memcpy(scalars, m.scal, sizeof(double) * SGPR_MD_SCAL * (size_t)done);
+    if (scalars && done > 0) {
+        memcpy(scalars, m.scal, sizeof(double) * SGPR_MD_SCAL * (size_t)done);
+        for (int r = 0; r < done; r++) scalars[(size_t)SGPR_MD_SCAL * r + 14] = scalars[(size_t)SGPR_MD_SCAL * r + 15] = 0.0;  // (spare)
+    }
     *evals_done = done;
     if (halt_code) *halt_code = code;
     h->lists_valid = false;
