@@ -40,6 +40,7 @@ SIGNATURES = {
     "sgpr_restore_weights": (C.c_int, [_vp, _vp]),
     "sgpr_solve": (C.c_int, [_vp, C.c_int, _vp, _vp, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_resolve": (C.c_int, [_vp, _dbl, _vp, _vp, _vp, _vp]),
+    "sgpr_jitcholesky": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "sgpr_resolve_batch": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "sgpr_make_vscale": (C.c_int, [_vp, _vp]),
     "sgpr_data_force_mae": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),

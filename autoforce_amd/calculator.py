@@ -705,7 +705,8 @@ class ActiveCalculator(Calculator):
             if not skip:
                 return int(np.argmax(beta))
             masked = np.array(beta, dtype=float)
-            masked[np.asarray(skip, dtype=int)] = -inf
+            idx = [int(i) for i in skip if 0 <= int(i) < len(masked)]   # (an `ignore` entry outside the frame is inert, as
+            masked[np.asarray(idx, dtype=int)] = -inf                    # in the reference's `k not in self.ignore`)
             if np.isfinite(masked).any() or (masked == inf).any():
                 return int(np.argmax(masked))
         order = np.argsort(-beta, kind="stable")

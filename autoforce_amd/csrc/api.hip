@@ -45,7 +45,6 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -53,22 +52,38 @@ static RcclApi g_rccl;
 static int rccl_load()
 {
     if (g_rccl.lib) return SGPR_OK;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // A copy that is ALREADY mapped wins (a process that imported torch has torch's bundled librccl.so.1: opening the
+    // unversioned name beside it could map a second, different RCCL with global symbol interposition).  Only when
+    // nothing is loaded is a library opened, and then with local binding.
     void *lib = nullptr;
-    for (const char *n : names)
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    const char *loaded[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : loaded)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names)
+            if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    }
     if (!lib) return fail(SGPR_E_NODEVICE, "RCCL is not available (dlopen librccl.so: %s): multi-GPU runs need it", dlerror());
     RcclApi a;
     a.lib = lib;
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
-    a.CommAbort = (decltype(a.CommAbort))dlsym(lib, "ncclCommAbort");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
         dlclose(lib);
         return fail(SGPR_E_NODEVICE, "librccl.so lacks an expected entry point");
+    }
+    // the types compiled in (ncclUniqueId, the enums) are those of <rccl/rccl.h>: the library must be of that major version
+    if (auto get_version = (ncclResult_t(*)(int *))dlsym(lib, "ncclGetVersion")) {
+        int v = 0;
+        if (get_version(&v) == ncclSuccess && v / 10000 != NCCL_VERSION_CODE / 10000) {
+            dlclose(lib);
+            return fail(SGPR_E_NODEVICE, "the RCCL in this process is version %d, the library was built against %d: rebuild "
+                        "libsgpr_hip.so against the installed rccl.h", v, (int)NCCL_VERSION_CODE);
+        }
     }
     g_rccl = a;
     return SGPR_OK;
@@ -593,7 +608,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
         }
         double *packed = f.packed + by * f.p_stride;
 #pragma unroll
-        for (int k = 0; k < 3; k++) packed[3 * c + k] = f.Fnbr[by * f.f_stride + 3 * i + k] + f.Fself[by * f.f_stride + 3 * i + k];
+        // (the scattered part is a fixed-point integer sum: order-independent, sgpr_internal.h)
+        for (int k = 0; k < 3; k++)
+            packed[3 * c + k] = (double)((const long long *)f.Fnbr)[by * f.f_stride + 3 * i + k] * (1.0 / SGPR_FIX_SCALE) + f.Fself[by * f.f_stride + 3 * i + k];
         double bt = 0.0;
         const int il = (i - f.first) / f.stride;
         if (f.has_beta && i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt) {
@@ -1814,6 +1831,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     if (h->d_stamps.p && h->d_pstamps.n < (size_t)16 * N) h->d_pstamps.alloc((size_t)16 * N);
     dp.stamps = h->d_stamps.p ? h->d_pstamps.p : nullptr;
     dp.xq = h->xcd_quads ? h->gemm_bm_k / 4 : 0;  // the forward pass writes the rows of the K_nm tiles
+    dp.stat = h->d_stat.p;
     int rcd = launch_list_forward(dp, sc, h->d_pos.p, cell_dev, h->d_pack.p, h->d_nn.p, h->d_lnn.p, h->d_nbr_j.p,
                                   h->d_nbr_shift.p, h->d_Pn.p, h->d_norm.p, h->d_C.p, h->d_shear.p, h->d_prec.p, st);
     if (rcd) return fail(SGPR_E_UNSUPPORTED, "descriptor kernel not compiled in");
@@ -1917,6 +1935,7 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         int stat[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
         if (stat[3] == 2) return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero");
+        if (stat[3] == 3) return fail(SGPR_E_OVERFLOW, "a pair force beyond 1024 eV/A left the fixed-point range of the sharded reverse pass");
         if (stat[3])
             return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 "
                         "cells from the origin): wrap the positions into the cell");
@@ -2038,6 +2057,26 @@ extern "C" int sgpr_stress_from_virial(const double *v, const double *cell, doub
     return SGPR_OK;
 }
 
+// A rank-local failure inside a sharded call must not leave the peers blocked in the step's all-reduce: this rank still
+// issues its ONE collective of the call, with a poison value in the overflow word, so that every rank fails the call
+// alike; and it forgets its warm state, like its peers will (the next call takes the checked path on every rank: the
+// same number of collectives everywhere).
+static void poison_peers(sgpr_model *h, int N)
+{
+    h->warm = false;
+    h->lists_valid = false;
+    if (!(h->comm && h->world > 1)) return;
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    static const double poison = SGPR_PEER_POISON;
+    const size_t n_out = (size_t)4 * N + 11;
+    if (hipMemsetAsync(h->d_packed.p, 0, sizeof(double) * n_out, h->stream) == hipSuccess &&
+        hipMemcpyAsync(h->d_packed.p + 4 * (size_t)N + 10, &poison, sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+        reduce_packed(h, h->d_packed.p, h->stream) == SGPR_OK)
+        (void)hipStreamSynchronize(h->stream);
+    memcpy(g_err, keep, sizeof(keep));
+}
+
 extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
                             const double *cell, const int32_t *pbc, int rank, int world, double *energy,
                             double *forces, double *stress, double *beta, double *cov)
@@ -2091,8 +2130,9 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         const bool direct = h->zero_copy_out && !h->comm && h->world == 1 && h->pin_dev;
         const double *pos_src = in_direct ? h->pin_dev : h->d_pos_in.p;
         int rf = enqueue_step(h, pos_src, pos_src + 3 * (size_t)N, direct ? h->pin_dev + n_in : h->d_packed.p, h->stream);
-        if (!rf) rf = reduce_packed(h, h->d_packed.p, h->stream);
-        if (rf) return rf;
+        if (rf) { poison_peers(h, N); return rf; }   // (a local enqueue failure: the peers are about to enter the all-reduce)
+        rf = reduce_packed(h, h->d_packed.p, h->stream);
+        if (rf) { h->warm = false; h->lists_valid = false; return rf; }
         if (!direct) HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
         if (tl) tls[3] = nowus();
         if (h->spin_wait) {  // option "spin_wait": poll the stream instead of a blocking wait
@@ -2127,20 +2167,7 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
     HIPCHK(hipMemcpyAsync(h->d_pos_in.p, positions, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_cell_in.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));
     const int rc_ = run_checked(h, h->d_pos_in.p, h->d_cell_in.p, h->d_packed.p, h->stream);
-    if (rc_ && h->comm && h->world > 1) {
-        // A rank-local failure must not leave the peers blocked in the step's all-reduce: this rank still issues
-        // its collective, with a poison value in the overflow word, and every rank fails the call alike.
-        char keep[sizeof(g_err)];
-        memcpy(keep, g_err, sizeof(keep));
-        const double poison = SGPR_PEER_POISON;
-        if (hipMemsetAsync(h->d_packed.p, 0, sizeof(double) * n_out, h->stream) == hipSuccess &&
-            hipMemcpyAsync(h->d_packed.p + 4 * (size_t)N + 10, &poison, sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
-            reduce_packed(h, h->d_packed.p, h->stream) == SGPR_OK)
-            (void)hipStreamSynchronize(h->stream);
-        memcpy(g_err, keep, sizeof(keep));
-        return rc_;
-    }
-    if (rc_) return rc_;
+    if (rc_) { poison_peers(h, N); return rc_; }
     h->warm = true;
     {   // (after the capacity-checked local pass: every rank issues exactly one collective per call)
         const int rr = reduce_packed(h, h->d_packed.p, h->stream);

@@ -261,7 +261,8 @@ struct DescArgs {
     int rows_ld, batch;
     size_t g_stride, f_stride, v_stride;  // doubles between the batch entries of G, F (= [Fnbr | Fself]), vir_part
     const double *W;        // backward: [N][Dpad]
-    double *Fnbr;           // backward: [Nall][3] (atomic)
+    double *Fnbr;           // backward: [Nall][3] 64-bit fixed-point sums (integer atomics; SGPR_FIX_SCALE)
+    int *stat;              // sticky status words (neighbor.hip): [3] = 3 when a force contribution leaves the fixed-point range
     double *Fself;          // backward: [Nall][3] (plain store, one writer)
     double *vir_part;       // backward: [gridDim][4 waves][9]
 };
@@ -1515,7 +1516,11 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
                     dst[1] = make_double2(gr[2], 0.0);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) unsafeAtomicAdd(&Fnbr_b[3 * (size_t)j + k], -gr[k]);
+                    for (int k = 0; k < 3; k++) {
+                        // (fixed point: the same bits whatever order the ranks' waves arrive in — sgpr_internal.h)
+                        if (!(fabs(gr[k]) < SGPR_FIX_LIMIT) && a.stat) atomicMax(&a.stat[3], 3);
+                        atomicAdd((unsigned long long *)&Fnbr_b[3 * (size_t)j + k], (unsigned long long)__double2ll_rn(-gr[k] * SGPR_FIX_SCALE));
+                    }
                 }
             }
             // 9 virial sums (+ 3 force sums in the sharded form) through the region: [12][CH], then 48
@@ -1678,6 +1683,7 @@ static DescArgs make_args(const DescParams &p)
     a.N = p.N; a.Nall = p.Nall; a.first = p.first; a.stride = p.stride > 0 ? p.stride : 1; a.maxnn = p.maxnn; a.S = p.S; a.Dc = p.Dc; a.Dpad = p.Dpad; a.CS = p.CS;
     a.rc = p.rc;
     a.xq = p.xq;
+    a.stat = p.stat;
     a.irc = 1.0 / p.rc;
     for (int k = 0; k < SGPR_MAX_S; k++) { a.radii_v[k] = p.radii_v[k]; a.radii_iv[k] = 1.0 / p.radii_v[k]; }
     return a;
@@ -1741,7 +1747,7 @@ int launch_descriptor_backward(const DescParams &p, const double *pos, const dou
     a.shear = (int *)shear; a.W = W; a.prec = (double *)prec;
     a.stamps = p.stamps ? p.stamps + 8 * (size_t)p.Nall : nullptr;
     // gather form (G != null): pair gradients go to G[Nall][maxnn][4], the step's last kernel sums them.
-    // scatter form: F points at [Fnbr | Fself] (fp64 atomics into Fnbr; sharded frames).
+    // scatter form: F points at [Fnbr | Fself] (64-bit fixed-point integer atomics into Fnbr; sharded frames).
     a.G = G; a.aux = aux; a.T = T; a.t_stride = t_stride; a.cidx = cidx; a.hm = hm; a.hmw = hmw;
     a.Fnbr = F;
     a.Fself = F ? F + 3 * (size_t)p.Nall : nullptr;

@@ -11,6 +11,13 @@
 #define SGPR_MAX_N 4        // nmax supported
 #define SGPR_EPS 2.220446049250313e-16  // torch.finfo(float64).eps (descriptor/sesoap.py:250)
 #define SGPR_TINY_ANGLE 1e-2            // descriptor/ylm.py:10
+// Scatter form of the reverse pass (sharded frames): the force a neighbour receives is accumulated as a 64-bit FIXED-POINT
+// integer, SGPR_FIX_SCALE = 2^46 units per eV/A.  Integer addition is associative: the sum no longer depends on the order
+// in which the atomics land, so a sharded step repeats bit for bit (fp64 atomics did not: 1e-16-level noise that an
+// ill-conditioned refit amplifies, and the hardest runs to debug are the sharded ones).  One unit is 1.4e-14 eV/A — a few
+// ulp of a typical force; a single contribution is limited to 2^10 eV/A (flagged beyond: stat[3] = 3), a sum to 2^17.
+#define SGPR_FIX_SCALE 70368744177664.0
+#define SGPR_FIX_LIMIT 1024.0
 
 // Coefficients of the solid-harmonic recurrences (descriptor/ylm.py:57-77), fp64, host-built.
 struct HarmCoef {
@@ -113,6 +120,7 @@ struct DescParams {
     double rc;
     long long *stamps;  // diagnostic build only (SGPR_STAMPS=1 + -DSGPR_PHASE_STAMPS): [2][Nall][8]
     int xq;             // quads of atoms per row tile of the GEMM that follows / precedes (XCD-aware workgroup -> atoms map), 0: off
+    int *stat;          // sticky status words (NlScratch::stat), may be null
 };
 
 // Neighbour lists + forward descriptors of this rank's atoms, one launch (one wave per atom): sweep of

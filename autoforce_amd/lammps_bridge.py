@@ -19,9 +19,12 @@ try:  # pragma: no cover - ASE is optional
 except ImportError:
     from .ase_shim import Atoms
 
-# 1 [LAMMPS unit] = factor [ASE unit]  (ASE: Angstrom, eV, eV/Angstrom, eV/Angstrom^3)
-_EV_PER_KCALMOL = 0.0433641153087705
-_EV_A3_PER_PA = 1.0 / 1.602176634e11
+# 1 [LAMMPS unit] = factor [ASE unit]  (ASE: Angstrom, eV, eV/Angstrom, eV/Angstrom^3), from the SI values
+# ase.calculators.lammps.convert is built on (unitconvert_constants.py: LAMMPS' own kim_units numbers, CODATA 2014) —
+# the reference converts with that function (cl/lmp.py:3,47-67); tests/golden/lammps_units.json holds the tables
+_EV_SI, _KCAL_SI, _AVOGADRO = 1.6021766208e-19, 4184.0, 6.022140857e23
+_EV_PER_KCALMOL = _KCAL_SI / _AVOGADRO / _EV_SI
+_EV_A3_PER_PA = 1e-30 / _EV_SI
 TO_ASE = {
     "metal": dict(distance=1.0, energy=1.0, force=1.0, pressure=1e5 * _EV_A3_PER_PA),                       # bar
     "real": dict(distance=1.0, energy=_EV_PER_KCALMOL, force=_EV_PER_KCALMOL, pressure=101325.0 * _EV_A3_PER_PA),  # atm

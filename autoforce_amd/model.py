@@ -299,6 +299,18 @@ class SGPRModel:
         self.make_vscale()
         return mu
 
+    def jitcholesky(self, A):
+        """regression/algebra.py:29-47 on the device for any symmetric matrix: (L, ridge)."""
+        A = f64(A)
+        n = len(A)
+        L = np.zeros((n, n))
+        ridge = C.c_double(0)
+        code = _lib.load().sgpr_jitcholesky(self._h, n, ptr(A), ptr(L), C.addressof(ridge))
+        if code == _lib.E_NOT_PD:
+            raise RuntimeError("cholesky was not successful!")
+        check(code)
+        return L, ridge.value
+
     def resolve(self, noise=0.01):
         """The same regression for another noise, re-using the factored [K | Y] of the last `solve`
         (the evaluations of _regression(optimize=True), gppotential.py:1265-1300)."""

@@ -17,9 +17,12 @@ import threading
 
 class Watchdog:
     def __init__(self, what, seconds=None, rank=0, stream=None):
+        # SGPR_WATCHDOG_S is a FLOOR (wait at least that long), not an override: a site that asks for more — the timed
+        # region of a long benchmark — keeps its own limit; 0 switches every watchdog off
         env = os.environ.get("SGPR_WATCHDOG_S")
         self.what, self.rank = what, rank
-        self.seconds = float(env) if env else (120.0 if seconds is None else float(seconds))
+        base = 120.0 if seconds is None else float(seconds)
+        self.seconds = base if not env else (0.0 if float(env) <= 0 else max(float(env), base))
         self.stream = stream or sys.stderr
         self._timer = None
 

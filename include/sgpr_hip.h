@@ -121,6 +121,14 @@ int sgpr_restore_weights(sgpr_model *h, const double *mu);
 int sgpr_solve(sgpr_model *h, int rows, const double *K, const double *Y, double noise0,
                double *mu_out, double *choli_out, double *ridge_out, double *sigma_out);
 
+/*
+ * jitcholesky of a matrix the caller holds (regression/algebra.py:29-47): L L^T = A + ridge I with the reference's
+ * ladder — ridge 0 first, then 1e-6 * mean(diag A) doubled until the factorisation succeeds; SGPR_E_NOT_PD
+ * ("cholesky was not successful!", :45-46) once the ridge exceeds mean(diag A).  A: host, row-major n x n
+ * (symmetric; the lower triangle is read).  L_out (may be NULL): row-major n x n, upper triangle zero.
+ */
+int sgpr_jitcholesky(sgpr_model *h, int n, const double *A, double *L_out, double *ridge_out);
+
 /* The same regression for another noise value, with the design matrix of the last sgpr_solve:
  * the QR of [K | Y] is kept on the device (R, Q^T Y), the noise only enters a 2m x m second stage.
  * This is what _regression(optimize=True) evaluates repeatedly (gppotential.py:1265-1300). */

@@ -183,6 +183,28 @@ def test_sharded_lips4096_against_oracle():
     mdl.close()
 
 
+def test_sharded_partial_sums_repeat_bit_for_bit():
+    """The scatter form of the reverse pass (what a rank of a sharded run executes) hands forces to neighbours through
+    atomics: as 64-bit fixed-point integer sums they do not depend on the order the atomics land in, so every rank's
+    partial forces repeat bit for bit from run to run — as the single-rank path's do
+    (test_full_size_step_is_bit_reproducible) — and the sharded total equals the unsharded one to a few units of the
+    fixed-point grid (1.4e-14 eV/A per addition)."""
+    mdl, numbers, pos, cell, pbc = _lips_model(16, 512)
+    whole = mdl.predict(numbers, pos, cell, pbc)
+    for world in (2, 4, 8):
+        runs = []
+        for _ in range(3):
+            parts = [mdl.predict(numbers, pos + 0.0, cell, pbc, rank=r, world=world) for r in range(world)]
+            runs.append(parts)
+        for r in range(world):
+            for k in ("forces", "energy", "stress", "beta"):
+                assert np.array_equal(np.asarray(runs[0][r][k]), np.asarray(runs[1][r][k])), (world, r, k)
+                assert np.array_equal(np.asarray(runs[0][r][k]), np.asarray(runs[2][r][k])), (world, r, k)
+        tot = sum(p["forces"] for p in runs[0])
+        assert np.abs(tot - whole["forces"]).max() <= 2e-11 * max(1.0, np.abs(whole["forces"]).max())
+    mdl.close()
+
+
 def test_native_communicator_single_rank():
     """The library's own RCCL path on the one GPU of this box: a communicator of one rank, the step's
     all-reduce enqueued on the step's stream (sgpr_comm_init / sgpr_step_dev), the free-standing

@@ -198,9 +198,37 @@ def test_solve_jitter_ladder_and_failure():
     assert mdl.ridge > 0.0
     _, ridge = orc.jitcholesky(mdl.M)
     assert ridge > 0.0
-    # both sit on a rung of the same ladder: ratio is a power of two
-    ratio = np.log2(mdl.ridge / ridge)
-    assert abs(ratio - round(ratio)) < 1e-9 and abs(ratio) <= 2
+    # the ladder is deterministic given M (regression/algebra.py:29-47): the SAME rung
+    assert mdl.ridge == ridge, (mdl.ridge, ridge, np.log2(mdl.ridge / ridge))
+    mdl.close()
+
+
+def test_jitcholesky_ladder_against_the_reference_fixture():
+    """g7 (the reference's own jitcholesky on a positive definite, a semi-definite and the all-ones matrix of
+    algebra.py:218-224): the device ladder must stop at the rung the reference stopped at, with its factor."""
+    g = load("g7_regression")
+    mdl = model_from_fixture(load("g5_si32"))
+    L, ridge = mdl.jitcholesky(g["chol_pd_M"])
+    assert ridge == 0.0
+    np.testing.assert_allclose(L, g["chol_pd_L"], rtol=1e-11, atol=1e-13)
+    L, ridge = mdl.jitcholesky(g["chol_sd_M"])
+    assert abs(ridge - float(g["chol_sd_ridge"])) <= 1e-14 * ridge     # (the mean's summation order is torch's)
+    M = g["chol_sd_M"] + ridge * np.eye(len(g["chol_sd_M"]))
+    np.testing.assert_allclose(L @ L.T, M, rtol=0, atol=1e-12 * np.abs(M).max())
+    L, ridge = mdl.jitcholesky(np.ones((30, 30)))
+    assert ridge == float(g["chol_ones_ridge"])
+    np.testing.assert_allclose(L, g["chol_ones_L"], rtol=1e-6, atol=1e-9)
+    with pytest.raises(RuntimeError, match="cholesky was not successful"):
+        mdl.jitcholesky(-np.eye(4))
+    # a larger matrix than one panel: a rank-deficient Gram matrix of 150 vectors in 100 dimensions
+    rng = np.random.default_rng(3)
+    V = rng.normal(size=(150, 100))
+    G = V @ V.T
+    from oracle import oracle as orc
+    L0, r0 = orc.jitcholesky(G)
+    L1, r1 = mdl.jitcholesky(G)
+    assert r1 == r0 and r0 > 0.0
+    np.testing.assert_allclose(L1 @ L1.T, G + r1 * np.eye(150), rtol=0, atol=1e-10 * np.abs(G).max())
     mdl.close()
 
 

@@ -67,4 +67,59 @@ def test_callback(units):
     ref2 = calc.engine.predict(g["numbers"], g["positions"] + 0.01, cell, [True] * 3)
     np.testing.assert_allclose(fext, convert(ref2["forces"][tag - 1], "force", "ASE", units), rtol=1e-12, atol=1e-14)
     if units == "metal":
-        assert abs(convert(1.0, "pressure", "metal", "ASE") * 1.602176634e6 - 1.0) < 1e-12  # 1 bar in eV/A^3
+        assert abs(convert(1.0, "pressure", "metal", "ASE") * 1.6021766208e6 - 1.0) < 1e-12  # 1 bar in eV/A^3 (ASE's e)
+
+
+def _fixture():
+    import json
+    import os
+    from conftest import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "lammps_units.json")))
+
+
+@pytest.mark.parametrize("units", ["metal", "real"])
+def test_units_against_the_lammps_tables(units):
+    """tests/golden/lammps_units.json (LAMMPS' documented unit styles and Update::set_units constants, the SI values
+    ase.calculators.lammps.convert uses): every factor of the bridge re-derived from the fixture, the nktv2p column the
+    reference copies, and the physical identity that ties them — the virial handed to LAMMPS is -stress x volume in
+    LAMMPS energy units."""
+    fx = _fixture()
+    st, si = fx["styles"][units], fx["si"]
+    assert NKTV2P[units] == st["nktv2p"]
+    e_si = {"ev": si["ev"], "kcal/mol": si["kcal"] / si["avogadro"]}[st["energy"]]
+    p_si = si[st["pressure"]]
+    assert st["distance"] == "angstrom"
+    assert abs(float(convert(1.0, "distance", units, "ASE")) - 1.0) == 0.0
+    assert abs(float(convert(1.0, "energy", units, "ASE")) - e_si / si["ev"]) <= 1e-15
+    assert abs(float(convert(1.0, "force", units, "ASE")) - e_si / si["ev"]) <= 1e-15
+    assert abs(float(convert(1.0, "pressure", units, "ASE")) / (p_si * si["angstrom"] ** 3 / si["ev"]) - 1.0) <= 1e-15
+    # nktv2p converts [energy / volume] of the style into its pressure unit (LAMMPS doc: "nktv2p"): consistent with
+    # the SI table to the vintage of the constants (LAMMPS' 1.6021765e-19 C against 1.6021766208e-19)
+    assert abs(st["nktv2p"] / (e_si / si["angstrom"] ** 3 / p_si) - 1.0) < 2e-7
+    # the callback's virial: -sigma V, energy units of the style
+    sigma = np.array([0.011, -0.007, 0.004, 0.0021, -0.0013, 0.0008])   # eV / A^3, Voigt
+    vol = 812.5
+    v = -convert(sigma, "pressure", "ASE", units) / (NKTV2P[units] / vol)
+    np.testing.assert_allclose(convert(v, "energy", units, "ASE"), -sigma * vol, rtol=2e-7, atol=0)
+
+
+def test_virial_component_order():
+    """LAMMPS: xx, yy, zz, xy, xz, yz; ASE Voigt: xx, yy, zz, yz, xz, xy — the bridge reverses the last three
+    (cl/lmp.py:70), checked through the callback with a calculator whose stress names its components."""
+    fx = _fixture()
+    lam, ase = fx["virial_order_lammps"], fx["voigt_order_ase"]
+    perm = [ase.index(c) for c in lam]
+    assert perm == [0, 1, 2, 5, 4, 3]
+
+    class Calc:
+        implemented_properties = ["energy", "forces", "stress"]
+
+        def get_property(self, name, atoms=None):
+            return {"energy": 0.0, "forces": np.zeros((2, 3)), "stress": np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0])}[name]
+
+    cell = np.diag([5.0, 6.0, 7.0])
+    lmp = FakeLammps(np.zeros((2, 3)), np.array([1, 1]), cell, 1.0)
+    bridge = FixExternalBridge(lmp, Calc(), "metal", {1: 3}, "autoforce")
+    bridge(None, 0, 2, np.array([1, 2]), None, np.zeros((2, 3)))
+    got = lmp.virial[1] / lmp.virial[1][0]      # (xx carries 1.0)
+    np.testing.assert_allclose(got, np.array([1.0, 2.0, 3.0, 6.0, 5.0, 4.0]), rtol=1e-14)
