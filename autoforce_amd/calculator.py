@@ -421,20 +421,24 @@ class ActiveCalculator(Calculator):
             return EPS
         return float(min(self._ediff_lb.values))
 
-    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256):
+    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256, seed=1):
         """`steps` steps of Langevin NVT (friction = 0: NVE) from atoms.positions / velocities, as cl/md.py:117-128 sets
         it up around this calculator — but the state stays in device memory between model updates: the integrator runs
         inside the step's last kernel (SGPRModel.md_run), the host reads 16 scalars per step and writes the same log
         line calculate() would ("energy temperature covloss", active.py:518-523), and a step whose largest covloss
         reaches the sampling threshold stops the device, is handed to calculate() — which updates the model exactly as
         it does inside an ASE loop — and the run goes on from there with the new model.  Yields (step, energy,
-        temperature, updated, wall seconds) per step (device steps share the wall time of their batch evenly); atoms.positions / velocities are current at every yield that follows an update
+        temperature, updated, wall seconds) per step (device steps share the wall time of their batch evenly).  rng: a
+        numpy Generator whose normal deviates move the atoms (the stream of workloads.langevin_nvt: the two loops then
+        agree bit for bit), or None — the integrator draws its own on the device (counter-based on `seed`: no host
+        generator and no upload on the step's path, same trajectory however the run is batched); atoms.positions / velocities are current at every yield that follows an update
         and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no."""
         from .ase_shim import kB
         from .workloads import FS, MASS, langevin_nvt
         numbers, pos, cell, pbc = self._system(atoms)
         N = len(numbers)
-        rng = np.random.default_rng(1) if rng is None else rng
+        on_device_rng = rng is None and friction > 0.0
+        rng = np.random.default_rng(seed) if rng is None else rng
         if getattr(atoms, "_masses", "ase") is None:  # (the stand-in Atoms without masses; ase.Atoms knows its own)
             masses = np.array([MASS[int(z)] for z in numbers])
             atoms._masses = masses.copy()
@@ -455,7 +459,8 @@ class ActiveCalculator(Calculator):
                 return
         eng = self.engine
         kT = kB * temperature_K
-        eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=friction, kT=kT)
+        eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=friction, kT=kT,
+                     seed=(int(seed) or 1) if on_device_rng else 0)
         # (skip_gate: the configuration has been through calculate() — logged, counted, the model updated if need be —
         # and is evaluated once more on the device, whatever its covloss, to move on from it)
         done, rows, skip_gate, t_host = 0, np.empty((0, N, 3)), first_on_host, 0.0
@@ -463,10 +468,10 @@ class ActiveCalculator(Calculator):
         while done <= steps:    # (every call uploads its rows of deviates; a halt throws the unused ones' upload away)
             n = 1 if skip_gate else min(batch, steps + 1 - done)
             final = done + n == steps + 1
-            need = n - 1 if final else n
+            need = 0 if on_device_rng else (n - 1 if final else n)
             if len(rows) < need:
                 rows = np.concatenate([rows, rng.normal(size=(need - len(rows), N, 3))])
-            noise = rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))])
+            noise = None if on_device_rng else (rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))]))
             gate = 0.0 if skip_gate else self._md_gate(numbers)
             t_run = time.time()
             sc, code = eng.md_run(n, noise, ediff=gate, final=final)

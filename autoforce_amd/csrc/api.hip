@@ -121,6 +121,7 @@ struct MdState {
     int N = 0;
     long long t = 0;               // evaluations completed (= index of the configuration to evaluate next)
     double hdt = 0.0, c1 = 1.0, dt = 0.0;
+    unsigned long long seed = 0;   // != 0: the integrator draws its own deviates (sgpr_md_seed)
     DevBuf<double> X, V, P, KE, mass, sig, noise, noise_raw, cell;
     DevBuf<int> halt;
     int *halt_host = nullptr, *halt_host_dev = nullptr;
@@ -393,7 +394,10 @@ struct FinNext {
     const double *x_cur, *v_cur;   // [N][3] sorted: positions of this step, velocities BEFORE its closing half kick
     double *x_next, *v_next;
     const double *mass, *sig;      // [N] sorted: mass, c2 sqrt(kT / m)
-    const double *noise;           // [N][3] SORTED order (sorted on upload): the normal deviates of the next step's O (null: none)
+    const double *noise;           // [N][3] SORTED order (sorted on upload): the normal deviates of the next step's O (null: none
+                                   //   — or, with a seed, drawn here: md_deviate)
+    unsigned long long seed;       // != 0 and noise == null: counter-based deviates (Philox4x32-10 + Box-Muller) of
+    long long t_index;             //   (seed; configuration index t_index, caller atom, component)
     double hdt, c1;                // dt / 2, exp(-friction dt)
     int pending;                   // the closing half kick of this step is due (0 only for the very first evaluation)
     double *ke_cur;                // [N][2] m v^2 of this step: after the closing half kick | before it
@@ -684,6 +688,37 @@ __global__ __launch_bounds__(256) void finalize_gather_kernel(FinArgs f)
     }
 }
 
+// Standard normal deviate number (t, atom, component) of the stream `seed`: Philox4x32-10 (Salmon et al., SC'11) on the
+// counter (t lo, t hi, atom, component), two 53-bit uniforms, Box-Muller.  Counter-based: a deviate depends on WHAT it
+// is for, not on when it is drawn — a run reproduces whatever its batching, and an evaluation repeated after a halt
+// draws the same numbers.  (The host loop draws from numpy instead: sgpr_md_run accepts its rows; sgpr_md_deviates
+// returns these for a host twin.)
+__device__ __forceinline__ double md_deviate(unsigned long long seed, long long t, int atom, int comp)
+{
+    unsigned c0 = (unsigned)t, c1 = (unsigned)((unsigned long long)t >> 32), c2 = (unsigned)atom, c3 = (unsigned)comp;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned long long a = ((unsigned long long)c0 << 32) | c1, b = ((unsigned long long)c2 << 32) | c3;
+    const double u1 = (double)((a >> 11) + 1ull) * (1.0 / 9007199254740992.0);   // (0, 1]
+    const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);           // [0, 1)
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+
+__global__ void md_deviates_kernel(int N, int rows, unsigned long long seed, long long t0, double *out)
+{
+    const size_t n3 = (size_t)3 * N, tot = n3 * rows;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / n3, w = e - r * n3;
+        out[e] = md_deviate(seed, t0 + (long long)r, (int)(w / 3), (int)(w % 3));
+    }
+}
+
 // The same gather, and with it the first kernel of the NEXT step (FinNext): a wave takes an atom to its next position —
 // read from the next frame (MODE 1) or integrated (MODE 2) —, bins it there and takes part in the rebuild decision.
 // Grid: ceil(N / 4) gather workgroups, 11 reducers of this step, 2 lagged reducers.
@@ -824,6 +859,7 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
         kp = ms * (vc * vc);               // ... and the one the calculator is handed with the positions (its log line)
         const double v2 = v + kick;        // B
         const double x1 = xc + x.hdt * v2; // A
+        if (!x.noise && x.seed != 0ull && sg != 0.0) nz = md_deviate(x.seed, x.t_index, c, lane);
         const double v3 = x.c1 * v2 + sg * nz;  // O
         xn = x1 + x.hdt * v3;              // A
         x.x_next[3 * (size_t)i + lane] = xn;
@@ -2419,6 +2455,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         x.x_next = m.X.p + (size_t)3 * N * sn; x.v_next = m.V.p + (size_t)3 * N * sn;
         x.mass = m.mass.p; x.sig = m.sig.p; x.noise = noise ? m.noise.p + (size_t)j * 3 * N : nullptr;
         x.hdt = m.hdt; x.c1 = m.c1; x.pending = (j > 0 || pend0) ? 1 : 0;
+        x.seed = noise ? 0ull : m.seed; x.t_index = m.t + j;
         x.ke_cur = m.KE.p + (size_t)2 * N * sl; x.ke_prev = j > 0 ? m.KE.p + (size_t)2 * N * sp : nullptr;
         x.packed_prev = j > 0 ? m.P.p + plen * sp : nullptr;
         x.ediff = ediff > 0.0 ? ediff : 1e300;
@@ -2502,6 +2539,30 @@ extern "C" int sgpr_md_state(sgpr_model *h, double *positions, double *velocitie
     }
     if (pending) *pending = (m.t + which) > 0 ? 1 : 0;   // (every configuration but the start of the trajectory)
     if (packed) HIPCHK(hipMemcpy(packed, m.P.p + (size_t)sgpr_packed_len(N) * sl, sizeof(double) * sgpr_packed_len(N), hipMemcpyDeviceToHost));
+    return SGPR_OK;
+}
+
+// Deviates of the integrator on the device: seed != 0 makes sgpr_md_run (called with noise = NULL) draw the standard
+// normal deviate of (configuration index, atom, component) from a counter-based generator; 0 switches that off.
+extern "C" int sgpr_md_seed(sgpr_model *h, uint64_t seed)
+{
+    if (!h) return fail(SGPR_E_INVALID, "sgpr_md_seed: bad arguments");
+    h->md.seed = seed;
+    return SGPR_OK;
+}
+
+// The deviates sgpr_md_run uses to move configurations [t_first, t_first + count) on, out[count][N][3] in caller atom
+// order (for a host-side twin of a seeded run).
+extern "C" int sgpr_md_deviates(sgpr_model *h, int64_t t_first, int count, double *out)
+{
+    if (!h || count <= 0 || !out) return fail(SGPR_E_INVALID, "sgpr_md_deviates: bad arguments");
+    MdState &m = h->md;
+    if (!m.active || m.seed == 0) return fail(SGPR_E_INVALID, "sgpr_md_deviates: call sgpr_md_begin and sgpr_md_seed first");
+    HIPCHK(hipSetDevice(h->device));
+    DevBuf<double> d;
+    if (d.alloc((size_t)count * 3 * m.N, false)) return fail(SGPR_E_NODEVICE, "sgpr_md_deviates: device allocation failed");
+    hipLaunchKernelGGL(md_deviates_kernel, dim3(1024), dim3(256), 0, h->stream, m.N, count, m.seed, (long long)t_first, d.p);
+    HIPCHK(hipMemcpy(out, d.p, sizeof(double) * (size_t)count * 3 * m.N, hipMemcpyDeviceToHost));
     return SGPR_OK;
 }
 

@@ -495,7 +495,7 @@ class SGPRModel:
     # ------------------------------------------------------------------ device-resident molecular dynamics
     MD_SCALARS = 16  # per evaluation: E, virial[9], overflow word, largest covloss, sum m v^2, 3 spare
 
-    def md_begin(self, numbers, positions, cell, pbc, masses, velocities=None, dt=1.0, friction=0.0, kT=0.0):
+    def md_begin(self, numbers, positions, cell, pbc, masses, velocities=None, dt=1.0, friction=0.0, kT=0.0, seed=0):
         """State of an MD run into device memory (cl/md.py:117-128 drives ase.md.langevin around calculate();
         here the integrator is part of the step's last kernel).  dt, friction and kT in the caller's units
         (workloads.FS / ase_shim.kB for fs / K)."""
@@ -507,6 +507,14 @@ class SGPRModel:
         check(_lib.load().sgpr_md_begin(self._h, N, ptr(numbers), ptr(f64(positions).reshape(N, 3)), ptr(self._md["cell"]),
                                         ptr(i32(np.asarray(pbc, bool).astype(np.int32))), ptr(self._md["masses"]), ptr(v),
                                         float(dt), float(friction), float(kT)))
+        # seed != 0: md_run(noise=None) draws the Langevin deviates on the device (counter-based, md_deviates returns them)
+        check(_lib.load().sgpr_md_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+        self._md["t"] = 0
+
+    def md_deviates(self, t_first, count):
+        out = np.empty((int(count), self._md["N"], 3))
+        check(_lib.load().sgpr_md_deviates(self._h, int(t_first), int(count), ptr(out)))
+        return out
 
     def md_run(self, nevals, noise=None, ediff=0.0, final=False):
         """Evaluate `nevals` configurations starting with the current one, integrating between them on the device

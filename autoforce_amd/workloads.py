@@ -183,7 +183,7 @@ def langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=
 
 
 def langevin_nvt_device(model, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=1e-3, seed=1, vel=None,
-                        ediff=0.0, chunk=256, on_halt=None):
+                        ediff=0.0, chunk=256, on_halt=None, device_rng=False):
     """langevin_nvt with the state in device memory (SGPRModel.md_begin / md_run): same scheme, same random stream
     (one rng.normal(size=(N, 3)) per step, drawn here and uploaded a chunk at a time), so positions and velocities equal
     the host loop's bit for bit.  Yields (step, energy, temperature, largest covloss) per evaluation.  With ediff > 0 an
@@ -199,17 +199,20 @@ def langevin_nvt_device(model, numbers, pos, cell, pbc, steps, temperature=600.0
     if vel is None:
         vel = rng.normal(size=(N, 3)) * np.sqrt(kT / mass[:, None])
         vel -= (mass[:, None] * vel).sum(0) / mass.sum()
-    model.md_begin(numbers, pos, cell, pbc, mass, vel, dt=dt_fs * FS, friction=friction, kT=kT)
+    # device_rng: the deviates are drawn on the device (counter-based on `seed`; SGPRModel.md_deviates returns them for a
+    # host twin) instead of from numpy here: nothing is generated or uploaded on the step's path
+    model.md_begin(numbers, pos, cell, pbc, mass, vel, dt=dt_fs * FS, friction=friction, kT=kT,
+                   seed=(int(seed) or 1) if device_rng else 0)
     done = 0                      # evaluations accepted so far (evaluation k = the configuration after k steps)
     rows = np.empty((0, N, 3))    # deviates drawn and not yet consumed: rows[0] moves the current configuration on
     skip_gate = False
     while done <= steps:
         n = 1 if skip_gate else min(chunk, steps + 1 - done)
         final = done + n == steps + 1
-        need = n - 1 if final else n
+        need = 0 if device_rng else (n - 1 if final else n)
         if len(rows) < need:  # (numpy fills an (r, N, 3) request like r requests of (N, 3): the host loop's stream)
             rows = np.concatenate([rows, rng.normal(size=(need - len(rows), N, 3))])
-        noise = rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))])
+        noise = None if device_rng else (rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))]))
         sc, code = model.md_run(n, noise, ediff=0.0 if skip_gate else ediff, final=final)
         accepted = len(sc) - 1 if code == 1 else len(sc)
         if accepted:

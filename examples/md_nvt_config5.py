@@ -22,7 +22,7 @@ from autoforce_amd import workloads  # noqa: E402
 
 
 def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=0.1, temperature=600.0, n_exceed=8,
-        verbose=False, stop_after_downsizes=None, min_steps=0, device_md=True):
+        verbose=False, stop_after_downsizes=None, min_steps=0, device_md=True, host_rng=False):
     """friction: per ASE time unit.  The reference CLI's default, 1e-3 (cl/md.py:31), is a 10-ps coupling: invisible
     in a few hundred fs.  The default here (0.1: 0.1 ps) lets a short run show whether the thermostat HOLDS the
     temperature while the model is edited under it."""
@@ -60,12 +60,13 @@ def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=
             yield step, E, T, wall, p, bool(calc.updated)
 
     def device_loop():
-        # the same scheme and the same random stream (workloads.langevin_nvt draws from default_rng(1)) with positions and
-        # velocities in device memory: prediction-only steps never leave the device, a step whose covloss reaches the
+        # the same scheme with positions and velocities in device memory (host_rng: also the same random stream as
+        # workloads.langevin_nvt, drawn from default_rng(1) here and uploaded; default: drawn on the device): prediction-only steps never leave the device, a step whose covloss reaches the
         # sampling threshold is handed to calculate() (ActiveCalculator.run_md); the steps of a device batch share its wall time
         from autoforce_amd.ase_shim import Atoms
         at = Atoms(numbers, pos, cell, pbc, velocities=vel, masses=np.array([workloads.MASS[int(z)] for z in numbers]))
-        for step, E, T, upd, wall in calc.run_md(at, steps, temperature, dt_fs=1.0, friction=friction, rng=np.random.default_rng(1), chunk=64):
+        rng = np.random.default_rng(1) if host_rng else None   # None: the deviates are drawn on the device
+        for step, E, T, upd, wall in calc.run_md(at, steps, temperature, dt_fs=1.0, friction=friction, rng=rng, chunk=64, seed=1):
             yield step, E, T, wall, at.positions, upd
 
     for step, E, T, wall, p, updated in (device_loop() if device_md else host_loop()):
@@ -124,10 +125,11 @@ def main():
     ap.add_argument("--friction", type=float, default=0.1)
     ap.add_argument("--n-exceed", type=int, default=8, help="ediff = the n-th largest covloss of a held-out equilibrated frame")
     ap.add_argument("--host-loop", action="store_true", help="integrate in numpy, one calculate() per step (the round-3 driver)")
+    ap.add_argument("--host-rng", action="store_true", help="device loop with numpy's deviates uploaded (the host loop's trajectory, bit for bit)")
     args = ap.parse_args()
     t0 = time.time()
     res = run(args.steps, tuple(args.side), args.m_seed, args.max_inducing, args.friction, n_exceed=args.n_exceed, verbose=True,
-              device_md=not args.host_loop)
+              device_md=not args.host_loop, host_rng=args.host_rng)
     rows = res["rows"]
     upd = [1e3 * r["wall"] - r["teacher_ms"] for r in rows[1:] if r["updated"]]
     capped = [1e3 * r["wall"] - r["teacher_ms"] for r in rows[1:] if r["updated"] and r["size"][1] >= args.max_inducing]

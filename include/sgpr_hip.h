@@ -322,6 +322,13 @@ int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, double ediff, in
                 int *evals_done, int *halt_code);
 int sgpr_md_state(sgpr_model *h, double *positions, double *velocities_pre, int *pending, double *packed, int which);
 int sgpr_md_end(sgpr_model *h);
+/* Deviates drawn on the device: with a seed != 0, sgpr_md_run called with noise = NULL draws xi itself — deviate
+ * (configuration index, atom, component) of a counter-based generator (Philox4x32-10, Box-Muller), so a run does not
+ * depend on how it is cut into calls and an evaluation repeated after a halt draws the same numbers; no host generator
+ * and no upload on the step's path (the reference draws from numpy inside ase.md.langevin, cl/md.py:117-128).
+ * sgpr_md_deviates returns the rows of configurations [t_first, t_first + count): out[count][N][3], caller atom order. */
+int sgpr_md_seed(sgpr_model *h, uint64_t seed);
+int sgpr_md_deviates(sgpr_model *h, int64_t t_first, int count, double *out);
 /*
  * Multi-GPU (one process per GPU, atoms sharded as in sgpr_bind_system): the reference combines the
  * ranks' partial sums with four MPI all-reduces per step (calculator/active.py:562,601,602,777,

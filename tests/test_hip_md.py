@@ -243,3 +243,51 @@ def test_on_the_fly_learning_on_the_device_equals_the_host_loop(tmp_path):
         else:
             assert a == b
     assert np.array_equal(finals[0][0], finals[1][0]) and np.array_equal(finals[0][1], finals[1][1])
+
+
+def test_deviates_drawn_on_the_device():
+    """A seeded run (the integrator draws its own deviates: Philox4x32-10 + Box-Muller on (seed, configuration, atom,
+    component)): standard normal to sampling accuracy; the host loop fed the SAME deviates (SGPRModel.md_deviates)
+    reproduces it bit for bit; and the trajectory does not depend on how the run is cut into calls."""
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS, langevin_nvt
+    mdl, (numbers, pos, cell, pbc) = _model()
+    N = len(numbers)
+    mass = np.array([MASS[int(z)] for z in numbers])
+    vel = np.random.default_rng(2).normal(size=(N, 3)) * np.sqrt(kB * 600.0 / mass[:, None])
+    steps = 40
+
+    def run(cuts):
+        mdl.md_begin(numbers, pos, cell, pbc, mass, vel, dt=FS, friction=0.05, kT=kB * 600.0, seed=77)
+        out = []
+        for k, n in enumerate(cuts):
+            sc, code = mdl.md_run(n, None, final=(k == len(cuts) - 1))
+            assert code == 0 and len(sc) == n
+            out.append(sc)
+        return np.concatenate(out), mdl.md_state(results=True)
+
+    sc_a, st_a = run([steps + 1])
+    xi = mdl.md_deviates(0, steps)
+    n = xi.size   # 61440 deviates: four standard errors of each moment
+    assert abs(xi.mean()) < 4.0 / np.sqrt(n) and abs(xi.std() - 1.0) < 4.0 / np.sqrt(2 * n) and abs((xi ** 3).mean()) < 4.0 * np.sqrt(6.0 / n)
+    assert abs((xi ** 4).mean() - 3.0) < 4.0 * np.sqrt(96.0 / n) and np.abs(np.corrcoef(xi[:-1].ravel(), xi[1:].ravel())[0, 1]) < 4.0 / np.sqrt(n)
+    assert np.abs(xi).max() > 3.5    # (the tails are there)
+    assert not np.array_equal(xi, mdl.md_deviates(1, steps))      # (the counter matters)
+    sc_b, st_b = run([7, 1, 16, 17])                                # 41 evaluations in four calls
+    assert np.array_equal(sc_a[:, :13], sc_b[:, :13])
+    assert np.array_equal(st_a["positions"], st_b["positions"]) and np.array_equal(st_a["velocities"], st_b["velocities"])
+
+    class Rows:   # a Generator stand-in that deals the device's rows to the host loop
+        def __init__(self):
+            self.k = 0
+
+        def normal(self, size):
+            self.k += 1
+            return xi[self.k - 1]
+
+    calc = _PredictCalc(mdl)
+    host = [(s, E, T, w, p.copy(), v.copy()) for s, E, T, w, p, v in
+            langevin_nvt(calc, numbers, pos, cell, pbc, steps, 600.0, 1.0, 0.05, vel=vel, rng=Rows())]
+    assert [h[1] for h in host] == sc_a[:, 0].tolist()
+    assert np.array_equal(host[-1][4], st_a["positions"]) and np.array_equal(host[-1][5], st_a["velocities"])
+    mdl.close()
