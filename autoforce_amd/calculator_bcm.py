@@ -20,11 +20,19 @@ from .posterior import PosteriorPotential
 
 
 class BCMActiveCalculator(ActiveCalculator):
-    def __init__(self, covariance=None, kernel_model_dict=None, pckl=None, tape=None, member_engine=None, **kw):
+    def __init__(self, covariance=None, kernel_model_dict=None, pckl=None, tape=None, member_engine=None,
+                 members_over_ranks=False, **kw):
         """kernel_model_dict: {key: SGPRModel | PosteriorPotential | path of a saved model}: the frozen
         members.  pckl / tape: *heads*; the live model uses `<head>_<id>.npz` / `<head>_<id>.sgpr`
         (active_bcm.py:263-301).  member_engine: test hook — callable returning an empty engine for members
-        loaded from disk."""
+        loaded from disk.
+        members_over_ranks (with a process_group): ONE MEMBER PER RANK instead of every member sharded over all
+        ranks — member k (the live model last) is evaluated, unsharded, by rank k mod world on its own GPU; the
+        ranks exchange the members' weights (one tiny all-reduce), their weighted sums (one packed all-reduce of
+        [F | E | stress], as the sharded path's) and the member-wise minimum covloss (one MIN all-reduce).  The
+        members are independent models (active_bcm.py:589-633 loops over them): a committee of G members on G GPUs
+        costs one member's step, where sharding each 4096-atom member eight ways gains 1.4x."""
+        self.members_over_ranks = bool(members_over_ranks)
         self.model_dict = {}
         fresh = (lambda: member_engine()) if member_engine else (lambda: None)
         for key, mdl in (kernel_model_dict or {}).items():
@@ -83,7 +91,77 @@ class BCMActiveCalculator(ActiveCalculator):
         b = -np.log(covmax) if covmax < 1.0 else 0.0
         return (b / covmax if covmax > 0.0 else inf), covmax
 
+    def _whole(self, engine):
+        """One UNSHARDED pass of `engine` over the current atoms, whatever the process group says."""
+        numbers, positions, cell, pbc = self._system(self.atoms)
+        N = len(numbers)
+        if not (engine.m > 0 and engine.mu is not None):
+            return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf), ready=False)
+        out = engine.predict(numbers, positions, cell, pbc, rank=0, world=1, cov=False, beta=True)
+        out["ready"] = True
+        return out
+
+    def _update_results_over_ranks(self, covloss_only):
+        """members_over_ranks: this rank evaluates the members it owns; the committee is combined across ranks."""
+        import torch.distributed as dist
+        rank, world = self._dist()
+        keys = list(self.model_dict.keys())
+        engines = [self.model_dict[k].engine for k in keys] + [self.engine]
+        K, N = len(engines), len(self.atoms)
+        mine = [k for k in range(K) if k % world == rank]
+        outs = {k: self._whole(engines[k]) for k in mine}
+        # 1. every member's weight (and whether it has a model at all): each rank fills in its own
+        sc = np.zeros(2 * K)
+        for k, o in outs.items():
+            s_k = self._scale(o["beta"])[0]
+            sc[k] = 1e300 if np.isinf(s_k) else s_k       # (inf does not survive a SUM of zeros and itself on every backend)
+            sc[K + k] = 1.0 if o["ready"] else 0.0
+        t = self._tensor(sc)
+        dist.all_reduce(t, group=self.process_group)
+        sc = t.cpu().numpy()
+        scales = np.where(sc[:K] >= 1e300, inf, sc[:K])
+        w = np.where(sc[K:] > 0.5, scales, 0.0)
+        if np.isinf(w).any():
+            w = np.isinf(w).astype(float)
+        if w.sum() <= 0.0:
+            w = np.zeros(K)
+            w[-1] = 1.0
+        w = w / w.sum()
+        self.bcm_weights = dict(zip(keys + ["live"], w.tolist()))
+        # 2. the member-wise minimum of the covlosses (active_bcm.py:885-894)
+        b = np.full(N, inf)
+        for o in outs.values():
+            b = np.minimum(b, o["beta"])
+        tb = self._tensor(np.where(np.isinf(b), 1e300, b))
+        dist.all_reduce(tb, op=dist.ReduceOp.MIN, group=self.process_group)
+        b = tb.cpu().numpy()
+        self._beta = np.where(b >= 1e300, inf, b)
+        self._member_beta = {}     # (get_covloss() returns _beta: already the total)
+        self._cov = None
+        self._nl = None
+        if covloss_only:
+            return
+        # 3. the weighted sums, one packed buffer (the same collective as a sharded step's)
+        v = np.zeros(3 * N + 7)
+        for k, o in outs.items():
+            if w[k] != 0.0:
+                v[:3 * N] += w[k] * np.asarray(o["forces"], float).reshape(-1)
+                v[3 * N] += w[k] * o["energy"]
+                v[3 * N + 1:] += w[k] * np.asarray(o["stress"], float)
+        tv = self._tensor(v)
+        dist.all_reduce(tv, group=self.process_group)
+        v = tv.cpu().numpy()
+        self._set_results(dict(energy=float(v[3 * N]), forces=v[:3 * N].reshape(N, 3).copy(), stress=v[3 * N + 1:].copy()))
+
+    def local(self, k):
+        if self.members_over_ranks and self._dist()[1] > 1:
+            # (no rank's sharded list to ask: the frame's list is built here, unsharded, on the live engine)
+            return self._locals_of(*self._system(self.atoms), indices=[k])[0]
+        return super().local(k)
+
     def update_results(self, retain_graph=False, covloss_only=False):
+        if self.members_over_ranks and self._dist()[1] > 1:
+            return self._update_results_over_ranks(covloss_only)
         live = self._evaluate_engine(self.engine)
         self._cov = None
         self._nl = None

@@ -439,3 +439,70 @@ def test_hyperparameter_search_against_the_reference():
     g = load("g5_big40")
     ac.check_g14_hpo(OracleModel(int(g["lmax"]), int(g["nmax"]), float(g["eta"]), float(g["rc"]),
                                  species=g["species"].tolist()))
+
+
+def _bcm_worker(rank, world, port, tmp, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch.distributed as dist
+    from autoforce_amd.ase_shim import Atoms as A
+    from autoforce_amd.calculator_bcm import BCMActiveCalculator
+    from autoforce_amd.modelio import load_model
+    from helpers import OracleModel as OM
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = lambda: OM(3, 3, 4, 4.5, species=[3, 9])  # noqa: E731
+    members = {k: load_model(os.path.join(tmp, f"{k}.npz"), engine=eng()) for k in ("a", "b")}
+    live = load_model(os.path.join(tmp, "c.npz"), engine=eng())
+    bcm = BCMActiveCalculator(covariance=live, kernel_model_dict=members, logfile=None, process_group=dist.group.WORLD,
+                              members_over_ranks=True)
+    fr = np.load(os.path.join(tmp, "frame.npz"))
+    at = A(fr["numbers"], fr["positions"], fr["cell"], True)
+    at.calc = bcm
+    calls0 = [m.engine.calls for m in members.values()] + [live.engine.calls]
+    e, f, s = at.get_potential_energy(), at.get_forces(), at.get_stress()
+    calls = [m.engine.calls - c for m, c in zip(list(members.values()) + [live], calls0)]
+    q.put((rank, e, f, s, bcm.get_covloss().copy(), dict(bcm.bcm_weights), calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bcm_one_member_per_rank_world2_gloo(tmp_path):
+    """members_over_ranks: three members on two ranks, every member evaluated by ONE rank, unsharded; energies, forces,
+    stress, weights and the member-wise minimum covloss equal the single-process committee's on every rank."""
+    import torch.multiprocessing as mp
+    from autoforce_amd.calculator_bcm import BCMActiveCalculator
+    from autoforce_amd.modelio import save_model
+    calcs = []
+    for k, seed in (("a", 0), ("b", 3), ("c", 5)):
+        (tmp_path / k).mkdir()
+        c, teacher, tr = ac.run(engine(), tmp_path / k, steps=3, seed=seed, tape=False)
+        save_model(str(tmp_path / f"{k}.npz"), c.model)
+        calcs.append((c, tr))
+    at = calcs[0][1][-1][5]
+    np.savez(tmp_path / "frame.npz", numbers=at.numbers, positions=at.positions, cell=at.cell)
+    ref = BCMActiveCalculator(covariance=calcs[2][0].model, kernel_model_dict={"a": calcs[0][0].model, "b": calcs[1][0].model},
+                              logfile=None)
+    p = Atoms(at.numbers, at.positions, at.cell, True)
+    p.calc = ref
+    e0, f0, s0 = p.get_potential_energy(), p.get_forces(), p.get_stress()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 91) % 500)
+    procs = [ctx.Process(target=_bcm_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank, e, f, s, beta, w, calls in got:
+        assert abs(e - e0) < 1e-10
+        np.testing.assert_allclose(f, f0, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(s, s0, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(beta, ref.get_covloss_total(), rtol=0, atol=1e-12)
+        assert set(w) == set(ref.bcm_weights) and all(abs(w[k] - ref.bcm_weights[k]) < 1e-12 for k in w)
+        # members a, c (indices 0, 2) on rank 0, member b on rank 1: nobody evaluates somebody else's member
+        assert [c > 0 for c in calls] == ([True, False, True] if rank == 0 else [False, True, False]), (rank, calls)
