@@ -665,41 +665,56 @@ class ActiveCalculator(Calculator):
         self.log(f"added {added} randomly displaced LCEs")
 
     # ------------------------------------------------------------------ the sampling rules
+    # The sampling rules of active.py:806-984 as DATA: what to do with an environment is a function of where its covloss
+    # sits relative to the two thresholds and of how many inducing LCEs its species already has.
+    #   band     covloss >= ediff_ub          ediff_lb <= covloss < ediff_ub        covloss < ediff_lb
+    #   m >= 2   take it (+1)                 trial against ediff                   leave it
+    #   m < 2    take it, flag blind (-1)     trial against EPS (any change)        take it if covloss > EPS (-1)
+    # "take" = add_inducing; "trial" = add_1inducing (add, refit, keep only if the predictions moved by the threshold).
+    _TAKE, _TRIAL, _LEAVE = "take", "trial", "leave"
+
+    def _lce_rule(self, beta, m):
+        """(action, code reported when the LCE is kept, trial threshold) for a covloss and an inducing count."""
+        scarce = m < 2
+        if beta >= self.ediff_ub:
+            return self._TAKE, (-1 if scarce else 1), None
+        if beta >= self.ediff_lb:
+            return self._TRIAL, None, (EPS if scarce else self.ediff)
+        if scarce and beta > EPS:
+            return self._TAKE, -1, None
+        return self._LEAVE, 0, None
+
+    def _covloss_of(self, loc):
+        """Covloss of an environment that is not an atom of the current frame (active.py:809-818)."""
+        if not (self.engine.m > 0 and self.model.choli is not None):
+            return inf
+        k, _ = self.engine.kernel_local(loc)
+        proj = self.model.choli @ k
+        with np.errstate(invalid="ignore"):
+            return np.sqrt(np.maximum((1.0 - proj @ proj) * self.model._vscale.get(loc.number, inf), 0.0))
+
     def update_lce(self, loc, beta=None):
-        """active.py:806-839."""
+        """active.py:806-839: returns +1 / -1 (kept; -1: its species was short of inducing LCEs — "blind") or 0."""
         if loc.number not in self.engine.species:
             return 0
-        if beta is None:
-            if self.engine.m > 0 and self.model.choli is not None:
-                k, _ = self.engine.kernel_local(loc)
-                b = self.model.choli @ k
-                vscale = self.model._vscale.get(loc.number, inf)
-                with np.errstate(invalid="ignore"):
-                    beta = np.sqrt(np.maximum((1.0 - b @ b) * vscale, 0.0))
-            else:
-                beta = inf
-        added = 0
-        m = self.model.indu_counts[loc.number]
-        if beta >= self.ediff_ub:
+        beta = self._covloss_of(loc) if beta is None else beta
+        action, code, threshold = self._lce_rule(beta, self.model.indu_counts[loc.number])
+        if action == self._LEAVE:
+            return 0
+        if action == self._TAKE:
             self.model.add_inducing(loc)
-            added = -1 if m < 2 else 1
-        elif beta < self.ediff_lb:
-            if m < 2 and beta > EPS:
-                self.model.add_inducing(loc)
-                added = -1
         else:
-            ediff = self.ediff if m > 1 else EPS
-            added, _ = self.model.add_1inducing(loc, ediff)
-        if added != 0:
-            if self.model.ridge > 0.0:
-                self.model.pop_1inducing()
-                added = 0
-            else:
-                if self.tape:
-                    self.tape.write(loc)
-                if self.ioptim == 0:
-                    self.optimize()
-        return added
+            code, _ = self.model.add_1inducing(loc, threshold)
+            if code == 0:
+                return 0
+        if self.model.ridge > 0.0:          # the new LCE made K_mm need a jitter: not worth having (active.py:829-831)
+            self.model.pop_1inducing()
+            return 0
+        if self.tape:
+            self.tape.write(loc)
+        if self.ioptim == 0:
+            self.optimize()
+        return code
 
     def _largest_covloss(self, beta, chosen):
         """The first atom in descending order of covloss that is neither chosen nor ignored (active.py:851-856 walks
@@ -749,71 +764,87 @@ class ActiveCalculator(Calculator):
         self.covlog = f"{float(np.max(self.get_covloss()))}"
         return added
 
-    def update_data(self, try_fake=True, internal=False, save_model=True):
-        """active.py:887-933."""
-        if self.tune_for_md and len(self.model.data) > 2:
-            last = self.model.data[-1]
-            if last.natoms == len(self.atoms) and (last.numbers == self.atoms.numbers).all() and \
-                    (np.abs(last.positions - self.atoms.positions) < self.eps_dr).all():
-                return 0
-        n = self.model.ndata
-        new = self.snapshot(fake=try_fake)
-        _, de, df = self.model.add_1atoms_fast(new, self.ediff_tot, self.fdiff)
-        added = self.model.ndata - n
-        self.log(f"DF: {df}  accept: {added}")
-        if added > 0:
-            if try_fake:
-                self.head()
-            if self.tape and self._saved_for_tape is not None:
-                self.tape.write(self._saved_for_tape)
-                self._saved_for_tape = None
-            self.log("added data: {} -> size: {} {}".format(added, *self.size))
-            if self.ioptim in (0, 2):
+    def _same_as_last_datum(self):
+        """tune_for_md (active.py:888-897): the frame has barely moved since the newest datum."""
+        if not (self.tune_for_md and len(self.model.data) > 2):
+            return False
+        last = self.model.data[-1]
+        return (last.natoms == len(self.atoms) and bool((last.numbers == self.atoms.numbers).all())
+                and bool((np.abs(last.positions - self.atoms.positions) < self.eps_dr).all()))
+
+    def _optimize_after_data(self):
+        """ioptim: 0 / 2 refit the hyper-parameters after every datum, k > 2 after every (k - 1)-th (active.py:919-926)."""
+        if self.ioptim in (0, 2):
+            self.optimize()
+        elif self.ioptim > 2:
+            self._ioptim = (self._ioptim + 1) % (self.ioptim - 1)
+            if self._ioptim == 0:
                 self.optimize()
-            elif self.ioptim > 2:
-                self._ioptim += 1
-                if self._ioptim % (self.ioptim - 1) == 0:
-                    self.optimize()
-                    self._ioptim = 0
-            if save_model:
-                self.save_model()
+
+    def update_data(self, try_fake=True, internal=False, save_model=True):
+        """active.py:887-933: offer the current frame as a datum — with the model's own predictions as labels first
+        (try_fake), exact ones once it is accepted.  Returns the number of data added (0 or 1)."""
+        if self._same_as_last_datum():
+            return 0
+        before = self.model.ndata
+        _, de, df = self.model.add_1atoms_fast(self.snapshot(fake=try_fake), self.ediff_tot, self.fdiff)
+        added = self.model.ndata - before
+        self.log(f"DF: {df}  accept: {added}")
+        if added <= 0:
+            return added
+        if try_fake:
+            self.head()
+        if self.tape and self._saved_for_tape is not None:
+            self.tape.write(self._saved_for_tape)
+            self._saved_for_tape = None
+        self.log("added data: {} -> size: {} {}".format(added, *self.size))
+        self._optimize_after_data()
+        if save_model:
+            self.save_model()
         return added
 
     def optimize(self):
         self.model.make_munu(algo=3, noise_f=self.noise_f)  # active.py:939-940
 
+    def _wants_data(self, n_lces, inducing, data):
+        """Is the frame offered as a datum?  After new LCEs (if data sampling is on); and when only data are sampled
+        (include_tape), whenever some covloss is still above ediff (active.py:947-951)."""
+        if inducing:
+            return n_lces > 0 and data
+        return bool(np.max(self.get_covloss()) > self.ediff)
+
+    def _after_model_change(self):
+        """Size limits, the refit that goes with them, the three log lines, the model file (active.py:961-981)."""
+        # (ioptim == 1: optimize() below refits the downsized model from the same matrix — hyper-parameter search
+        # and weights — so the refit downsize would end with is the one result nobody reads)
+        if any(self.model.downsize(self.max_data, self.max_inducing, first=True, lii=True, remake=self.ioptim != 1)):
+            self.log("downsized -> size: {} {}".format(*self.size))
+        if self.ioptim == 1:
+            self.optimize()
+        self.log("fit error (mean,mae): E: {:.2g} {:.2g}   F: {:.2g} {:.2g}   R2: {:.4g}".format(
+            *(float(v) for v in self.model._stats)))
+        self.log(f"noise: {self.model.scaled_noise}")
+        self.log(f"mean: {self.model.mean}")
+        self.save_model()
+        self.updated = True
+
     def update(self, inducing=True, data=True):
-        """active.py:942-984."""
-        self.updated = False
-        self.blind = False
-        m = self.update_inducing() if inducing else 0
-        try_real = self.blind or isinstance(self._calc, SinglePointCalculator)
-        update_data = (m > 0 and data) or not inducing
-        if update_data and not inducing:  # include_tape
-            update_data = np.max(self.get_covloss()) > self.ediff
-        n = self.update_data(try_fake=not try_real, internal=True, save_model=False) if update_data else 0
-        if self.step == 0 and self.step0_forced_fp and data and n == 0:
+        """active.py:942-984: sample LCEs, then (maybe) the frame; returns (LCEs added, data added)."""
+        self.updated = self.blind = False
+        n_lces = self.update_inducing() if inducing else 0
+        n_data = 0
+        if self._wants_data(n_lces, inducing, data):
+            exact_labels = self.blind or isinstance(self._calc, SinglePointCalculator)
+            n_data = self.update_data(try_fake=not exact_labels, internal=True, save_model=False)
+        if n_data == 0 and data and self.step == 0 and self.step0_forced_fp:
             self.log("forced data addition")
             self.model.add_data([self.snapshot()])
             self.log("added data: {} -> size: {} {}".format(1, *self.size))
-            n = 1
-        if m > 0 or n > 0:
-            # (ioptim == 1: optimize() below refits the downsized model from the same matrix — hyper-parameter search
-            # and weights — so the refit downsize would end with is the one result nobody reads)
-            ch1, ch2 = self.model.downsize(self.max_data, self.max_inducing, first=True, lii=True,
-                                           remake=self.ioptim != 1)
-            if ch1 or ch2:
-                self.log("downsized -> size: {} {}".format(*self.size))
-            if self.ioptim == 1:
-                self.optimize()
-            self.log("fit error (mean,mae): E: {:.2g} {:.2g}   F: {:.2g} {:.2g}   R2: {:.4g}".format(
-                *(float(v) for v in self.model._stats)))
-            self.log(f"noise: {self.model.scaled_noise}")
-            self.log(f"mean: {self.model.mean}")
-            self.save_model()
-            self.updated = True
+            n_data = 1
+        if n_lces > 0 or n_data > 0:
+            self._after_model_change()
         self._update_args = {}
-        return m, n
+        return n_lces, n_data
 
     def save_model(self):
         if self.pckl and self.rank == 0:

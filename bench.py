@@ -305,17 +305,20 @@ def main():
         for _ in range(max(args.warmup, 2)):
             step()
         _lib.check(lib.sgpr_sync_check(h, sp))
-        # ... and on until the step time has settled: batches of 20 steps until three in a row agree within 2 % (clocks,
-        # caches and the first list rebuilds of a fresh process take tens of steps; --warmup is the minimum).  Every rank
-        # runs the same number of batches (the decision is rank 0's).
-        for _ in range(40):
+        # ... and on until the step time has settled (clocks, caches and the first list rebuilds of a fresh process take
+        # tens of steps; --warmup is the minimum).  Every rank runs the same number of batches (the decision is rank 0's).
+        for _ in range(80):
             torch.cuda.synchronize(dev)
             tb = time.perf_counter()
             for _ in range(20):
                 step()
             torch.cuda.synchronize(dev)
             warm_batches.append((time.perf_counter() - tb) / 20)
-            stop = len(warm_batches) >= 3 and max(warm_batches[-3:]) <= 1.02 * min(warm_batches[-3:])
+            # (at least ten batches — the clock of a fresh process keeps rising for some 150 steps, slowly enough for three
+            # batches in a row to agree long before it has settled; then three within 1.5 % of each other, none of them more
+            # than 1.5 % above the fastest batch so far)
+            stop = (len(warm_batches) >= 10 and max(warm_batches[-3:]) <= 1.015 * min(warm_batches[-3:])
+                    and max(warm_batches[-3:]) <= 1.015 * min(warm_batches))
             if world > 1:
                 t = torch.tensor([1 if stop else 0])
                 dist.broadcast(t, src=0)

@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"]
 # an update = a stretch between two finalize_gather kernels that contains a rows16_kernel with many chunks (long one)
-fg = [i for i, r in enumerate(rows) if "finalize_gather" in name(r)]
+fg = [i for i, r in enumerate(rows) if "finalize_gather" in name(r) or "finalize_next" in name(r)]
 best = None
 for a, b in zip(fg, fg[1:]):
     seg = rows[a + 1:b + 1]
