@@ -286,6 +286,17 @@ __device__ __forceinline__ double inv_unit_of(const DescArgs &a, int s)
     return u;
 }
 
+// Species slots in use.  The default instantiations (lmax = nmax = 3, up to four slots) are dispatched one per species
+// count (DISPATCH_LNS: st_of(S) = S), so there the count is a COMPILE-TIME constant: the loops over species and channels
+// unroll and the `v < channels` guards fold away — they were scalar branches around single LDS reads (a third of the
+// instruction stream of the reverse kernel was scalar: profiles/r03_pmc_sq_summary.txt).
+template <int LMAX, int NMAX, int ST>
+__device__ __forceinline__ int species_in_use(const DescArgs &a)
+{
+    if constexpr (LMAX == 3 && NMAX == 3 && ST <= 4) return ST;
+    else return a.S;
+}
+
 // neighbour t of atom (global sorted index gi / local index ia): displacement, species slot
 template <bool ENV>
 __device__ __forceinline__ void load_neighbor(const DescArgs &a, int gi, int ia, int t, const double *pi,
@@ -1027,7 +1038,7 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
     // c for the reverse pass goes out from LDS, lane = consecutive entry: in the accumulator layout neighbouring lanes
     // hold neighbouring CHANNELS (16 doubles apart in memory) and every store instruction touched 64 cache lines
     if (a.C)
-        for (int idx = lane; idx < a.S * NSLOT; idx += 64)
+        for (int idx = lane; idx < species_in_use<LMAX, NMAX, ST>(a) * NSLOT; idx += 64)
             a.C[(size_t)ia * a.CS + idx] = cl[PMF ? (idx / LL) * CLS + idx % LL : idx];
     // packed power spectrum: entry e = pair(u<=v)*L1 + l : coef * sum_{lm in l} c[u][lm] c[v][lm].
     double nrm2 = 0.0;
@@ -1039,7 +1050,7 @@ __global__ __launch_bounds__(256, 4) void nl_fwd_kernel(DescArgs a, NlArgs n)
         // of c (64 reads per lane with two pairs: every wave of the CU does this at the same moment and LDS bytes bound it).
         // The lane gets P_l[u = (lane >> 4) + 4 r][v = lane & 15] and keeps u <= v < U; the coefficient of the entry is
         // requested first (its address depends on the lane only).
-        const int Ur = a.S * N1, vch = lane & 15;
+        const int Ur = species_in_use<LMAX, NMAX, ST>(a) * N1, vch = lane & 15;
         double cf[L1][4];
         int eidx[4];
 #pragma unroll
@@ -1181,6 +1192,7 @@ template <int LMAX, int NMAX, int ST, bool GATHER, bool ROWS, bool COV = false>
 __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs gc, int n_cov)
 {
     extern __shared__ double smem[];
+    const int S_use = species_in_use<LMAX, NMAX, ST>(a);
     if constexpr (COV) {
         if ((int)blockIdx.x < n_cov) {
             using GL = GemmLds<EPI_ROWSQ, 1, 16>;
@@ -1251,7 +1263,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
 #pragma unroll
             for (int k = 0; k < SPL; k++) {
                 const int slot = lane + 64 * k;
-                cv_h[s * SPL + k] = (active && s < a.S && (SPL * 64 == NSLOT || slot < NSLOT)) ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+                cv_h[s * SPL + k] = (active && s < S_use && (SPL * 64 == NSLOT || slot < NSLOT)) ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
             }
     }
     if (nn > 0) {
@@ -1261,7 +1273,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
             for (int k = lane; k < ST * NSLOT; k += 64) dcl[k] = 0.0;
             zero_dc = true;
         } else {
-            const int Ur = a.S * N1;  // channels of the packed layout (pack table built with the real S)
+            const int Ur = S_use * N1;  // channels of the packed layout (pack table built with the real S)
             // Up to 4 species the packed gradient is expanded into the full symmetric [u][v][l] array in
             // LDS (stride-1 addressing in the contraction); 8 slots keep the packed form.
             constexpr bool EXPAND = ST <= 4;
@@ -1330,7 +1342,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
                     for (int k = 0; k < SPL; k++) {
                         const int slot = lane + 64 * k;
                         if (SPL * 64 == NSLOT || slot < NSLOT)
-                            cl[s * NSLOT + slot] = s < a.S ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
+                            cl[s * NSLOT + slot] = s < S_use ? a.C[(size_t)ia * a.CS + s * NSLOT + slot] : 0.0;
                     }
             }
             wave_sync();
@@ -1352,7 +1364,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
                     const int slot = lane + 64 * k;
                     if (SPL * 64 == NSLOT || slot < NSLOT) {
                         double d = 0.0;
-                        if (s < a.S) {
+                        if (s < S_use) {
                             const int n = slot / LL, lm = slot % LL;
                             int l = 0;
 #pragma unroll
@@ -1474,7 +1486,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
 #pragma unroll
                     for (int rb = 0; rb < RB; rb++) {
                         v4d D = (v4d){0.0, 0.0, 0.0, 0.0};
-                        for (int sp = 0; sp < a.S; sp++) {
+                        for (int sp = 0; sp < S_use; sp++) {
                             if (__ballot(sr[rb] == sp) == 0ull) continue;
 #pragma unroll
                             for (int ks = 0; ks < KS; ks++) {
