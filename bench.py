@@ -356,14 +356,15 @@ def main():
     # ---- per-kernel durations: HIP events on the launch stream, same steps run eagerly
     mdl.profile(True)
     acc = {}
-    nprof = min(args.steps, 50)
+    nprof = max(min(args.steps, 50), 30)
     for _ in range(nprof):
         step()
         torch.cuda.synchronize(dev)
         for k, v in mdl.stage_times().items():
-            acc[k] = acc.get(k, 0.0) + v
+            acc.setdefault(k, []).append(v)
     mdl.profile(False)
-    stage_ms = {k: v / nprof for k, v in acc.items()}
+    # (medians: one stalled launch in fifty — a rebuild step, a clock change — would otherwise sit in the mean of its stage)
+    stage_ms = {k: float(np.median(v)) for k, v in acc.items() if len(v) >= nprof // 2}
     # An event-to-event interval holds one launch's marker/dispatch overhead besides the kernel.
     # Calibration: the same steps without the markers (and without the collective) take t_plain;
     # the markers therefore cost (sum of intervals - t_plain) / n_stages per stage.
