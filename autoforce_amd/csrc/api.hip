@@ -627,6 +627,98 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
     }
 }
 
+// scatter form with the next frame named (sharded steps over resident frames, FinNext mode 1): thread w packs sorted
+// atom w as finalize_kernel does — and clears what the binning kernel would clear for the next step: its fixed-point
+// force sums, its covloss partials — and bins CALLER atom w of the next frame (finalize_next_kernel<1>'s second job).
+// Every rank bins all atoms, as every rank's stand-alone binning launch did: one launch less per rank and step.
+__global__ __launch_bounds__(256) void finalize_scatter_next_kernel(FinArgs f)
+{
+    const int tid = threadIdx.x, b = blockIdx.x, nA = gridDim.x - 11;
+    if (b >= nA) { finalize_reduce(f, b - nA); return; }
+    const FinNext &x = f.nx;
+    const int i = b * 256 + tid, s1 = x.step + 1;
+    const bool act = i < f.N;
+    const int ia = act ? i : 0;
+    // requests (unconditional, see finalize_next_kernel)
+    const int rebuilt = *f.flag;
+    const NlGrid g = *f.grid;
+    const int c = f.perm[ia], slot_i = f.slot[ia], ib = x.iperm[ia], slot_b = x.cslot[ia];
+    long long fn[3];
+    double fsv[3], xn[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        fn[k] = ((const long long *)f.Fnbr)[3 * (size_t)ia + k];
+        fsv[k] = f.Fself[3 * (size_t)ia + k];
+        xn[k] = x.pos_in[3 * (size_t)ia + k];
+    }
+    const int il = (ia - f.first) / f.stride;
+    const bool mine = f.has_beta && act && ia >= f.first && (ia - f.first) % f.stride == 0 && il < f.cnt;
+    double cs = 0.0;
+    if (mine)
+        for (int k = 0; k < f.csq_slots; k++) cs += f.csq[(size_t)il * f.csq_slots + k];
+    double xc[3], p0[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { xc[k] = x.pos[3 * (size_t)ib + k]; p0[k] = f.pos0[3 * (size_t)ib + k]; }
+    const double vs = mine ? f.vs_sqrt[slot_i < x.S ? slot_i : 0] : 0.0;
+    for (int k = i; k < f.nbins_clear; k += nA * 256) x.bc_cur[(size_t)k * SGPR_BIN_STRIDE] = 0;
+    if (i == 0) {
+        if (x.force) atomicMax(&x.flags[s1 & 3], 1);
+        x.flags[(s1 + 2) & 3] = 0;
+    }
+    if (!act) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        f.packed[3 * (size_t)c + k] = (double)fn[k] * (1.0 / SGPR_FIX_SCALE) + fsv[k];
+        ((long long *)f.Fnbr)[3 * (size_t)i + k] = 0;
+    }
+    if (mine)
+        for (int k = 0; k < f.csq_slots; k++) x.csq_rw[(size_t)il * f.csq_slots + k] = 0.0;
+    const double v = 1.0 - cs;
+    f.packed[3 * (size_t)f.N + c] = mine ? sqrt(v > 0.0 ? v : 0.0) * vs : 0.0;
+    // ---- the next frame's atom w
+    int bidx[3], w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double fr = xn[0] * g.inv[k] + xn[1] * g.inv[3 + k] + xn[2] * g.inv[6 + k];
+        w[k] = 0;
+        bidx[k] = 0;
+        if (x.pbc[k] && (g.inv[k] != 0.0 || g.inv[3 + k] != 0.0 || g.inv[6 + k] != 0.0)) {
+            const double fl = floor(fr);
+            w[k] = (int)fl;
+            fr -= fl;
+            const int bb = (int)(fr * g.nb[k]);
+            bidx[k] = bb >= g.nb[k] ? g.nb[k] - 1 : (bb < 0 ? 0 : bb);
+        }
+    }
+    const int bin = (bidx[0] * g.nb[1] + bidx[1]) * g.nb[2] + bidx[2];
+    int kb = -1;
+    if (slot_b < x.S) kb = atomicAdd(&x.bc_next[(size_t)bin * SGPR_BIN_STRIDE], 1);
+    double d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double q0 = rebuilt ? xc[k] : p0[k];
+        d2 += (xn[k] - q0) * (xn[k] - q0);
+        x.pos[3 * (size_t)ib + k] = xn[k];
+        if (rebuilt) f.pos0[3 * (size_t)ib + k] = xc[k];
+    }
+    if (!(d2 <= x.thr2)) atomicMax(&x.flags[s1 & 3], 1);
+    x.bin_of[ib] = bin;
+    x.kslot[ib] = kb;
+    if (slot_b < x.S) {
+        if (max(max(abs(w[0]), abs(w[1])), abs(w[2])) > 32767) atomicMax(&f.stat[3], 1);
+        if (kb < x.cap) {
+            const size_t e = (size_t)bin * x.cap + kb;
+            BinRec r;
+            r.x = xn[0]; r.y = xn[1]; r.z = xn[2]; r.idx = ib; r.pad = 0;
+            x.b_rec[e] = r;
+            BinAux ax;
+            ax.w0 = (short)w[0]; ax.w1 = (short)w[1]; ax.w2 = (short)w[2]; ax.slot = (short)slot_b;
+            x.b_aux[e] = ax;
+        } else
+            atomicMax(&f.stat[1], kb + 1);
+    }
+}
+
 // gather form: one wave per atom i,  F_i = (sum_t g_it, kept by the reverse kernel) - sum_t' G[i][t']
 // where G[i][t'] is the gradient of the pair (j_t' -> i), stored at i's own list position by the
 // reverse kernel: one coalesced row per wave, fixed shuffle tree: reproducible.
@@ -1806,7 +1898,10 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
         x.bin_of = h->d_bin_of.p; x.kslot = h->d_kslot.p; x.b_rec = h->d_b_rec.p; x.b_aux = h->d_b_aux.p;
         x.csq_rw = h->d_csq.p;
         const dim3 grid((std::max(N, 1) + 3) / 4 + 13);
-        if (nx->mode == 1) hipLaunchKernelGGL(finalize_next_kernel<1>, grid, dim3(256), 0, st, f);
+        if (!gather) {
+            x.csq_rw = h->d_csq.p;
+            hipLaunchKernelGGL(finalize_scatter_next_kernel, dim3((std::max(N, 1) + 255) / 256 + 11), dim3(256), 0, st, f);
+        } else if (nx->mode == 1) hipLaunchKernelGGL(finalize_next_kernel<1>, grid, dim3(256), 0, st, f);
         else hipLaunchKernelGGL(finalize_next_kernel<2>, grid, dim3(256), 0, st, f);
         return;
     }
@@ -1934,7 +2029,10 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     if (forked) (void)hipStreamWaitEvent(st, h->ev_join, 0);
     // the last kernel also opens the next step when the caller has said where the next positions are (same cell), the frame
     // is not sharded and nothing of the step ran on a side stream
-    const bool fuse = nx && nx->mode && h->fuse_next && gather && predict && !forked && !h->use_graph && h->comm == nullptr && h->skin > 0.0;
+    // (frames: also the scatter form of a sharded rank, whose all-reduce follows on the same stream; the integrator only in
+    // the single-rank gather form)
+    const bool fuse = nx && nx->mode && h->fuse_next && predict && !forked && !h->use_graph && h->skin > 0.0 &&
+                      ((gather && h->comm == nullptr) || (nx->mode == 1 && !gather && h->world > 1));
     launch_finalize(h, gather && predict, predict ? h->epart_len : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
                     packed_dev, st, nullptr, fuse ? nx : nullptr, step);
     if (fuse) {

@@ -291,7 +291,7 @@ def main():
         # step starts with the list filter (single rank; 5 launches per step instead of 6)
         k = counter[0] % nframes
         counter[0] += 1
-        if world == 1 and args.fuse_next:
+        if args.fuse_next:   # (sharded ranks too: the scatter-form last kernel bins the next frame, the all-reduce follows it)
             _lib.check(lib.sgpr_step_dev_next(h, frame_ptr[k], cell_d.data_ptr(), packed.data_ptr(), frame_ptr[(k + 1) % nframes], sp))
         else:
             _lib.check(lib.sgpr_step_dev(h, frame_ptr[k], cell_d.data_ptr(), packed.data_ptr(), sp))
@@ -566,7 +566,7 @@ def main():
             "config": {
                 "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
-                "packed_row": Dc, "graph": bool(args.graph), "launches_per_step": 5 if (world == 1 and args.fuse_next) else 6,
+                "packed_row": Dc, "graph": bool(args.graph), "launches_per_step": 5 if args.fuse_next else 6,
                 "input": (f"closed Gaussian random walk, sigma {args.walk_sigma} A per component per step, {nframes} frames "
                           f"resident in HBM" if nframes > 1 else "static frame"),
                 "neighbor_skin_A": args.skin,

@@ -291,3 +291,41 @@ def test_deviates_drawn_on_the_device():
     assert [h[1] for h in host] == sc_a[:, 0].tolist()
     assert np.array_equal(host[-1][4], st_a["positions"]) and np.array_equal(host[-1][5], st_a["velocities"])
     mdl.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_frames_with_the_next_step_binned(world):
+    """A sharded rank's step over resident frames (scatter-form reverse pass, fixed-point force sums) with the next
+    frame binned by its last kernel, rank by rank on this one device: every packed partial result bit for bit equal to
+    sgpr_step_dev's, and the partial sums add up to the unsharded step."""
+    import torch
+    from autoforce_amd import _lib
+    mdl, (numbers, pos, cell, pbc) = _model()
+    lib, h = _lib.load(), mdl.handle
+    N = len(numbers)
+    rng = np.random.default_rng(6)
+    frames = [pos]
+    for _ in range(24):
+        frames.append(frames[-1] + 0.015 * rng.normal(size=pos.shape))
+    dev = torch.device("cuda:0")
+    fr = torch.tensor(np.stack(frames), device=dev)
+    cl = torch.tensor(cell, device=dev)
+    plen = 4 * N + 11
+    whole = mdl.predict(numbers, frames[-1], cell, pbc)
+    tot = np.zeros(plen)
+    for r in range(world):
+        mdl.predict(numbers, pos, cell, pbc, rank=r, world=world)   # binds the share, sizes the capacities
+        out = []
+        for use_next in (False, True):
+            o = torch.zeros((len(frames), plen), dtype=torch.float64, device=dev)
+            for k in range(len(frames)):
+                nxt = fr[k + 1].data_ptr() if (use_next and k + 1 < len(frames)) else None
+                _lib.check(lib.sgpr_step_dev_next(h, fr[k].data_ptr(), cl.data_ptr(), o[k].data_ptr(), nxt, None))
+            _lib.check(lib.sgpr_sync_check(h, None))
+            out.append(o.cpu().numpy())
+        assert np.array_equal(out[0], out[1]), (r, np.abs(out[0] - out[1]).max())
+        tot += out[1][-1]
+    fmax = np.abs(whole["forces"]).max()
+    assert np.abs(tot[:3 * N].reshape(N, 3) - whole["forces"]).max() <= 1e-10 * fmax
+    assert abs(tot[4 * N] - whole["energy"]) <= 1e-10 * max(1.0, abs(whole["energy"]))
+    mdl.close()
