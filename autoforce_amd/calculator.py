@@ -421,7 +421,7 @@ class ActiveCalculator(Calculator):
             return EPS
         return float(min(self._ediff_lb.values))
 
-    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256, seed=1):
+    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256, seed=1, sync_every=None):
         """`steps` steps of Langevin NVT (friction = 0: NVE) from atoms.positions / velocities, as cl/md.py:117-128 sets
         it up around this calculator — but the state stays in device memory between model updates: the integrator runs
         inside the step's last kernel (SGPRModel.md_run), the host reads 16 scalars per step and writes the same log
@@ -431,7 +431,9 @@ class ActiveCalculator(Calculator):
         temperature, updated, wall seconds) per step (device steps share the wall time of their batch evenly).  rng: a
         numpy Generator whose normal deviates move the atoms (the stream of workloads.langevin_nvt: the two loops then
         agree bit for bit), or None — the integrator draws its own on the device (counter-based on `seed`: no host
-        generator and no upload on the step's path, same trajectory however the run is batched); atoms.positions / velocities are current at every yield that follows an update
+        generator and no upload on the step's path, same trajectory however the run is batched).  sync_every: steps
+        k = 0 mod sync_every end a batch and atoms.positions / velocities are theirs when they are yielded (a trajectory
+        writer's loginterval, cl/md.py:24); atoms.positions / velocities are current at every yield that follows an update
         and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no."""
         from .ase_shim import kB
         from .workloads import FS, MASS, langevin_nvt
@@ -467,6 +469,8 @@ class ActiveCalculator(Calculator):
         batch = min(8, chunk)   # evaluations per md_run call: grows while nothing halts the device, shrinks back after a halt
         while done <= steps:    # (every call uploads its rows of deviates; a halt throws the unused ones' upload away)
             n = 1 if skip_gate else min(batch, steps + 1 - done)
+            if sync_every and not skip_gate:
+                n = min(n, sync_every - done % sync_every if done % sync_every else 1)   # (… a batch ends on a multiple)
             final = done + n == steps + 1
             need = 0 if on_device_rng else (n - 1 if final else n)
             if len(rows) < need:
@@ -488,6 +492,10 @@ class ActiveCalculator(Calculator):
                 out.append((done, float(r[0]), float(r[12] / (3 * N * kB)), upd, wall))
                 done += 1
             self._log_lines(lines)
+            if sync_every and out and out[-1][0] % sync_every == 0 and code != 1:
+                # the configuration of the batch's last row: the device has moved on to the next one unless the run is over
+                st = eng.md_state(which=0 if final else -1)
+                atoms.positions, atoms._velocities = st["positions"], st["velocities_pre"]
             yield from out
             rows = rows[accepted:]
             batch = min(8, chunk) if code else min(2 * batch, chunk)

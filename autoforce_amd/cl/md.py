@@ -1,0 +1,116 @@
+"""Machine-learning molecular dynamics from the command line — theforce/cl/md.py in this package's terms:
+
+    python -m autoforce_amd.cl.md -i start.xyz -o final.xyz        # keywords from ./ARGS
+
+Langevin dynamics (the reference's `dynamics = 'Langevin'`, cl/md.py:117-128) runs with positions and velocities in
+device memory (ActiveCalculator.run_md); `dynamics = 'NPT'` (cl/md.py:131-166) is ase.md.npt.NPT around the calculator
+and needs ASE.  Structures are read and written as extended XYZ (ASE's own format; without ASE no other reader exists
+here), the trajectory likewise (`trajectory = 'md.xyz'`)."""
+import argparse
+
+import numpy as np
+
+from . import gen_active_calc, get_default_args, read_args, update_args
+from ..ase_shim import kB
+from ..sgprio import Frame, format_extxyz, parse_extxyz
+from ..workloads import MASS
+
+
+def read_structure(path, index=-1):
+    """Frame `index` of an extended-XYZ file."""
+    lines = open(path).read().splitlines()
+    frames, k = [], 0
+    while k < len(lines):
+        if not lines[k].strip():
+            k += 1
+            continue
+        n = int(lines[k].split()[0])
+        frames.append(parse_extxyz(lines[k:k + n + 2]))
+        k += n + 2
+    if not frames:
+        raise ValueError(f"{path}: no frames")
+    return frames[index]
+
+
+def init_velocities(numbers, masses, temperature, rng, cm0=True):
+    """util/aseutil.py:11-20: Maxwell-Boltzmann momenta (ase.md.velocitydistribution: p = xi sqrt(m kB T)), then the
+    centre-of-mass momentum removed (Stationary).  (ZeroRotation is left out for periodic cells, where it has no meaning.)"""
+    xi = rng.standard_normal((len(numbers), 3))
+    p = xi * np.sqrt(masses * kB * temperature)[:, None]
+    if cm0:
+        p -= p.sum(0) * (masses / masses.sum())[:, None]
+    return p / masses[:, None]
+
+
+def manual_steps(atoms, calc, eps, rng):
+    """cl/md.py:176-199 for constant-cell runs: a rattled copy is shown to an active calculator before the run."""
+    calc._logpref = "#"
+    calc.log("manual steps:")
+    calc.log(f"rattle: {eps}")
+    if eps > 0.0:
+        saved = atoms.positions.copy()
+        atoms.positions = saved + rng.normal(scale=eps, size=saved.shape)
+        atoms.calc = calc
+        atoms.get_potential_energy()
+        atoms.positions = saved
+    calc._logpref = ""
+
+
+def md(atoms, calc=None, dynamics="Langevin", dt=None, tem=300.0, picos=100, trajectory="md.xyz", loginterval=1, append=False,
+       rattle=0.0, friction=1e-3, eps_pos=0.05, seed=None, bulk_modulus=None, stress=0.0, mask=None, iso=False, tdamp=25, pdamp=100,
+       ml_filter=0.8, eps_cell=0.05):
+    """The keywords of theforce/cl/md.py::md (same names, same defaults except `dynamics`: the reference defaults to NPT).
+    picos > 0: pico-seconds per temperature; picos < 0: -picos steps (cl/md.py:100)."""
+    rng = np.random.default_rng(seed)
+    numbers = np.asarray(atoms.numbers)
+    calc = gen_active_calc(species=sorted(set(int(z) for z in numbers))) if calc is None else calc
+    atoms.calc = calc
+    if calc.active:
+        manual_steps(atoms, calc, eps_pos, rng)
+    if rattle:
+        atoms.positions = atoms.positions + rng.normal(scale=rattle, size=atoms.positions.shape)
+    temperatures = list(tem) if hasattr(tem, "__iter__") else [tem]
+    if calc.rank == 0:
+        print(f"MD temperatures: {temperatures}")
+    if getattr(atoms, "_masses", "ase") is None:
+        atoms._masses = np.array([MASS[int(z)] for z in numbers])
+    masses = np.asarray(atoms.get_masses(), float)
+    v = atoms.get_velocities()
+    if v is None or np.allclose(v, 0.0):
+        atoms.set_velocities(init_velocities(numbers, masses, temperatures[0], rng))
+    if dt is None:
+        dt = 0.25 if (numbers == 1).any() else 1.0          # cl/md.py:70-74
+    if dynamics.upper() != "LANGEVIN":
+        raise NotImplementedError("dynamics = 'NPT' is ase.md.npt.NPT around this calculator (cl/md.py:131-166): install ASE and "
+                                  "use the reference's driver with autoforce_amd.calculator.ActiveCalculator; here: 'Langevin'")
+    out = open(trajectory, "a" if append else "w") if (trajectory and calc.rank == 0) else None
+    for T in temperatures:
+        steps = int(picos * 1000 / dt) if picos > 0 else int(-picos)
+        for step, energy, temperature, updated, wall in calc.run_md(atoms, steps, T, dt_fs=dt, friction=friction, rng=None,
+                                                                    seed=int(rng.integers(1, 2 ** 62)), sync_every=loginterval or None):
+            if out is not None and loginterval and step % loginterval == 0:
+                # (the state lives on the device: run_md brings the positions back at the steps a trajectory wants them)
+                out.writelines(format_extxyz(Frame(numbers, atoms.positions, atoms.cell, atoms.pbc, energy, None, None)))
+    if out is not None:
+        out.close()
+    return atoms
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Machine Learning Molecular Dynamics (MLMD)")
+    ap.add_argument("-i", "--input", default="POSCAR.xyz", help="the initial coordinates of the atoms (extended XYZ)")
+    ap.add_argument("-o", "--output", default="CONTCAR.xyz", help="the final coordinates of the atoms (extended XYZ)")
+    a = ap.parse_args(argv)
+    from ..ase_shim import Atoms
+    fr = read_structure(a.input)
+    atoms = Atoms(fr.numbers, fr.positions, fr.cell, fr.pbc)
+    kwargs = get_default_args(md)
+    kwargs.pop("calc", None)
+    update_args(kwargs, read_args())
+    md(atoms, **kwargs)
+    with open(a.output, "w") as f:
+        f.writelines(format_extxyz(Frame(atoms.numbers, atoms.positions, atoms.cell, atoms.pbc, None, None, None)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""The command-line layer (autoforce_amd/cl, after theforce/cl): ARGS parsing with the reference's syntax, keyword
+splitting between the calculator and the driver, structure IO, velocity initialisation, and the `md` driver end to end on
+the CPU engine (which has no device loop: run_md falls back to the host integrator)."""
+import os
+
+import numpy as np
+import pytest
+
+import active_common as ac
+from autoforce_amd.ase_shim import Atoms, kB
+from autoforce_amd.calculator import ActiveCalculator, kcal_mol
+from helpers import OracleModel, PairTeacher
+
+
+def test_args_file_syntax(tmp_path, monkeypatch):
+    from autoforce_amd import cl
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "ARGS").write_text("# a comment\ncovariance = None   # model\nediff = 2*kcal_mol\ntem = [300., 600.]\n\npicos = -5\n"
+                                   "kernel_kw = {'lmax': 3, 'species': [3, 9]}\nmax_inducing = inf\ndynamics = 'Langevin'\n")
+    args = cl.read_args()
+    assert args["ediff"] == 2 * kcal_mol and args["tem"] == [300.0, 600.0] and args["picos"] == -5
+    assert args["kernel_kw"]["species"] == [3, 9] and args["max_inducing"] == float("inf") and args["covariance"] is None
+    kw = cl.update_args(cl.get_default_args(ActiveCalculator.__init__), args)
+    assert kw["ediff"] == 2 * kcal_mol and "tem" not in kw and kw["max_inducing"] == float("inf")
+    from autoforce_amd.cl import md as mdmod
+    dk = cl.update_args(cl.get_default_args(mdmod.md), args)
+    assert dk["tem"] == [300.0, 600.0] and dk["picos"] == -5 and dk["friction"] == 1e-3 and "ediff" not in dk
+    with pytest.raises(Exception):
+        (tmp_path / "ARGS").write_text("x = __import__('os').system('true')\n")
+        cl.read_args()
+
+
+def test_velocities_and_structure_io(tmp_path):
+    from autoforce_amd.cl.md import init_velocities, read_structure
+    from autoforce_amd.sgprio import Frame, format_extxyz
+    rng = np.random.default_rng(0)
+    numbers = np.array([3, 9] * 200)
+    masses = np.where(numbers == 3, 6.94, 18.998)
+    v = init_velocities(numbers, masses, 500.0, rng)
+    T = (masses[:, None] * v ** 2).sum() / (3 * len(numbers) * kB)
+    assert abs(T - 500.0) < 40.0 and np.abs((masses[:, None] * v).sum(0)).max() < 1e-10
+    pos = rng.random((400, 3)) * 10
+    cell = np.diag([10.0, 11.0, 12.0])
+    p = tmp_path / "two.xyz"
+    with open(p, "w") as f:
+        f.writelines(format_extxyz(Frame(numbers, pos, cell, True, None, None, None)))
+        f.writelines(format_extxyz(Frame(numbers, pos + 1.0, cell, True, -3.5, None, None)))
+    last = read_structure(str(p))
+    np.testing.assert_array_equal(last.numbers, numbers)
+    np.testing.assert_allclose(last.positions, pos + 1.0, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(read_structure(str(p), 0).positions, pos, rtol=0, atol=1e-13)
+
+
+def test_md_driver_on_the_cpu_engine(tmp_path, monkeypatch):
+    """`md` end to end: an active calculator on the CPU engine, two temperatures, five steps each (picos < 0), a
+    trajectory every second step; the log has one line per step and the model has grown."""
+    from autoforce_amd.cl.md import md, read_structure
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(7)
+    rng0, numbers, pos, cell = ac.start(0)
+    calc = ActiveCalculator(engine=OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=PairTeacher(rc=4.0),
+                            logfile="active.log", pckl=None, tape=None, **ac.KW)
+    atoms = Atoms(numbers, pos, cell, True)
+    md(atoms, calc=calc, dynamics="Langevin", tem=[300.0, 400.0], picos=-5, trajectory="md.xyz", loginterval=2, friction=0.02, seed=3)
+    assert calc.size[1] > 2 and calc.step >= 12
+    steps = [ln for ln in open("active.log").read().splitlines() if len(ln.split()) >= 6 and ln.split()[2].isdigit()
+             and ln.split()[3].lstrip("-").replace(".", "", 1).replace("e-", "", 1).isdigit()]
+    assert len(steps) >= 12
+    frames = open("md.xyz").read().count("Lattice=")
+    assert frames == 2 * 3      # steps 0, 2, 4 of each temperature
+    assert read_structure("md.xyz").natoms == len(numbers)
+    with pytest.raises(NotImplementedError, match="NPT"):
+        md(atoms, calc=calc, dynamics="NPT", picos=-1)

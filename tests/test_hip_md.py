@@ -329,3 +329,31 @@ def test_sharded_frames_with_the_next_step_binned(world):
     assert np.abs(tot[:3 * N].reshape(N, 3) - whole["forces"]).max() <= 1e-10 * fmax
     assert abs(tot[4 * N] - whole["energy"]) <= 1e-10 * max(1.0, abs(whole["energy"]))
     mdl.close()
+
+
+def test_command_line_md_on_the_device(tmp_path, monkeypatch):
+    """autoforce_amd.cl.md (theforce/cl/md.py's keywords): Langevin on the device loop, a trajectory frame every fifth
+    step brought back from device memory, the ARGS file read with the reference's syntax."""
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.cl import get_default_args, read_args, update_args
+    from autoforce_amd.cl.md import md, read_structure
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "ARGS").write_text("dynamics = 'Langevin'\ntem = 600.   # K\npicos = -20\nloginterval = 5\nfriction = 0.02\nseed = 3\n")
+    mdl, (numbers, pos, cell, pbc) = _model()
+    calc = ActiveCalculator(covariance=mdl, logfile=str(tmp_path / "active.log"))
+    assert calc.md_on_device_ok()
+    atoms = Atoms(numbers, pos, cell, pbc)
+    kw = update_args(get_default_args(md), read_args())
+    kw.pop("calc")
+    md(atoms, calc=calc, **kw)
+    lines = open("md.xyz").read().splitlines()
+    assert sum("Lattice=" in ln for ln in lines) == 5         # steps 0, 5, 10, 15, 20
+    frames = [read_structure("md.xyz", k).positions for k in range(5)]
+    for a, b in zip(frames, frames[1:]):
+        d = np.abs(b - a).max()
+        assert 1e-3 < d < 0.5, d                               # five thermal steps apart
+    np.testing.assert_allclose(frames[-1], atoms.positions, rtol=0, atol=1e-13)
+    log = [ln for ln in open(tmp_path / "active.log").read().splitlines()]
+    assert sum(1 for ln in log if len(ln.split()) == 6 and ln.split()[2].isdigit()) >= 21   # one line per step
+    mdl.close()
