@@ -125,7 +125,8 @@ struct MdState {
     DevBuf<double> X, V, P, KE, mass, sig, noise, noise_raw, cell;
     DevBuf<int> halt;
     int *halt_host = nullptr, *halt_host_dev = nullptr;
-    double *scal = nullptr, *scal_dev = nullptr;
+    DevBuf<double> scal_d;                    // [rows][SGPR_MD_SCAL] per-evaluation scalars, device memory (copied out once per run)
+    int *mark = nullptr, *mark_dev = nullptr;  // [rows] mapped host memory: evaluation j has passed its last kernel (look-ahead throttle)
     size_t scal_rows = 0;
     std::vector<double> mass_sorted;
 };
@@ -323,7 +324,14 @@ struct sgpr_model {
     int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
     bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
     bool xcd_quads = true;               // SGPR_XCD_QUADS=0: workgroup b of the descriptor kernels works on atoms 4b .. 4b+3
-    std::vector<int4> h_t_w, h_t_cov;
+    std::vector<int4> h_t_w, h_t_cov, h_t_knm, h_t_both;
+    // the three products of a step as ONE launch (gemm.hip::launch_gemm_fused): K_nm tiles first, then their consumers
+    DevBuf<int4> t_fused;
+    DevBuf<int> d_panel_cnt;
+    int fuse_epoch = 0;
+    // OFF by default: bit-identical, but 62 us against 18.7 + 22.7 for the two launches at 4096 / 512 (both
+    // phases are ONE wave of tiles, so there is nothing to overlap, and the fused K_nm tiles run on four waves, not eight)
+    bool gemm_fused = false;   // option "gemm_fused" (SGPR_GEMM_FUSED=1 at creation)
     // graph
     hipGraphExec_t gexec = nullptr;
     const void *g_pos = nullptr, *g_cell = nullptr, *g_out = nullptr;
@@ -406,7 +414,8 @@ struct FinNext {
     int *halt;                     // device: the first step that halted the run (INT_MAX: running; atomicMin)
     int *halt_host;                // mapped host memory, polled between chunks of launches: [0] the step whose covloss
                                    //   reached ediff, [1] the step that overflowed a capacity (INT_MAX: none)
-    double *scal_cur, *scal_prev;  // rows of the scalar ring (mapped host memory)
+    double *scal_cur, *scal_prev;  // rows of the scalar ring (device memory)
+    int *mark_cur;                 // mapped host memory: set to 1 by this evaluation's last kernel (ONE posted write per step)
 };
 
 struct FinArgs {
@@ -527,6 +536,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
             f.packed[4 * (size_t)f.N + 10] = ov ? 1.0 : 0.0;
             if (f.nx.mode == 2) {
                 f.nx.scal_cur[10] = ov ? 1.0 : 0.0;
+                *f.nx.mark_cur = 1;
                 if (ov) {  // the lists of this step were clamped: its results and the state integrated from them are void
                     atomicMin(&f.nx.halt[0], f.nx.step);
                     f.nx.halt_host[1] = f.nx.step;
@@ -1114,6 +1124,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     h->d_cell0.alloc(18);  // cell at the last rebuild + its inverse
     if (const char *e = getenv("SGPR_SPIN_WAIT")) h->spin_wait = atoi(e) != 0;
     if (const char *e = getenv("SGPR_FUSE_NEXT")) h->fuse_next = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_GEMM_FUSED")) h->gemm_fused = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
@@ -1307,6 +1318,35 @@ static void decide_tile_heights(sgpr_model *h)
     h->gemm_w64 = count_tiles(h, 1, 32) + count_tiles(h, 2, 32) >= 24 * ncu;
 }
 
+// The fused table: the K_nm tiles in their own order (so that their energy partials keep their slots), tagged kind 2,
+// then the grouped W + covloss table with the number of K_nm tiles of each entry's row panel in bits 20..27.  Only for the
+// 32-row / 16-deep forms of all three products (the row panels of producer and consumers must coincide).
+static int build_fused_tiles(sgpr_model *h)
+{
+    h->t_fused.release();
+    h->fuse_epoch = 0;
+    if (h->gemm_bm_k != 32 || h->gemm_bm_w != 32 || h->gemm_kd_k != 16 || h->gemm_kd_w != 16 || h->gemm_k64 || h->gemm_w64) return 0;
+    if (h->h_t_knm.empty() || h->h_t_both.empty()) return 0;
+    const int nrt = (h->cnt + 31) / 32;
+    std::vector<int> need(std::max(nrt, 1), 0);
+    std::vector<int4> fused;
+    fused.reserve(h->h_t_knm.size() + h->h_t_both.size());
+    for (const int4 &t : h->h_t_knm) {
+        if (t.w > t.z) need[t.x] += 1;
+        fused.push_back(make_int4(t.x | (2 << 16), t.y, t.z, t.w));
+    }
+    for (const int4 &t : h->h_t_both) {
+        if (t.w <= t.z) { fused.push_back(t); continue; }
+        const int rt = t.x & 0xffff;
+        if (need[rt] <= 0 || need[rt] > 255) { h->t_fused.release(); return 0; }   // (no producer / beyond the field: stay unfused)
+        fused.push_back(make_int4(t.x | (need[rt] << 20), t.y, t.z, t.w));
+    }
+    if (h->t_fused.alloc(fused.size(), false) || h->d_panel_cnt.alloc(std::max(nrt, 1))) return -1;
+    if (hipMemcpy(h->t_fused.p, fused.data(), sizeof(int4) * fused.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemset(h->d_panel_cnt.p, 0, h->d_panel_cnt.n * sizeof(int)) != hipSuccess) return -1;
+    return 0;
+}
+
 static int build_tiles(sgpr_model *h, int kind)
 {
     const int KTc = 32;
@@ -1364,6 +1404,7 @@ static int build_tiles(sgpr_model *h, int kind)
     for (int x = 0; x < 8; x++)
         for (size_t j = 0; j < bucket[x].size(); j++) list[j * 8 + x] = bucket[x][j];
     DevBuf<int4> &dst = kind == 0 ? h->t_knm : kind == 1 ? h->t_w : kind == 2 ? h->t_cov : h->t_kmm;
+    if (kind == 0) h->h_t_knm = list;
     if (kind == 1) h->h_t_w = list;
     if (kind == 2) h->h_t_cov = list;
     if (kind == 1 || kind == 2) {
@@ -1402,6 +1443,8 @@ static int build_tiles(sgpr_model *h, int kind)
             if (h->t_wcov.alloc(both.size(), false)) return -1;
             if (hipMemcpy(h->t_wcov.p, both.data(), sizeof(int4) * both.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
         }
+        h->h_t_both = both;
+        if (build_fused_tiles(h)) return -1;
     }
     dst.release();
     if (list.empty()) return 0;
@@ -1410,9 +1453,18 @@ static int build_tiles(sgpr_model *h, int kind)
     return 0;
 }
 
+static GemmParams knm_params(sgpr_model *h, const double *A, int M, const int *row_slot, const int *row_nn,
+                             const DevBuf<int4> &tiles, double *Kout, double *Aw, const double *mu, double *Epart);
+
 static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row_slot, const int *row_nn,
                            const DevBuf<int4> &tiles, double *Kout, double *Aw, const double *mu, double *Epart,
                            hipStream_t st)
+{
+    launch_gemm_nt(knm_params(h, A, M, row_slot, row_nn, tiles, Kout, Aw, mu, Epart), EPI_KERNEL, st);
+}
+
+static GemmParams knm_params(sgpr_model *h, const double *A, int M, const int *row_slot, const int *row_nn,
+                             const DevBuf<int4> &tiles, double *Kout, double *Aw, const double *mu, double *Epart)
 {
     GemmParams g = {};
     g.M = M; g.N = h->m; g.K = h->Dpad;
@@ -1425,7 +1477,7 @@ static void gemm_kernel_pm(sgpr_model *h, const double *A, int M, const int *row
     g.eta = h->eta; g.lone_m1 = h->lone_w - 1.0; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
     g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
-    launch_gemm_nt(g, EPI_KERNEL, st);
+    return g;
 }
 
 static int alloc_work(sgpr_model *h);
@@ -1969,7 +2021,12 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     stamp(h, "list_forward", st);
     const bool predict = h->m > 0 && h->has_mu && cnt > 0 && !h->rows_mu;
     const bool beta = h->m > 0 && h->has_choli && cnt > 0 && !h->rows_mu;
-    if (h->m > 0 && cnt > 0) {
+    // one launch for the three products when their tile forms allow it: the K_nm tiles first, the W and covloss tiles of
+    // a row panel start when that panel's K_nm tiles have signalled (gemm_tile.inc, EPI_FUSED)
+    const bool fused3 = predict && beta && h->gemm_fused && h->t_fused.n > 0 && !h->use_graph &&
+                        !(h->use_fork && h->side && !h->profile) &&
+                        !(h->cov_in_rev && h->gemm_bm_w == 32 && h->gemm_kd_w == 16 && h->t_covl.n > 0);
+    if (h->m > 0 && cnt > 0 && !fused3) {
         gemm_kernel_pm(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->t_knm, h->d_K.p, h->d_Aw.p,
                        h->rows_mu ? h->rows_mu : (h->has_mu ? h->d_mu.p : nullptr), h->d_Epart.p, st);
         stamp(h, "gemm_knm", st);
@@ -1994,7 +2051,17 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     // "overlap" option: the covloss product (MFMA-bound) runs on a side stream next to the reverse pass
     // (VALU/latency-bound) instead of being grouped with the W product
     bool forked = false, cov_rides = false;
-    if (predict && beta && h->use_fork && h->side && !h->profile) {
+    if (fused3) {
+        if (h->fuse_epoch >= (1 << 22)) {   // (counters reach epoch x 255 at most: far from the end of an int)
+            (void)hipMemsetAsync(h->d_panel_cnt.p, 0, h->d_panel_cnt.n * sizeof(int), st);
+            h->fuse_epoch = 0;
+        }
+        GemmParams gk = knm_params(h, h->d_Pn.p, cnt, h->d_lslot.p, h->d_lnn.p, h->t_knm, h->d_K.p, h->d_Aw.p, h->d_mu.p,
+                                   h->d_Epart.p);
+        launch_gemm_fused(gk, gw, gc, h->t_fused.p, (int)h->t_fused.n, h->d_Epart.p, h->d_panel_cnt.p, ++h->fuse_epoch,
+                          h->d_stat.p + 3, st);
+        stamp(h, "gemm_fused", st);
+    } else if (predict && beta && h->use_fork && h->side && !h->profile) {
         (void)hipEventRecord(h->ev_fork, st);
         (void)hipStreamWaitEvent(h->side, h->ev_fork, 0);
         launch_gemm_nt(gc, EPI_ROWSQ, h->side);
@@ -2033,7 +2100,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     // the single-rank gather form)
     const bool fuse = nx && nx->mode && h->fuse_next && predict && !forked && !h->use_graph && h->skin > 0.0 &&
                       ((gather && h->comm == nullptr) || (nx->mode == 1 && !gather && h->world > 1));
-    launch_finalize(h, gather && predict, predict ? h->epart_len : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
+    launch_finalize(h, gather && predict, predict ? (fused3 ? 4 * (int)h->t_knm.n : h->epart_len) : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
                     packed_dev, st, nullptr, fuse ? nx : nullptr, step);
     if (fuse) {
         h->pre_valid = true; h->pre_pos = nx->pos_next; h->pre_cell = cell_dev; h->pre_step = step + 1;
@@ -2069,6 +2136,11 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         int stat[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
         if (stat[3] == 2) return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero");
+        if (stat[3] == 4) {   // a consumer tile of the fused GEMM launch gave up waiting for its producers: never again
+            h->gemm_fused = false;
+            fprintf(stderr, "[sgpr] the fused GEMM launch timed out waiting for its K_nm tiles: continuing with separate launches\n");
+            continue;
+        }
         if (stat[3] == 3) return fail(SGPR_E_OVERFLOW, "a pair force beyond 1024 eV/A left the fixed-point range of the sharded reverse pass");
         if (stat[3])
             return fail(SGPR_E_OVERFLOW, "an atom lies more than 127 periodic images away from a neighbour (or > 32767 "
@@ -2484,13 +2556,16 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     if (halt_code) *halt_code = 0;
     // scalar ring in mapped host memory
     if (m.scal_rows < (size_t)nevals + 1) {
-        if (m.scal) (void)hipHostFree(m.scal);
-        m.scal = nullptr; m.scal_rows = 0;
-        if (hipHostMalloc((void **)&m.scal, sizeof(double) * SGPR_MD_SCAL * ((size_t)nevals + 1), hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer((void **)&m.scal_dev, m.scal, 0) != hipSuccess)
-            return fail(SGPR_E_NODEVICE, "sgpr_md_run: no mapped host memory");
+        if (m.mark) (void)hipHostFree(m.mark);
+        m.mark = nullptr; m.scal_rows = 0;
+        if (m.scal_d.alloc((size_t)SGPR_MD_SCAL * ((size_t)nevals + 1), false) ||
+            hipHostMalloc((void **)&m.mark, sizeof(int) * ((size_t)nevals + 1), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&m.mark_dev, m.mark, 0) != hipSuccess)
+            return fail(SGPR_E_NODEVICE, "sgpr_md_run: no memory for the scalar ring");
         m.scal_rows = (size_t)nevals + 1;
     }
+    HIPCHK(hipMemsetAsync(m.scal_d.p, 0, sizeof(double) * SGPR_MD_SCAL * ((size_t)nevals + 1), st));
+    memset(m.mark, 0, sizeof(int) * ((size_t)nevals + 1));
     if (noise) {
         if (m.noise.alloc((size_t)nevals * 3 * N) || m.noise_raw.alloc((size_t)nevals * 3 * N))
             return fail(SGPR_E_NODEVICE, "sgpr_md_run: device allocation failed");
@@ -2518,24 +2593,24 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     const unsigned step0 = h->step_count;
     const bool pend0 = m.t > 0;   // (the closing half kick of the first configuration: due unless it is the start of the trajectory)
     // The host runs AHEAD of the device by at most `LA` evaluations: before evaluation j is enqueued, evaluation j - LA must
-    // have written its overflow word into the scalar ring (mapped host memory; the ring is filled with NaN first), or
-    // the run must have halted.  A halt therefore leaves at most LA + 1 evaluations in the queue (they exit at once or
+    // have set its mark (one int per evaluation in mapped host memory, written by the reducer of the overflow word: the ONLY
+    // posted write of a step — the sixteen scalars stay in device memory and are copied out once per call), or the run must
+    // have halted.  A halt therefore leaves at most LA + 1 evaluations in the queue (they exit at once or
     // recompute a discarded step), where a fixed chunk of 16 left up to 32 (14 ms per halt at 16384 atoms).  LA = 6 at 4096
     // atoms (the host needs ~25 us to enqueue a step of ~80 us), 2 at 16384 (~0.5 ms per step).
     const int LA = std::min(6, std::max(2, (int)lround(24576.0 / std::max(N, 1))));   // (fewer for large frames: their steps are long)
-    for (size_t k = 0; k < (size_t)SGPR_MD_SCAL * ((size_t)nevals + 1); k++) m.scal[k] = std::numeric_limits<double>::quiet_NaN();
     int enq = 0;
     bool halted = false;
     int rc_ = SGPR_OK;
     for (int j = 0; j < nevals && !halted && !rc_; j++) {
         if (j >= LA) {
-            const volatile double *mark = m.scal + (size_t)SGPR_MD_SCAL * (j - LA) + 10;
+            const volatile int *mark = m.mark + (j - LA);
             const volatile int *hh = m.halt_host;
             unsigned spins = 0;
-            while (std::isnan(*mark) && hh[0] == halt_none && hh[1] == halt_none) {
+            while (*mark == 0 && hh[0] == halt_none && hh[1] == halt_none) {
                 if ((++spins & 0x3fffu) == 0) {  // (a dead queue must not hang the host)
                     const hipError_t q = hipStreamQuery(st);
-                    if (q == hipSuccess && std::isnan(*mark)) { rc_ = fail(SGPR_E_NODEVICE, "sgpr_md_run: the queue drained without evaluation %d reporting", j - LA); break; }
+                    if (q == hipSuccess && *mark == 0) { rc_ = fail(SGPR_E_NODEVICE, "sgpr_md_run: the queue drained without evaluation %d reporting", j - LA); break; }
                     if (q != hipSuccess && q != hipErrorNotReady) { rc_ = fail(SGPR_E_NODEVICE, "sgpr_md_run: %s", hipGetErrorString(q)); break; }
                 }
             }
@@ -2558,7 +2633,8 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         x.packed_prev = j > 0 ? m.P.p + plen * sp : nullptr;
         x.ediff = ediff > 0.0 ? ediff : 1e300;
         x.halt = m.halt.p; x.halt_host = m.halt_host_dev;
-        x.scal_cur = m.scal_dev + (size_t)SGPR_MD_SCAL * j; x.scal_prev = m.scal_dev + (size_t)SGPR_MD_SCAL * (j > 0 ? j - 1 : 0);
+        x.scal_cur = m.scal_d.p + (size_t)SGPR_MD_SCAL * j; x.scal_prev = m.scal_d.p + (size_t)SGPR_MD_SCAL * (j > 0 ? j - 1 : 0);
+        x.mark_cur = m.mark_dev + j;
         (void)integrate;  // (the last evaluation of a `final` run integrates speculatively too: its outcome is not adopted below)
         rc_ = enqueue_step(h, x.x_cur, m.cell.p, m.P.p + plen * sl, st, &nx);
         if (rc_) break;
@@ -2575,7 +2651,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         f.nx.mode = 3; f.nx.step = (int)(step0 + enq);
         f.nx.ke_prev = m.KE.p + (size_t)2 * N * sl; f.nx.packed_prev = m.P.p + plen * sl;
         f.nx.ediff = ediff > 0.0 ? ediff : 1e300; f.nx.halt = m.halt.p; f.nx.halt_host = m.halt_host_dev;
-        f.nx.scal_prev = m.scal_dev + (size_t)SGPR_MD_SCAL * (enq - 1);
+        f.nx.scal_prev = m.scal_d.p + (size_t)SGPR_MD_SCAL * (enq - 1);
         hipLaunchKernelGGL(finalize_tail_kernel, dim3(2), dim3(256), 0, st, f);
     }
     // (the last kernel enqueued has binned a step that will not run — or, after a halt, the bins are those of a discarded
@@ -2600,7 +2676,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     }
     if (code == 2) done -= 1;  // (the overflowing evaluation's own results are void)
     if (scalars && done > 0) {
-        memcpy(scalars, m.scal, sizeof(double) * SGPR_MD_SCAL * (size_t)done);
+        HIPCHK(hipMemcpy(scalars, m.scal_d.p, sizeof(double) * SGPR_MD_SCAL * (size_t)done, hipMemcpyDeviceToHost));
         for (int r = 0; r < done; r++) scalars[(size_t)SGPR_MD_SCAL * r + 14] = scalars[(size_t)SGPR_MD_SCAL * r + 15] = 0.0;  // (spare)
     }
     *evals_done = done;
@@ -2682,6 +2758,11 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
     HIPCHK(hipMemcpy(stat, h->d_stat.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemset(h->d_stat.p, 0, 4 * sizeof(int)));
     if (stat[3] == 2) { h->warm = false; h->lists_valid = false; return fail(SGPR_E_INVALID, "the cell vector of a periodic direction is zero"); }
+    if (stat[3] == 4) {
+        h->warm = false; h->gemm_fused = false;
+        return fail(SGPR_E_OVERFLOW, "the fused GEMM launch timed out waiting for its K_nm tiles (separate launches from now on); "
+                    "results since the last check are invalid");
+    }
     if (stat[3]) {
         h->warm = false;
         h->lists_valid = false;
@@ -2710,6 +2791,7 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!strcmp(name, "overlap")) { h->use_fork = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "cov_in_rev")) { h->cov_in_rev = value != 0; drop_graph(h); return SGPR_OK; }
     if (!strcmp(name, "spin_wait")) { h->spin_wait = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "gemm_fused")) { h->gemm_fused = value != 0; return SGPR_OK; }
     if (!strcmp(name, "fuse_next")) { h->fuse_next = value != 0; h->pre_valid = false; h->lists_valid = false; return SGPR_OK; }
     if (!strcmp(name, "zero_copy_out")) { h->zero_copy_out = value != 0; return SGPR_OK; }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }

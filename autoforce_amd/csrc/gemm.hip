@@ -69,6 +69,22 @@ void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *ti
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 2>), dim3(ntiles), dim3(256), 0, st, g);
 }
 
+void launch_gemm_fused(const GemmParams &pk, const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles,
+                       double *Epart, int *panel_cnt, int epoch, int *err, hipStream_t st)
+{
+    if (ntiles <= 0) return;
+    GemmArgs g = {};
+    g.p = pw; g.p2 = pc; g.p3 = pk;
+    g.p.tiles = tiles;
+    g.p.ntiles = ntiles;
+    g.ieta = (pk.eta == (double)(int)pk.eta && pk.eta >= 1.0 && pk.eta <= 64.0) ? (int)pk.eta : -1;
+    g.row_slot = pk.row_slot;
+    g.col_slot = pk.col_slot;
+    g.Epart = Epart;
+    g.panel_cnt = panel_cnt; g.epoch = epoch; g.fuse_err = err;
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI_FUSED, 1, 16>), dim3(ntiles), dim3(256), 0, st, g);
+}
+
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
 {
     if (p.M <= 0 || p.N <= 0) return;

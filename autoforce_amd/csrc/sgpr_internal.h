@@ -190,7 +190,7 @@ void launch_unpack_descriptors(int n, int S, int lmax, int nmax, int Dc, int Dpa
                                const double *Pp, double *Pdense, hipStream_t st);
 
 // ---- fp64 MFMA GEMM family (C = A * B^T, both operands row-major with K contiguous) --------
-enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4 };
+enum GemmEpilogue { EPI_STORE = 0, EPI_KERNEL = 1, EPI_ROWSQ = 2, EPI_SUBLOWER = 3, EPI_WCOV = 4, EPI_FUSED = 5 };
 
 struct GemmParams {
     int M, N, K;          // C is M x N, reduction K
@@ -227,6 +227,11 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st);
 // one launch for two products sharing the row dimension: pw with EPI_STORE, pc with EPI_ROWSQ;
 // tiles[].x carries the row tile in its low 16 bits and the problem (0 = pw, 1 = pc) in bit 16
 void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st);
+// ONE launch for the three products of a step: K_nm (pk, EPI_KERNEL epilogue) and, behind per-row-panel counters, its
+// consumers W (pw) and covloss (pc).  tiles[].x: row tile | kind << 16 (0 W, 1 covloss, 2 K_nm) | K tiles of the row
+// panel << 20; K_nm entries first.  panel_cnt: [row tiles] ints, zero when `epoch` starts at 1; err: one int, zero.
+void launch_gemm_fused(const GemmParams &pk, const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles,
+                       double *Epart, int *panel_cnt, int epoch, int *err, hipStream_t st);
 
 // ---- dense solve side ---------------------------------------------------------------------
 // All on one stream, m x m row-major with leading dimension ld.

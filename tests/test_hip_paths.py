@@ -299,3 +299,47 @@ def test_npt_walk_reuses_candidates_under_strain():
     for k in ("energy", "forces", "stress", "beta"):
         np.testing.assert_array_equal(np.asarray(a[k]), np.asarray(b[k]))
     fast.close(); slow.close()
+
+
+@pytest.mark.parametrize("side,m", [(8, 48), (16, 512)])
+def test_fused_gemm_launch_equals_the_three_launches(side, m):
+    """The K_nm, W and covloss products of a step go out as ONE launch whose W / covloss tiles wait, panel by panel, on
+    the K_nm tiles ahead of them in the tile list (gemm_tile.inc, EPI_FUSED).  Against the same handle with the option off
+    (K_nm launch, then the grouped W + covloss launch): forces, stress and covloss bit for bit on every frame of a walk —
+    a consumer that started before its producers had written through would show here — the energy to the rounding of
+    its per-tile partials (four per K_nm tile instead of eight), and the stage table shows one GEMM stage."""
+    import ctypes as C
+    import torch
+    from autoforce_amd import _lib
+    from test_hip_md import _model
+    mdl, (numbers, pos, cell, pbc) = _model(side=side, m=m)
+    lib, h, N = _lib.load(), mdl.handle, len(numbers)
+    rng = np.random.default_rng(8)
+    frames = [pos]
+    for _ in range(60):
+        frames.append(frames[-1] + 0.01 * rng.normal(size=pos.shape))
+    mdl.predict(numbers, pos, cell, pbc)
+    dev = torch.device("cuda:0")
+    fr, cl = torch.tensor(np.stack(frames), device=dev), torch.tensor(cell, device=dev)
+    outs = []
+    for fused in (1, 0, 1):
+        _lib.check(lib.sgpr_set_option(h, b"gemm_fused", fused))
+        out = torch.zeros((len(frames), 4 * N + 11), dtype=torch.float64, device=dev)
+        for rep in range(3):   # (the same frames three times over: every repetition must land on the same bits)
+            for k in range(len(frames)):
+                nxt = fr[k + 1].data_ptr() if k + 1 < len(frames) else None
+                _lib.check(lib.sgpr_step_dev_next(h, fr[k].data_ptr(), cl.data_ptr(), out[k].data_ptr(), nxt, None))
+            _lib.check(lib.sgpr_sync_check(h, None))
+            outs.append(out.cpu().numpy().copy())
+        mdl.profile(True)
+        mdl.predict(numbers, pos, cell, pbc)
+        stages = list(mdl.stage_times())
+        mdl.profile(False)
+        assert ("gemm_fused" in stages) == bool(fused) and ("gemm_knm" in stages) != bool(fused), stages
+    ref = outs[3]   # the three-launch form
+    for o in outs:
+        e = 4 * N   # packed: [F (3N) | covloss (N) | E | virial (9) | overflow]
+        assert np.array_equal(np.delete(o, e, axis=1), np.delete(ref, e, axis=1)), np.abs(o - ref).max()
+        assert np.all(np.abs(o[:, e] - ref[:, e]) <= 4e-16 * np.abs(ref[:, e]) * np.sqrt(N) + 1e-13)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[6])
+    mdl.close()

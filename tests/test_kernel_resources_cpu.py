@@ -22,6 +22,7 @@ LIMITS = {
     r"finalize_gather_kernel": (0, 64),
     r"gemm_nt_kernel8ILi1E": (0, 128),
     r"gemm_nt_kernelILi4ELi1ELi16E": (0, 128),
+    r"gemm_nt_kernelILi5ELi1ELi16E": (0, 128),      # (the fused K_nm + W + covloss launch)
     r"tsqr_leaf_wave_kernel": (0, 128),
 }
 
