@@ -329,8 +329,10 @@ struct sgpr_model {
     DevBuf<int4> t_fused;
     DevBuf<int> d_panel_cnt;
     int fuse_epoch = 0;
-    // OFF by default: bit-identical, but 62 us against 18.7 + 22.7 for the two launches at 4096 / 512 (both
-    // phases are ONE wave of tiles, so there is nothing to overlap, and the fused K_nm tiles run on four waves, not eight)
+    // OFF by default: bit-identical, but 42.9 us against 18.3 + 22.5 for the two launches at 4096 / 512 (62 before every
+    // panel counter had a cache line of its own).  DESIGN.md §3: both phases are ONE wave of tiles that end together, so
+    // there is nothing to overlap; the fused K_nm tiles run on four waves, not eight; and the hand-off without an acquire
+    // fence is the guide's measured-not-guaranteed form, here at four workgroups per CU
     bool gemm_fused = false;   // option "gemm_fused" (SGPR_GEMM_FUSED=1 at creation)
     // graph
     hipGraphExec_t gexec = nullptr;
@@ -1341,7 +1343,7 @@ static int build_fused_tiles(sgpr_model *h)
         if (need[rt] <= 0 || need[rt] > 255) { h->t_fused.release(); return 0; }   // (no producer / beyond the field: stay unfused)
         fused.push_back(make_int4(t.x | (need[rt] << 20), t.y, t.z, t.w));
     }
-    if (h->t_fused.alloc(fused.size(), false) || h->d_panel_cnt.alloc(std::max(nrt, 1))) return -1;
+    if (h->t_fused.alloc(fused.size(), false) || h->d_panel_cnt.alloc((size_t)32 * std::max(nrt, 1))) return -1;
     if (hipMemcpy(h->t_fused.p, fused.data(), sizeof(int4) * fused.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (hipMemset(h->d_panel_cnt.p, 0, h->d_panel_cnt.n * sizeof(int)) != hipSuccess) return -1;
     return 0;
