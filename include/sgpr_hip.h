@@ -381,6 +381,8 @@ int sgpr_sync_check(sgpr_model *h, void *stream);
  *  "fuse_next" = 1/0        the last kernel of a step may open the next one (sgpr_step_dev_next, sgpr_md_run;
  *                           default 1; 0: every step bins for itself — sgpr_md_run then returns SGPR_E_UNSUPPORTED).
  *                           Environment: SGPR_FUSE_NEXT
+ *  "gemm_fused" = 1/0       K_nm, W and covloss of a step in ONE launch (consumer tiles wait on per-panel counters;
+ *                           same bits, measured slower at 4096 atoms: default 0).  Environment: SGPR_GEMM_FUSED
  *  "spin_wait" = 1/0        sgpr_compute polls its stream for the end of a step instead of a blocking wait
  *                           (default 1: one host thread spins for the ~0.1 ms of a step, 16 us less wall time per
  *                           call on a 4096-atom frame; 0: hipStreamSynchronize).  Environment: SGPR_SPIN_WAIT */
