@@ -1205,6 +1205,16 @@ extern "C" void sgpr_destroy(sgpr_model *h)
             fprintf(stderr, "[sgpr stamps] %s: %d waves, cycles per phase:", pass == 0 ? "list+forward (sweep, sort, list out, tiles, c+spectrum)" : "reverse (dE/dc, pairs)", cntw);
             for (int k = 0; k + 1 < np; k++) fprintf(stderr, " %.0f", d[k] / std::max(cntw, 1));
             fprintf(stderr, "; first start -> last end %lld\n", t1 - t0);
+            if (pass == 0) {   // a step that reused its candidates has no stamps 1, 2: start -> list, list -> c, c -> spectrum out
+                double e[3] = {0, 0, 0};
+                for (int i = 0; i < h->cnt; i++) {
+                    const long long *w = st.data() + (size_t)i * 8;
+                    if (w[0] <= 0 || w[5] <= 0) continue;
+                    e[0] += (double)(w[3] - w[0]); e[1] += (double)(w[4] - w[3]); e[2] += (double)(w[5] - w[4]);
+                }
+                fprintf(stderr, "[sgpr stamps]    as a reuse step: list filter %.0f | c (radial, harmonics, MFMA) %.0f | spectrum + rows out %.0f\n",
+                        e[0] / std::max(cntw, 1), e[1] / std::max(cntw, 1), e[2] / std::max(cntw, 1));
+            }
         }
     }
     h->d_pstamps.release();
