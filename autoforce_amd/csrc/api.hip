@@ -1234,6 +1234,18 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     h->d_rows_cols.release();
     h->d_rows_rowof.release(); h->d_rows_qoff.release(); h->d_rows_vpart.release();
     if (h->pin) (void)hipHostFree(h->pin);
+    if (h->md.halt_host) (void)hipHostFree(h->md.halt_host);
+    if (h->md.mark) (void)hipHostFree(h->md.mark);
+    {   // (a DevBuf has no destructor — handles are copied around as plain structs —: every buffer is released by name)
+        MdState &m = h->md;
+        DevBuf<double> *mdb[] = {&m.X, &m.V, &m.P, &m.KE, &m.mass, &m.sig, &m.noise, &m.noise_raw, &m.cell, &m.scal_d};
+        for (auto b : mdb) b->release();
+        m.halt.release();
+        DevBuf<int4> *tb[] = {&h->t_knm, &h->t_w, &h->t_cov, &h->t_kmm, &h->t_wcov, &h->t_fused};
+        for (auto b : tb) b->release();
+        h->d_panel_cnt.release();
+        h->d_stamps.release(); h->d_stamps2.release();
+    }
     {
         DevBuf<double> *sd[] = {&h->sc_s2A, &h->sc_s2x, &h->sc_s2work, &h->sc_mv_v, &h->sc_mv_o, &h->sc_ra_y, &h->sc_ra_t, &h->sc_vs_t,
                                 &h->sc_ai_er, &h->sc_ai_p, &h->sc_ai_norm, &h->sc_ai_krow, &h->sc_ai_kself, &h->sc_y, &h->sc_bA, &h->sc_bx,

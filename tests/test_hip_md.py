@@ -357,3 +357,31 @@ def test_command_line_md_on_the_device(tmp_path, monkeypatch):
     log = [ln for ln in open(tmp_path / "active.log").read().splitlines()]
     assert sum(1 for ln in log if len(ln.split()) == 6 and ln.split()[2].isdigit()) >= 21   # one line per step
     mdl.close()
+
+
+def test_handles_give_back_their_device_memory():
+    """A handle owns its device buffers by name (no destructors): after a predict step, a device MD run with a halt, a
+    refit and `close()` the free memory of the device is what it was, handle after handle — the MD state, the tile tables
+    and the mapped host words of the run included (sgpr_destroy)."""
+    import torch
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS
+
+    def cycle():
+        mdl, (numbers, pos, cell, pbc) = _model(side=16, m=48)   # 4096 atoms: the MD state alone is 1.3 MB
+        mdl.predict(numbers, pos, cell, pbc)
+        mass = np.array([MASS[int(z)] for z in numbers])
+        mdl.md_begin(numbers, pos, cell, pbc, mass, np.zeros_like(pos), dt=FS, friction=1e-3, kT=kB * 300.0, seed=3)
+        mdl.md_run(12, None)
+        mdl.md_end()
+        mdl.close()
+
+    cycle()  # (the first two handles also pay for pools of the runtime: +48 MB once, with the second handle's streams)
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (4 << 20), (free0, free1)   # (six leaked MD states would be 8 MB; the driver hands out 2 MB pages)
