@@ -3,8 +3,11 @@
 tag=$1
 cd $GRAFT_REPO_ROOT
 bash tools/collect_profiles.sh $tag "builder run, round ${tag#r} (final build)" > gpurun_out/${tag}_collect.log 2>&1
+cp gpurun_out/${tag}_pmc_traffic_lips4096_m512.json profiles/   # (the bench line quotes the traffic of THIS build: same csrc sha)
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_line.err
 python examples/md_nvt_config5.py --steps 300 > gpurun_out/${tag}_md_config5_16384.log 2>&1
+python examples/md_nvt_config5.py --steps 1000 > gpurun_out/${tag}_md_config5_16384_1000steps.log 2>&1
+python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_line_20steps.json 2>/dev/null
 (python tools/update_bench.py 32 1024 2; python tools/update_bench.py 32 256 2) > gpurun_out/${tag}_update_bench_16384.log 2>&1
 for cfg in "8 128" "16 512" "25 1024" "32 1024" "32 512"; do set -- $cfg
   python bench.py --atoms-side $1 --inducing $2 --steps 100 --warmup 10 --no-cpu-baseline --no-big-wall 2>/dev/null | tail -1
