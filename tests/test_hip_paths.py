@@ -3,6 +3,8 @@ oracle on identical inputs: 5 species (the 8-slot kernel instantiation), lmax=nm
 with more than 64 neighbours (multi-tile descriptor passes, neighbour capacity growth), a cell much
 smaller than the cutoff (many periodic images, more than 64 bins in the sweep), a dense cluster in
 ONE bin (bin-capacity growth), degenerate inputs (no atoms, no inducing set)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -343,3 +345,39 @@ def test_fused_gemm_launch_equals_the_three_launches(side, m):
         assert np.all(np.abs(o[:, e] - ref[:, e]) <= 4e-16 * np.abs(ref[:, e]) * np.sqrt(N) + 1e-13)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[6])
     mdl.close()
+
+
+def test_bench_line_keeps_its_contract():
+    """`python bench.py` as the driver runs it (fewer steps, a small CPU sample): ONE JSON line on stdout with the metric
+    BASELINE.json names, the whole-job value, and the `roofline` / `cpu_baseline` objects with every field the contract
+    lists; `frac` = achieved / peak, the value consistent with ms_per_step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                          "--md-steps", "60", "--no-big-wall", "--cpu-sample", "256"], capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert base["metric"].startswith("MD-step atoms") and d["metric"].startswith("MD-step atoms*steps/sec")   # BASELINE's metric
+    assert d["unit"] == "atom*steps/s"
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["dtype"] == "f64" and d["data"].startswith("synthetic") and "workload" in d["config"] and "model" not in d["config"]
+    atoms = 4096
+    assert abs(d["value"] - atoms / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    assert d["config"]["launches_per_step"] == 5 and d["value_md_loop"] > 0 and d["value_calculate_wall"] > 0
