@@ -437,6 +437,10 @@ class ActiveCalculator(Calculator):
         and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no."""
         from .ase_shim import kB
         from .workloads import FS, MASS, langevin_nvt
+        if len(getattr(atoms, "constraints", None) or ()):
+            # (neither integrator of this method knows ASE's constraints: an ASE dynamics object around calculate() does)
+            raise NotImplementedError("run_md integrates unconstrained atoms; with atoms.constraints set, drive calculate() "
+                                      "from an ase.md dynamics object as theforce/cl/md.py does")
         numbers, pos, cell, pbc = self._system(atoms)
         N = len(numbers)
         on_device_rng = rng is None and friction > 0.0

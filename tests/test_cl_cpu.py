@@ -71,3 +71,8 @@ def test_md_driver_on_the_cpu_engine(tmp_path, monkeypatch):
     assert read_structure("md.xyz").natoms == len(numbers)
     with pytest.raises(NotImplementedError, match="NPT"):
         md(atoms, calc=calc, dynamics="NPT", picos=-1)
+    # atoms that carry ASE constraints are not for this loop (neither integrator knows them): said so, not ignored
+    atoms.constraints = [object()]
+    with pytest.raises(NotImplementedError, match="constraints"):
+        next(calc.run_md(atoms, 2, 300.0))
+    atoms.constraints = []
