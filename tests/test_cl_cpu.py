@@ -76,3 +76,75 @@ def test_md_driver_on_the_cpu_engine(tmp_path, monkeypatch):
     with pytest.raises(NotImplementedError, match="constraints"):
         next(calc.run_md(atoms, 2, 300.0))
     atoms.constraints = []
+
+
+def test_built_in_bfgs_and_fire_follow_their_published_rules():
+    """The optimizers restated in cl/relax.py for images without ASE.  BFGS on an exactly quadratic surface E = x^T A x / 2:
+    the first step is the force over H0 = 70 eV/A^2 (scaled to the 0.2 A limit when longer), the Hessian update is the BFGS
+    formula, and the minimum is reached to 1e-8 eV/A in a few more steps than dimensions; FIRE stops every time the power
+    F.v turns negative and gets there too."""
+    from autoforce_amd.cl.relax import BFGS, FIRE, force_max
+
+    class Quad:
+        def __init__(self, A, x):
+            self.A, self.x = A, x.copy()
+        def get_positions(self):
+            return self.x.copy()
+        def set_positions(self, p):
+            self.x = np.asarray(p, float).copy()
+        def forces(self):
+            return -(self.A @ self.x.reshape(-1)).reshape(-1, 3)
+
+    rng = np.random.default_rng(3)
+    n = 4
+    B = rng.normal(size=(3 * n, 3 * n))
+    A = B @ B.T / (3 * n) + 20.0 * np.eye(3 * n)
+    x0 = 0.05 * rng.normal(size=(n, 3))
+    q = Quad(A, x0)
+    opt = BFGS(q)
+    f0 = q.forces()
+    opt.step(f0)
+    want = f0 / 70.0
+    longest = np.sqrt((want ** 2).sum(1)).max()
+    np.testing.assert_allclose(q.x - x0, want * min(1.0, 0.2 / longest), rtol=1e-12, atol=1e-15)
+    steps = 1
+    while force_max(q.forces()) > 1e-8 and steps < 60:
+        opt.step(q.forces())
+        steps += 1
+    assert force_max(q.forces()) <= 1e-8 and steps <= 40, steps
+    # the secant equation of the update: the new Hessian maps the last displacement onto the change of the gradient
+    q.set_positions(q.x + 0.01 * rng.normal(size=q.x.shape))
+    dpos, dgrad = q.x.reshape(-1) - opt.pos0, -(q.forces().reshape(-1)) + opt.forces0
+    opt.update(q.x.reshape(-1), q.forces().reshape(-1))
+    np.testing.assert_allclose(opt.H @ dpos, dgrad, rtol=1e-9, atol=1e-12)
+    q = Quad(A, x0)
+    fire = FIRE(q)
+    for k in range(4000):
+        if force_max(q.forces()) < 1e-6:
+            break
+        fire.step(q.forces())
+    assert force_max(q.forces()) < 1e-6, k
+
+
+def test_relax_driver_on_the_cpu_engine(tmp_path, monkeypatch):
+    """`relax` end to end on the CPU engine: an active calculator learns while the structure is minimised, the run stops at
+    fmax, the confirmation loop (cl/relax.py:59-70) asks the teacher for exact labels until `update_data(try_fake=False)`
+    declines, and the relaxed structure's EXACT forces are small too."""
+    from autoforce_amd.cl.relax import force_max, relax
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(11)
+    rng0, numbers, pos, cell = ac.start(0)
+    teacher = PairTeacher(rc=4.0)
+    calc = ActiveCalculator(engine=OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=teacher, logfile="active.log", pckl=None,
+                            tape=None, **ac.KW)
+    atoms = Atoms(numbers, pos, cell, True)
+    n_exact = relax(atoms, fmax=0.1, algo="BFGS", trajectory="relax.xyz", rattle=0.02, calc=calc, seed=5)
+    assert n_exact >= 1 and calc.size[0] >= 1
+    assert force_max(calc.results["forces"]) < 0.1
+    e_exact, f_exact = calc._test()
+    assert force_max(f_exact) < 0.35, force_max(f_exact)    # (the model is only as good as ediff / fdiff ask)
+    assert open("relax.xyz").read().count("Lattice=") >= 2
+    with pytest.raises(NotImplementedError):
+        relax(atoms, cell=True, calc=calc)
+    with pytest.raises(NotImplementedError):
+        relax(atoms, algo="LBFGS", calc=calc)
