@@ -242,3 +242,24 @@ def test_lammps_fix_external_callback_on_the_device(units):
         want = -convert(ref["stress"], "pressure", "ASE", units) / (NKTV2P[units] / vol)
         np.testing.assert_allclose(lmp.virial[1], want[[0, 1, 2, 5, 4, 3]], rtol=0, atol=1e-8 * np.abs(want).max())
     mdl.close()
+
+
+def test_relaxation_driver_on_the_device(tmp_path, monkeypatch):
+    """autoforce_amd.cl.relax (theforce/cl/relax.py) around the HIP engine: the model learns while BFGS minimises, the run
+    ends below fmax, the confirmation loop ends when update_data(try_fake=False) declines, and the teacher's own forces on
+    the relaxed structure are small too.  (The same driver on the CPU engine: tests/test_cl_cpu.py; the two engines under
+    the same host logic: test_learning_loop_matches_oracle_engine.)"""
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.cl.relax import force_max, relax
+    from helpers import PairTeacher
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(11)
+    rng0, numbers, pos, cell = ac.start(0)
+    calc = ActiveCalculator(engine=hip_engine(), calculator=PairTeacher(rc=4.0), logfile=None, pckl=None, tape=None, **ac.KW)
+    atoms = Atoms(numbers, pos, cell, True)
+    n_exact = relax(atoms, fmax=0.1, algo="BFGS", trajectory="relax.xyz", rattle=0.02, calc=calc, seed=5)
+    assert force_max(calc.results["forces"]) < 0.1 and n_exact >= 1 and calc.size[0] >= 1
+    e_exact, f_exact = calc._test()
+    assert force_max(f_exact) < 0.35, force_max(f_exact)
+    assert open("relax.xyz").read().count("Lattice=") >= 2
