@@ -16,8 +16,25 @@ from ..sgprio import Frame, format_extxyz, parse_extxyz
 from ..workloads import MASS
 
 
+def read_frames(path, r=None):
+    """The frames of an extended-XYZ file that ase.io.read(path, r) would return: r = None or an index: that ONE frame (None:
+    the last), r = 'start:stop:step': the slice."""
+    frames = _all_frames(path)
+    if r is None:
+        return [frames[-1]]
+    r = str(r)
+    if ":" not in r:
+        return [frames[int(r)]]
+    parts = [int(p) if p.strip() else None for p in (r.split(":") + ["", ""])[:3]]
+    return frames[slice(*parts)]
+
+
 def read_structure(path, index=-1):
     """Frame `index` of an extended-XYZ file."""
+    return _all_frames(path)[index]
+
+
+def _all_frames(path):
     lines = open(path).read().splitlines()
     frames, k = [], 0
     while k < len(lines):
@@ -29,7 +46,7 @@ def read_structure(path, index=-1):
         k += n + 2
     if not frames:
         raise ValueError(f"{path}: no frames")
-    return frames[index]
+    return frames
 
 
 def init_velocities(numbers, masses, temperature, rng, cm0=True):

@@ -148,3 +148,46 @@ def test_relax_driver_on_the_cpu_engine(tmp_path, monkeypatch):
         relax(atoms, cell=True, calc=calc)
     with pytest.raises(NotImplementedError):
         relax(atoms, algo="LBFGS", calc=calc)
+
+
+def test_train_and_test_drivers(tmp_path, monkeypatch):
+    """cl/train.py and cl/test.py: a learner's tape and its labelled frames (extended XYZ) train a fresh model through
+    include_tape / include_data, with `-r` read as the reference reads it; the test driver evaluates frames without a
+    teacher and writes energies and forces back; single_point is the last frame."""
+    from autoforce_amd.cl import md as mdmod
+    from autoforce_amd.cl import test as testmod
+    from autoforce_amd.cl import train as trainmod
+    from autoforce_amd.sgprio import Frame, format_extxyz
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "src").mkdir()
+    calc, teacher, trace = ac.run(OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), tmp_path / "src", steps=4)
+    # labelled frames as a trajectory file
+    with open("frames.xyz", "w") as f:
+        for tr in trace:
+            at = tr[5]
+            lab = Atoms(at.numbers, at.positions, at.cell, True)
+            lab.calc = PairTeacher(rc=4.0)
+            f.writelines(format_extxyz(Frame(at.numbers, at.positions, at.cell, at.pbc, lab.get_potential_energy(), lab.get_forces(), lab.get_stress())))
+    assert len(mdmod.read_frames("frames.xyz", "::2")) == 2 and len(mdmod.read_frames("frames.xyz", "1")) == 1
+    assert len(mdmod.read_frames("frames.xyz", None)) == 1 and len(mdmod.read_frames("frames.xyz", "1:")) == 3
+    fresh = ActiveCalculator(engine=OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=None, logfile="train.log", pckl=None,
+                             tape=None, **ac.KW)
+    fresh._calc = object()   # "active" without a live teacher: the labels come from the files
+    trainmod.train(str(tmp_path / "src" / "model.sgpr"), r="1", calc=fresh)
+    n_tape = fresh.size
+    assert n_tape[0] == 1 and n_tape[1] >= 2
+    trainmod.train("frames.xyz", r="::", calc=fresh)
+    assert fresh.size[0] >= n_tape[0] and fresh.size[1] >= n_tape[1]
+    with pytest.raises(RuntimeError, match="integer"):
+        trainmod.train(str(tmp_path / "src" / "model.sgpr"), r="::2", calc=fresh)
+    # evaluation only
+    probe = ActiveCalculator(covariance=fresh.model, logfile=None)
+    res = testmod.test("frames.xyz", r="::2", o="test.xyz", calc=probe)
+    assert len(res) == 2 and open("test.xyz").read().count("Lattice=") == 2
+    back = mdmod.read_frames("test.xyz", "0")[0]
+    np.testing.assert_allclose(back.forces, res[0][1], rtol=0, atol=1e-7)
+    e_last, f_last = testmod.single_point("frames.xyz", "sp.xyz", calc=probe)
+    assert abs(e_last - mdmod.read_frames("sp.xyz")[0].energy) < 1e-7
+    (tmp_path / "ARGS").write_text("calculator = 'PAIR'\n")
+    with pytest.raises(RuntimeError, match="calculator = None"):
+        testmod.test("frames.xyz")
