@@ -385,3 +385,48 @@ def test_handles_give_back_their_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < (4 << 20), (free0, free1)   # (six leaked MD states would be 8 MB; the driver hands out 2 MB pages)
+
+
+def test_a_capacity_outgrown_inside_the_device_loop_is_resized_and_the_run_goes_on():
+    """A cluster that contracts: the neighbour counts grow past the capacity the lists were allocated with WHILE the device
+    loop runs.  The step concerned flags the overflow, the run halts there (code 2), the next call re-sizes and repeats the
+    step — and the trajectory is the host loop's, bit for bit, as if nothing had happened."""
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.workloads import FS, inducing_from_frame, langevin_nvt, langevin_nvt_device, lips
+    numbers, pos, cell, pbc = lips(8, seed=0)
+    pos = (pos - pos.mean(0)) * (3.3 / 2.72)                 # 512 atoms, 3.3 A apart: ~25 neighbours inside 6 A
+    cell = np.eye(3) * 400.0
+    pbc = np.array([False, False, False])
+    species = sorted(set(int(z) for z in numbers))
+    mdl = SGPRModel(3, 3, 4, 6.0, species=species)
+    mdl.set_inducing(inducing_from_frame(mdl, numbers, pos, cell, pbc, 24, seed=1))
+    rng = np.random.default_rng(2)
+    mdl.solve(rng.normal(size=(40, 24)), rng.normal(size=40))
+    mdl.set_weights(1e-4 * rng.normal(size=24), choli=mdl.choli, vscale=mdl.make_vscale())   # (nearly ballistic motion)
+    steps = 60
+    vel = -pos * (0.30 / (steps * FS))                        # homogeneous contraction by 30 % over the run: ~75 neighbours
+    nn0 = np.diff(mdl.neighbors(len(numbers))[0]).max() if mdl.predict(numbers, pos, cell, pbc) else 0
+    calc = _PredictCalc(mdl)
+    host = [(s, E, p.copy(), v.copy()) for s, E, T, w, p, v in
+            langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=0.0, dt_fs=1.0, friction=0.0, seed=3, vel=vel)]
+    nn1 = np.diff(mdl.neighbors(len(numbers))[0]).max()
+    assert nn0 < 64 < nn1, (nn0, nn1)                         # the run crosses the initial capacity of 64 neighbours
+    # a fresh handle (capacities as allocated for the START frame) runs the same trajectory on the device
+    dev_mdl = SGPRModel(3, 3, 4, 6.0, species=species)
+    dev_mdl.set_inducing(mdl.X)
+    dev_mdl.set_weights(mdl.mu, choli=mdl.choli, vscale=mdl.make_vscale())
+    codes = []
+    real_run = dev_mdl.md_run
+    def spy(*a, **k):
+        sc, code = real_run(*a, **k)
+        codes.append(code)
+        return sc, code
+    dev_mdl.md_run = spy
+    dev = list(langevin_nvt_device(dev_mdl, numbers, pos, cell, pbc, steps, temperature=0.0, dt_fs=1.0, friction=0.0, seed=3, vel=vel, chunk=16))
+    assert 2 in codes, codes                                  # at least one call ended on an outgrown capacity
+    assert len(dev) == len(host) == steps + 1
+    for (s0, E0, _, _), (s1, E1, T1, bmax) in zip(host, dev):
+        assert s0 == s1 and E0 == E1, (s0, E0, E1)
+    st = dev_mdl.md_state(results=True)
+    assert np.array_equal(st["positions"], host[-1][2]) and np.array_equal(st["velocities"], host[-1][3])
+    mdl.close(); dev_mdl.close()
