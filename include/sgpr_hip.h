@@ -280,6 +280,8 @@ int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell
  * step bins them and takes the rebuild decision of the next step's neighbour candidates, so the next call — which must
  * pass exactly `positions_next_dev` — starts with the list filter instead of a binning launch (6 -> 5 launches per
  * step).  A call that passes anything else is served as usual.  positions_next_dev = NULL: sgpr_step_dev.
+ * The next step is binned with the cell AS IT IS NOW: a driver that changes the contents of `cell_dev` between two steps
+ * (NPT) passes NULL for the step in front of the change — every step of such a run bins for itself.
  * (The reference asks ASE for a fresh list inside every calculate(), descriptor/atoms.py:348-363, :402.)
  */
 int sgpr_step_dev_next(sgpr_model *h, const double *positions_dev, const double *cell_dev,
