@@ -191,3 +191,18 @@ def test_train_and_test_drivers(tmp_path, monkeypatch):
     (tmp_path / "ARGS").write_text("calculator = 'PAIR'\n")
     with pytest.raises(RuntimeError, match="calculator = None"):
         testmod.test("frames.xyz")
+
+
+def test_init_model_driver(tmp_path, monkeypatch):
+    """cl/init_model.py: rattled copies of one structure seed and grow a model; the trajectory holds them with results."""
+    from autoforce_amd.cl.init_model import init_model
+    from autoforce_amd.cl.md import read_frames
+    monkeypatch.chdir(tmp_path)
+    np.random.seed(5)
+    rng0, numbers, pos, cell = ac.start(0)
+    calc = ActiveCalculator(engine=OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=PairTeacher(rc=4.0), logfile=None, pckl=None,
+                            tape=None, **ac.KW)
+    init_model(Atoms(numbers, pos, cell, True), samples=3, rattle=0.05, trajectory="init.xyz", calc=calc, seed=1)
+    assert calc.size[0] >= 1 and calc.size[1] >= 2 and calc.step == 3
+    frames = read_frames("init.xyz", "::")
+    assert len(frames) == 3 and frames[0].forces is not None and np.abs(frames[0].positions - pos).max() > 1e-3
