@@ -191,6 +191,15 @@ def test_train_and_test_drivers(tmp_path, monkeypatch):
     (tmp_path / "ARGS").write_text("calculator = 'PAIR'\n")
     with pytest.raises(RuntimeError, match="calculator = None"):
         testmod.test("frames.xyz")
+    # cl/offline.py: the same walk over stored frames with a live teacher — the model learns from what it is unsure of
+    from autoforce_amd.cl.offline import offline
+    learner = ActiveCalculator(engine=OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=PairTeacher(rc=4.0), logfile=None,
+                               pckl=None, tape=None, **ac.KW)
+    res = offline("frames.xyz", r="::", o="offline.xyz", calc=learner)
+    assert len(res) == 4 and learner.size[0] >= 1 and open("offline.xyz").read().count("Lattice=") == 4
+    (tmp_path / "ARGS").write_text("calculator = None\n")
+    with pytest.raises(RuntimeError, match="set a calculator"):
+        offline("frames.xyz")
 
 
 def test_init_model_driver(tmp_path, monkeypatch):
