@@ -64,3 +64,29 @@ def test_sharded_learning_loop_two_ranks_one_gpu(tmp_path):
         assert comm_world == 1
     assert "host-side all-reduce instead" in got[0][6]
     np.testing.assert_array_equal(got[0][4], got[1][4])
+
+
+def test_bench_two_ranks_on_one_gpu_dry_run():
+    """`bench.py --gpus 2` launched as the driver launches it (torch.distributed.run, one rank per process), both ranks on
+    the one GPU of the test box with the host-side collective (`--collective torch`: RCCL refuses two ranks on a device):
+    the sharded path of the benchmark runs end to end and rank 0 prints ONE line with the whole-job value, `scaling`
+    "strong" (the frame does not grow with N) and one `per_rank` record per rank.  (The numbers mean nothing on a shared GPU.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + ((os.getpid() + 37) % 300)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10",
+                          "--warmup", "3", "--collective", "torch", "--no-cpu-baseline", "--no-big-wall", "--md-steps", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "strong"
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert len(d["per_rank"]) == 2 and sorted(r["rank"] for r in d["per_rank"]) == [0, 1]
+    assert all(r["local_atoms"] == 2048 for r in d["per_rank"])
+    assert "x2" in d["config"]["parallelism"]
