@@ -8,9 +8,10 @@ updates inside a 1000-step NVT run) with a stand-in teacher.
 * calculator: autoforce_amd.calculator.ActiveCalculator (the reference's ActiveCalculator surface);
 * teacher: a smooth pair potential evaluated in numpy on the device's own neighbour list (a real
   run passes any ASE calculator: VASP, GPAW, ...);
-* integrator: BAOAB Langevin in numpy with the parameters of the reference's driver
-  (cl/md.py:31,70-74: dt = 1 fs, friction 1e-3, T = 600 K; Maxwell-Boltzmann start as
-  util/aseutil.py:11-20).  With ASE installed, ase.md.langevin.Langevin drives the same calculator.
+* integrator: BAOAB Langevin with the parameters of the reference's driver (cl/md.py:31,70-74: dt = 1 fs, friction 1e-3,
+  T = 600 K; Maxwell-Boltzmann start as util/aseutil.py:11-20) on the device loop (ActiveCalculator.run_md: the state stays
+  in HBM between model updates); --host-loop: the same scheme in numpy, one calculate() per step.  With ASE installed,
+  ase.md.langevin.Langevin drives the same calculator.
 The system is an ordered two-species rocksalt-type lattice (2.72 A nearest-neighbour distance,
 rattled): its environments repeat, so the seed set stays small — a random alloy would make every
 LCE unique under the reference's 0.95 similarity seed rule (active.py:631-654).
@@ -93,6 +94,8 @@ def main():
     ap.add_argument("--fdiff", type=float, default=0.129)
     ap.add_argument("--ioptim", type=int, default=1)
     ap.add_argument("--out", default="gpurun_out/md_otf")
+    ap.add_argument("--host-loop", action="store_true", help="integrate in numpy, one calculate() per step (the driver of rounds 1-3); "
+                    "default: ActiveCalculator.run_md — positions and velocities stay in device memory between model updates")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     species = [3, 9]
@@ -121,10 +124,25 @@ def main():
         return at.get_forces(), at.get_potential_energy()
 
     t_all = time.time()
-    F, E = forces(pos, vel)
     rows = []
-    print(f"# {N} atoms, seed model {calc.size}, first step {time.time() - t_all:.2f} s (teacher {teacher.seconds:.2f} s)")
-    for step in range(1, args.steps + 1):
+    if not args.host_loop:
+        # the same scheme on the device loop: the run halts where a step's largest covloss asks for sampling, that step goes
+        # through calculate() (teacher, updates, log), and the run goes on with the new model
+        at = Atoms(numbers, pos, cell, pbc, velocities=vel, masses=mass[:, 0])
+        tcalls, tsec = teacher.calls, teacher.seconds
+        for step, E, T, updated, wall in calc.run_md(at, args.steps, args.temperature, dt_fs=args.dt, friction=args.friction, rng=None,
+                                                     chunk=64, seed=1):
+            if step == 0:
+                print(f"# {N} atoms, seed model {calc.size}, first step {time.time() - t_all:.2f} s (teacher {teacher.seconds:.2f} s)")
+            else:
+                rows.append((step, wall, teacher.seconds - tsec, teacher.calls - tcalls, calc.size, updated))
+                print(f"{step:5d} E={E:14.6f} T={T:7.1f} size={calc.size} wall={wall * 1e3:8.1f} ms "
+                      f"teacher={1e3 * (teacher.seconds - tsec):7.1f} ms", flush=True)
+            tcalls, tsec = teacher.calls, teacher.seconds
+    else:
+        F, E = forces(pos, vel)
+        print(f"# {N} atoms, seed model {calc.size}, first step {time.time() - t_all:.2f} s (teacher {teacher.seconds:.2f} s)")
+    for step in range(1, args.steps + 1 if args.host_loop else 0):
         t0 = time.time()
         tcalls, tsec = teacher.calls, teacher.seconds
         vel += 0.5 * dt * F / mass
