@@ -76,6 +76,9 @@ SIGNATURES = {
     "sgpr_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "sgpr_comm_destroy": (C.c_int, [_vp]),
     "sgpr_comm_allreduce": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp]),
+    "sgpr_peer_export": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _vp]),
+    "sgpr_peer_attach": (C.c_int, [_vp, _vp]),
+    "sgpr_peer_destroy": (C.c_int, [_vp]),
     "sgpr_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "sgpr_get_list_rebuilds": (C.c_int, [_vp, _vp]),
     "sgpr_solve_info": (C.c_int, [_vp, _vp, C.c_int]),

@@ -112,6 +112,7 @@ class ActiveCalculator(Calculator):
         self.step = 0
         self._wildcard = False
         self._comm_note, self._hello = "", False
+        self._peer_atoms = 0
         self.get_model(engine if engine is not None else covariance, kernel_kw or {})
         self.ediff = ediff
         self.ediff_lb = ediff_lb or ediff
@@ -185,6 +186,14 @@ class ActiveCalculator(Calculator):
         rank, world = self._dist()
         if world < 2:
             return
+        # SGPR_COLLECTIVE = auto (default): the library's own exchange through hipIpc-mapped buffers (deterministic sums, runs
+        # with several ranks on one device, the device MD loop can run sharded on it), else RCCL, else the host-side
+        # all-reduce; ipc / rccl / host: only that one (and the host-side all-reduce behind it)
+        mode = os.environ.get("SGPR_COLLECTIVE", "auto")
+        if mode in ("auto", "ipc") and hasattr(eng, "peer_export") and self._attach_peer(max(self._peer_atoms, 4096)):
+            return
+        if mode in ("ipc", "host"):
+            return
         # every rank takes the same branch: the outcome is agreed on (MIN over ranks) before anybody evaluates.  A rank
         # that cannot build the communicator (RCCL missing; two ranks on one device — RCCL refuses duplicate GPUs)
         # must not leave the others inside ncclCommInitRank: the id travels first, the attempt is made by all, and on
@@ -218,6 +227,42 @@ class ActiveCalculator(Calculator):
                 self._comm_note = "native communicator not built on another rank: host-side all-reduce instead"
         if self._comm_note and self._hello:
             self.log(self._comm_note)
+
+    def _attach_peer(self, atoms_cap):
+        """The library's own exchange (SGPRModel.peer_export / peer_attach) for frames of up to `atoms_cap` atoms: every rank
+        exports its receive buffers, the handles travel over the process group, everybody maps everybody's.  The outcome is
+        agreed on (MIN over the ranks): all attached, or nobody."""
+        import torch
+        import torch.distributed as dist
+        eng = self.model.engine
+        rank, world = self._dist()
+        ok, blob, why = 1, None, ""
+        try:
+            blob = eng.peer_export(rank, world, 7 * int(atoms_cap) + 11)
+        except Exception as exc:  # noqa: BLE001
+            ok, why = 0, str(exc)
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob, group=self.process_group)
+        if ok and all(b is not None for b in blobs):
+            try:
+                eng.peer_attach(blobs)
+            except Exception as exc:  # noqa: BLE001
+                ok, why = 0, str(exc)
+        else:
+            ok = 0
+        flag = torch.tensor([ok])
+        if dist.get_backend(self.process_group) == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
+        if int(flag.item()) == 0:
+            if blob is not None:
+                eng.peer_destroy()
+            self._comm_note = f"the library's own exchange was not built ({why or 'another rank failed'})"
+            if self._hello:
+                self.log(self._comm_note)
+            return False
+        self._peer_atoms = int(atoms_cap)
+        return True
 
     @property
     def engine(self):
@@ -274,6 +319,8 @@ class ActiveCalculator(Calculator):
         if not (engine.m > 0 and engine.mu is not None):
             # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
             return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf), ready=False)
+        if world > 1 and getattr(engine, "peer_world", 1) == world and N > self._peer_atoms and engine is self.engine:
+            self._attach_peer(2 * N)   # (a larger frame than the exchange buffers hold: every rank sees the same N)
         out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=False, beta=True)
         if world > 1 and getattr(engine, "comm_world", 1) == world:
             pass  # the library's own RCCL all-reduce already combined the ranks (totals on every rank)
@@ -409,8 +456,11 @@ class ActiveCalculator(Calculator):
         """The device loop replaces calculate() only where calculate() does nothing the device cannot see: a
         single process, no periodic test, no meta-dynamics hook, no force veto, one bead."""
         eng = self.engine
-        return (hasattr(eng, "md_run") and self._dist()[1] == 1 and not self.test and self.meta is None
-                and "forces" not in self._veto and self.nbeads == 1 and eng.m > 0 and eng.mu is not None)
+        world = self._dist()[1]
+        # (several ranks: only over the library's own exchange — every rank then integrates all atoms from the summed
+        # forces and halts at the same step, sgpr_md_run)
+        return (hasattr(eng, "md_run") and (world == 1 or getattr(eng, "peer_world", 1) == world) and not self.test
+                and self.meta is None and "forces" not in self._veto and self.nbeads == 1 and eng.m > 0 and eng.mu is not None)
 
     def _md_gate(self, numbers):
         """The smallest covloss at which calculate() would do more than log (update_lce, active.py:806-839): below
@@ -460,7 +510,8 @@ class ActiveCalculator(Calculator):
             if not self.md_on_device_ok():
                 for st, E, T, _, p, v in langevin_nvt(self, numbers, pos, cell, pbc, steps, temperature_K, dt_fs, friction, vel=vel,
                                                       rng=rng):
-                    atoms.positions, atoms._velocities = p, v
+                    atoms.positions = p
+                    atoms.set_velocities(v)
                     yield st, E, T, bool(self.updated), _
                 return
         eng = self.engine
@@ -499,7 +550,8 @@ class ActiveCalculator(Calculator):
             if sync_every and out and out[-1][0] % sync_every == 0 and code != 1:
                 # the configuration of the batch's last row: the device has moved on to the next one unless the run is over
                 st = eng.md_state(which=0 if final else -1)
-                atoms.positions, atoms._velocities = st["positions"], st["velocities_pre"]
+                atoms.positions = st["positions"]
+                atoms.set_velocities(st["velocities_pre"])
             yield from out
             rows = rows[accepted:]
             batch = min(8, chunk) if code else min(2 * batch, chunk)
@@ -507,14 +559,15 @@ class ActiveCalculator(Calculator):
                 t_host = time.time()
                 st = eng.md_state(results=True)
                 atoms.positions = st["positions"]
-                atoms._velocities = st["velocities_pre"]   # what the integrator holds when it asks for forces
+                atoms.set_velocities(st["velocities_pre"])   # what the integrator holds when it asks for forces
                 atoms.calc = self
                 self.results = {}
                 self.calculate(atoms)        # update_results + update + the log line, as inside an ASE loop
                 skip_gate = True
                 t_host = time.time() - t_host
         st = eng.md_state(results=True)
-        atoms.positions, atoms._velocities = st["positions"], st["velocities"]
+        atoms.positions = st["positions"]
+        atoms.set_velocities(st["velocities"])
 
     def _log_lines(self, lines):
         """A batch of per-step lines in one open (a device loop produces them by the hundred)."""

@@ -14,6 +14,7 @@
 #include <numeric>
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>  // types only: librccl is opened on the first sgpr_comm_* call (single-GPU installs need none)
 
 #include "../../include/sgpr_hip.h"
@@ -113,12 +114,47 @@ struct DevBuf {
         n = 0;
     }
 };
+// a DevBuf that is a LOCAL of one entry point: given back on every way out of the scope (the members of the handle have
+// no destructor on purpose: sgpr_destroy releases them in its own order)
+template <typename T>
+struct ScopedBuf : DevBuf<T> {
+    ScopedBuf() = default;
+    ScopedBuf(const ScopedBuf &) = delete;
+    ScopedBuf &operator=(const ScopedBuf &) = delete;
+    ~ScopedBuf() { this->release(); }
+};
+
+// The library's own exchange between the ranks of ONE node (peer.inc): every rank owns a receive buffer
+// recv[2][world][cap] (two epochs' parities x one slice per source rank) and one flag per source rank, exported through
+// hipIpcGetMemHandle and mapped by every peer; a step's partial sums are PUSHED into the slice `rank` of every peer (posted
+// writes over xGMI: an all-gather in one hop on the fully connected mesh), released with one flag store per peer, and summed
+// locally in rank order — the same bits on every rank, whatever the arrival order.
+#define SGPR_PEER_MAX 16
+struct PeerXchg {
+    int world = 1, rank = 0;
+    bool attached = false;
+    size_t cap = 0;                        // doubles per slice
+    size_t bytes = 0, flag_off = 0;
+    char *base = nullptr;                  // own allocation: recv | flags
+    char *peer_base[SGPR_PEER_MAX] = {};   // every rank's allocation as mapped here (own: base)
+    bool opened[SGPR_PEER_MAX] = {};       // mapped through hipIpcOpenMemHandle (to be closed)
+    unsigned epoch = 0;                    // exchanges so far (the same on every rank: exchanges are collective)
+    DevBuf<int> ctl;                       // [SGPR_PEER_MAX + 2] lines of 32 ints: push counters per peer | error word | dead word
+    long long timeout_ticks = 200000000LL; // bounded spin of the wait kernel (100 MHz ticks; SGPR_PEER_TIMEOUT_MS)
+    const double *slice(int parity, int r) const { return (const double *)base + ((size_t)parity * world + r) * cap; }
+};
 
 // device-resident molecular dynamics (sgpr_md_*): positions / velocities / results of the last three evaluations in
 // rings (sorted atom order), see FinNext
 struct MdState {
     bool active = false;
     int N = 0;
+    // the system the run was begun on: another evaluation on the handle in between (a model update computes training rows
+    // of stored frames, trial models rebind) leaves the handle bound to something else — sgpr_md_run binds it back
+    std::vector<int32_t> numbers;
+    std::vector<int> perm;          // sorted -> caller of THAT system (sgpr_md_state does not depend on the binding)
+    int32_t pbc[3] = {1, 1, 1};
+    int rank = 0, world = 1;
     long long t = 0;               // evaluations completed (= index of the configuration to evaluate next)
     double hdt = 0.0, c1 = 1.0, dt = 0.0;
     unsigned long long seed = 0;   // != 0: the integrator draws its own deviates (sgpr_md_seed)
@@ -141,6 +177,8 @@ struct sgpr_model {
     // all-reduce enqueued on the step's stream (sgpr_comm_init)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    PeerXchg peer;                 // the hipIpc all-gather exchange (sgpr_peer_*): preferred over RCCL when attached
+    DevBuf<double> d_xpacked;      // a sharded step's partial sums in the exchange layout (peer.inc)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // packed layout
     int D, Dc, Dpad, CS;
@@ -200,6 +238,8 @@ struct sgpr_model {
     unsigned pre_step = 0;
     bool fuse_next = true;           // option "fuse_next" (SGPR_FUSE_NEXT=0 at creation): off = every step bins for itself
     bool bin_identity = false;       // the positions handed to the binning kernel are in sorted order already (MD state)
+    bool reduce_done = false;        // the step just enqueued has combined the ranks' partial sums itself (shard_next_kernel)
+    bool force_scatter = false;      // option "reverse_scatter": the scatter form of the reverse pass on a single rank too
     MdState md;
     bool gather_ok = true;   // false: bin capacity / list length beyond the reverse-index format -> scatter form
     DevBuf<double> d_prec, d_G;
@@ -435,6 +475,8 @@ struct FinArgs {
                                                     // column, the lists' code words (neighbour species in bits 24..31)
     size_t g_stride, f_stride, v_stride, p_stride;  // batch (blockIdx.y, training rows): doubles between entries of
                                                     // G, [Fnbr | Fself], virpart, packed
+    int xp;                     // scatter form: `packed` has the EXCHANGE layout (peer.inc): [fixed-point sums 3N | own part 3N | beta N | scalars 11]
+    size_t scal_off;            // where the eleven scalars start in `packed` (4N; exchange layout: 7N)
     const int *flag;            // this step's rebuild flag: set -> the candidates were rebuilt from `pos`
     int *rebuilds;              // running count of rebuilds
     const double *pos;          // [N][3] sorted order
@@ -535,7 +577,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
             // packed[4N+10]: 1 when this rank's step overflowed a capacity (its results are invalid); summed
             // over ranks by the all-reduce, so every rank learns that the step must be repeated
             const bool ov = mx > f.maxnn || f.stat[1] > f.bin_cap || (f.t_check && f.stat[2] > f.t_stride) || f.stat[3] != 0;
-            f.packed[4 * (size_t)f.N + 10] = ov ? 1.0 : 0.0;
+            f.packed[f.scal_off + 10] = ov ? 1.0 : 0.0;
             if (f.nx.mode == 2) {
                 f.nx.scal_cur[10] = ov ? 1.0 : 0.0;
                 *f.nx.mark_cur = 1;
@@ -546,7 +588,7 @@ __device__ __forceinline__ void finalize_reduce(const FinArgs &f, int q)
             }
         } else if (q != 10) {
             const double v = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + (q == 0 ? f.mean_energy : 0.0);
-            f.packed[by * f.p_stride + 4 * (size_t)f.N + q] = v;
+            f.packed[by * f.p_stride + f.scal_off + q] = v;
             if (f.nx.mode == 2) f.nx.scal_cur[q] = v;
         }
     }
@@ -623,10 +665,20 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
             for (int k = 0; k < 3; k++) f.pos0[3 * i + k] = f.pos[3 * i + k];
         }
         double *packed = f.packed + by * f.p_stride;
+        if (f.xp) {
+            // exchange layout: the fixed-point sums travel as INTEGERS and are added as integers over the ranks (peer.inc):
+            // the total force is then the same bits for every number of ranks
 #pragma unroll
-        // (the scattered part is a fixed-point integer sum: order-independent, sgpr_internal.h)
-        for (int k = 0; k < 3; k++)
-            packed[3 * c + k] = (double)((const long long *)f.Fnbr)[by * f.f_stride + 3 * i + k] * (1.0 / SGPR_FIX_SCALE) + f.Fself[by * f.f_stride + 3 * i + k];
+            for (int k = 0; k < 3; k++) {
+                ((long long *)packed)[3 * (size_t)c + k] = ((const long long *)f.Fnbr)[3 * (size_t)i + k];
+                packed[3 * (size_t)f.N + 3 * (size_t)c + k] = f.Fself[3 * (size_t)i + k];
+            }
+        } else {
+            // (the scattered part is a fixed-point integer sum: order-independent, sgpr_internal.h)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                packed[3 * c + k] = (double)((const long long *)f.Fnbr)[by * f.f_stride + 3 * i + k] * (1.0 / SGPR_FIX_SCALE) + f.Fself[by * f.f_stride + 3 * i + k];
+        }
         double bt = 0.0;
         const int il = (i - f.first) / f.stride;
         if (f.has_beta && i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt) {
@@ -635,7 +687,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
             const double v = 1.0 - cs;
             bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
         }
-        packed[3 * f.N + c] = bt;
+        packed[(f.xp ? 6 : 3) * (size_t)f.N + c] = bt;
     }
 }
 
@@ -1273,6 +1325,8 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     h->d_b_aux.release();
     h->d_grid.release();
     if (h->comm) (void)g_rccl.CommDestroy(h->comm);
+    (void)sgpr_peer_destroy(h);
+    h->d_xpacked.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -1900,12 +1954,14 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     h->d_nbr_shift.release();
     h->d_T.release();
     h->t_stride = 0;
-    h->gather_ok = true;
+    h->gather_ok = !h->force_scatter;
     h->warm = false;
     return alloc_work(h);
 }
 
 extern "C" int64_t sgpr_packed_len(int N) { return 4 * (int64_t)N + 11; }
+
+#include "peer.inc"
 
 // ---------------------------------------------------------------------------- one step
 static void stamp(sgpr_model *h, const char *name, hipStream_t st)
@@ -1936,10 +1992,11 @@ struct StepNext {
 
 static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool beta, double mean_energy,
                             double *packed_dev, hipStream_t st, const FinBatch *fb = nullptr, const StepNext *nx = nullptr,
-                            unsigned step = 0)
+                            unsigned step = 0, bool xp = false, const ShardSrc *consume = nullptr)
 {
     const int N = h->N;
     FinArgs f = {};
+    f.xp = xp ? 1 : 0; f.scal_off = (xp ? 7 : 4) * (size_t)N;
     f.N = N; f.cnt = h->cnt; f.first = h->rank; f.stride = h->world; f.maxnn = h->maxnn; f.t_stride = h->t_stride;
     f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV; f.bin_cap = h->bin_cap; f.nbins_clear = 4096;
     f.t_check = (h->world == 1 && h->gather_ok) ? 1 : 0;
@@ -1974,6 +2031,13 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
         x.bin_of = h->d_bin_of.p; x.kslot = h->d_kslot.p; x.b_rec = h->d_b_rec.p; x.b_aux = h->d_b_aux.p;
         x.csq_rw = h->d_csq.p;
         const dim3 grid((std::max(N, 1) + 3) / 4 + 13);
+        if (consume) {
+            // the consumer of a sharded step's exchange (peer.inc): totals, the next positions, the next step's bins
+            const dim3 gs((std::max(N, 1) + 63) / 64 + 3);
+            if (nx->mode == 1) hipLaunchKernelGGL(shard_next_kernel<1>, gs, dim3(256), 0, st, f, *consume);
+            else hipLaunchKernelGGL(shard_next_kernel<2>, gs, dim3(256), 0, st, f, *consume);
+            return;
+        }
         if (!gather) {
             x.csq_rw = h->d_csq.p;
             hipLaunchKernelGGL(finalize_scatter_next_kernel, dim3((std::max(N, 1) + 255) / 256 + 11), dim3(256), 0, st, f);
@@ -1988,7 +2052,7 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
 }
 
 static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell_dev, double *packed_dev,
-                        hipStream_t st, const StepNext *nx = nullptr)
+                        hipStream_t st, const StepNext *nx = nullptr, bool no_exchange = false)
 {
     const int N = h->N, cnt = h->cnt;
     h->last_cell = cell_dev;
@@ -2122,14 +2186,41 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     // is not sharded and nothing of the step ran on a side stream
     // (frames: also the scatter form of a sharded rank, whose all-reduce follows on the same stream; the integrator only in
     // the single-rank gather form)
-    const bool fuse = nx && nx->mode && h->fuse_next && predict && !forked && !h->use_graph && h->skin > 0.0 &&
-                      ((gather && h->comm == nullptr) || (nx->mode == 1 && !gather && h->world > 1));
+    // With the library's own exchange attached (peer.inc) a sharded step leaves its partial sums in the exchange layout; and
+    // when the next positions are known, the exchange and its consumer — totals, integrator or next frame, next bins — run
+    // here (shard_next_kernel): the caller's reduce_packed finds nothing left to do.  A scatter-form step of a SINGLE rank
+    // takes the same consumer with its own partial sums as the one slice (frames the gather form cannot serve; the twin a
+    // sharded run is compared with bit for bit).
+    const bool px = peer_on(h) && h->world > 1;
+    const bool can_next = nx && nx->mode && h->fuse_next && predict && !forked && !h->use_graph && h->skin > 0.0;
+    const bool shard_next = can_next && !gather && (px || (nx->mode == 2 && h->world == 1)) && !no_exchange;
+    const bool fuse = can_next && !shard_next &&
+                      ((gather && h->comm == nullptr) || (nx->mode == 1 && !gather && h->world > 1 && !px));
+    const bool xp = !gather && (px || shard_next);
+    const size_t xlen = peer_xlen(N);
+    if (xp && h->d_xpacked.n < xlen + 1 && h->d_xpacked.alloc(xlen + 1)) return fail(SGPR_E_NODEVICE, "hipMalloc failed (exchange buffer)");
     launch_finalize(h, gather && predict, predict ? (fused3 ? 4 * (int)h->t_knm.n : h->epart_len) : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
-                    packed_dev, st, nullptr, fuse ? nx : nullptr, step);
-    if (fuse) {
+                    xp ? h->d_xpacked.p : packed_dev, st, nullptr, fuse ? nx : nullptr, step, xp);
+    h->reduce_done = false;
+    if (shard_next) {
+        stamp(h, "finalize", st);
+        ShardSrc src;
+        src.base = h->d_xpacked.p; src.n = 1; src.stride = 0;
+        if (px) {
+            int parity = 0;
+            const int *halt = nx->mode == 2 ? nx->md.halt : nullptr;
+            const int re = peer_exchange(h, h->d_xpacked.p, xlen, st, &parity, halt, (int)step);
+            if (re) return re;
+            src = peer_src(h->peer, parity);
+            stamp(h, "exchange", st);
+        }
+        launch_finalize(h, false, 0, 0, beta, h->mean_energy, packed_dev, st, nullptr, nx, step, false, &src);
+        h->reduce_done = true;
+    }
+    if (fuse || shard_next) {
         h->pre_valid = true; h->pre_pos = nx->pos_next; h->pre_cell = cell_dev; h->pre_step = step + 1;
     }
-    stamp(h, fuse ? "finalize_bin_next" : "finalize", st);
+    stamp(h, shard_next ? "sum_bin_next" : fuse ? "finalize_bin_next" : "finalize", st);
     return SGPR_OK;
 }
 
@@ -2153,7 +2244,7 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
         HIPCHK(hipMemsetAsync(h->d_stat.p, 0, 4 * sizeof(int), st));
         HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
         h->pre_valid = false;
-        const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st);
+        const int rc_ = enqueue_step(h, pos_dev, cell_dev, packed_dev, st, nullptr, true);   // (local attempts: the ranks' ONE exchange follows)
         if (rc_) return rc_;
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
@@ -2208,6 +2299,20 @@ static int run_checked(sgpr_model *h, const double *pos_dev, const double *cell_
 // (replaces the reference's four MPI collectives, calculator/active.py:562,601,602,777)
 static int reduce_packed(sgpr_model *h, double *packed_dev, hipStream_t st)
 {
+    if (h->reduce_done) { h->reduce_done = false; return SGPR_OK; }   // (the step's own consumer kernel has: enqueue_step)
+    if (peer_on(h)) {
+        // the library's own exchange (peer.inc): the step's last kernel left the partial sums in the exchange layout
+        if (h->world == 1) return SGPR_OK;   // a replicated evaluation (below)
+        if (h->peer.world != h->world || h->peer.rank != h->rank)
+            return fail(SGPR_E_INVALID, "the bound sharding (rank %d of %d) differs from the exchange's (rank %d of %d)",
+                        h->rank, h->world, h->peer.rank, h->peer.world);
+        int parity = 0;
+        const int re = peer_exchange(h, h->d_xpacked.p, peer_xlen(h->N), st, &parity);
+        if (re) return re;
+        hipLaunchKernelGGL(peer_sum_xp_kernel, dim3(std::min(256, (4 * std::max(h->N, 1) + 11 + 255) / 256)), dim3(256), 0, st,
+                           peer_src(h->peer, parity), h->N, packed_dev);
+        return SGPR_OK;
+    }
     if (!h->comm) return SGPR_OK;  // no communicator attached: the caller combines the partial sums
     // an unsharded bind (rank 0 of 1) under a multi-rank communicator is a REPLICATED evaluation: every rank holds
     // the totals of the whole frame already (initiate_model / get_unique_lces / training rows evaluate whole frames
@@ -2267,9 +2372,18 @@ extern "C" int sgpr_comm_destroy(sgpr_model *h)
 extern "C" int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_max, void *stream)
 {
     if (!h || !buf_dev || count < 0) return fail(SGPR_E_INVALID, "sgpr_comm_allreduce: bad arguments");
-    if (!h->comm) return fail(SGPR_E_INVALID, "sgpr_comm_allreduce: no communicator (sgpr_comm_init)");
+    if (!h->comm && !peer_on(h)) return fail(SGPR_E_INVALID, "sgpr_comm_allreduce: no communicator (sgpr_comm_init / sgpr_peer_attach)");
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (peer_on(h)) {
+        if (count == 0) return SGPR_OK;
+        int parity = 0;
+        const int re = peer_exchange(h, buf_dev, (size_t)count, st, &parity);
+        if (re) return re;
+        hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)std::min<int64_t>(256, (count + 255) / 256)), dim3(256), 0, st,
+                           peer_src(h->peer, parity), (size_t)count, op_max, buf_dev);
+        return SGPR_OK;
+    }
     const ncclResult_t r = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, op_max ? ncclMax : ncclSum, h->comm, st);
     if (r != ncclSuccess) return fail(SGPR_E_NODEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(r));
     return SGPR_OK;
@@ -2295,13 +2409,19 @@ static void poison_peers(sgpr_model *h, int N)
 {
     h->warm = false;
     h->lists_valid = false;
-    if (!(h->comm && h->world > 1)) return;
+    if (!((h->comm || peer_on(h)) && h->world > 1)) return;
     char keep[sizeof(g_err)];
     memcpy(keep, g_err, sizeof(keep));
     static const double poison = SGPR_PEER_POISON;
     const size_t n_out = (size_t)4 * N + 11;
-    if (hipMemsetAsync(h->d_packed.p, 0, sizeof(double) * n_out, h->stream) == hipSuccess &&
-        hipMemcpyAsync(h->d_packed.p + 4 * (size_t)N + 10, &poison, sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+    h->reduce_done = false;
+    // (the exchange layout has its overflow word at 7N + 10; the all-reduce combines the packed layout itself)
+    double *buf = peer_on(h) ? h->d_xpacked.p : h->d_packed.p;
+    const size_t n_buf = peer_on(h) ? peer_xlen(N) : n_out;
+    if (peer_on(h) && h->d_xpacked.n < n_buf + 1 && h->d_xpacked.alloc(n_buf + 1)) { memcpy(g_err, keep, sizeof(keep)); return; }
+    buf = peer_on(h) ? h->d_xpacked.p : h->d_packed.p;
+    if (hipMemsetAsync(buf, 0, sizeof(double) * n_buf, h->stream) == hipSuccess &&
+        hipMemcpyAsync(buf + n_buf - 1, &poison, sizeof(double), hipMemcpyHostToDevice, h->stream) == hipSuccess &&
         reduce_packed(h, h->d_packed.p, h->stream) == SGPR_OK)
         (void)hipStreamSynchronize(h->stream);
     memcpy(g_err, keep, sizeof(keep));
@@ -2526,14 +2646,21 @@ extern "C" int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const
         return fail(SGPR_E_INVALID, "sgpr_md_begin: bad arguments");
     if (!(dt > 0.0) || friction < 0.0 || kT < 0.0) return fail(SGPR_E_INVALID, "sgpr_md_begin: dt > 0, friction >= 0, kT >= 0");
     HIPCHK(hipSetDevice(h->device));
-    bool same = (N == h->N && h->rank == 0 && h->world == 1 && (int)h->numbers.size() == N);
+    // with the library's own exchange attached the run is sharded over its ranks (every rank integrates all atoms from the
+    // summed forces: shard_next_kernel); otherwise a single process
+    const int tr = peer_on(h) ? h->peer.rank : 0, tw = peer_on(h) ? h->peer.world : 1;
+    bool same = (N == h->N && h->rank == tr && h->world == tw && (int)h->numbers.size() == N);
     for (int i = 0; i < N && same; i++) same = h->numbers[i] == numbers[i];
     for (int k = 0; k < 3 && same; k++) same = h->pbc[k] == (pbc ? (pbc[k] != 0) : 1);
-    int rc_ = same ? SGPR_OK : sgpr_bind_system(h, N, numbers, pbc, 0, 1);
+    int rc_ = same ? SGPR_OK : sgpr_bind_system(h, N, numbers, pbc, tr, tw);
     if (rc_) return rc_;
     rc_ = md_alloc(h, N);
     if (rc_) return rc_;
     MdState &m = h->md;
+    m.numbers.assign(numbers, numbers + N);
+    m.perm = h->perm;
+    for (int k = 0; k < 3; k++) m.pbc[k] = pbc ? (pbc[k] != 0) : 1;
+    m.rank = tr; m.world = tw;
     m.N = N; m.t = 0; m.dt = dt; m.hdt = 0.5 * dt; m.c1 = exp(-friction * dt);
     const double c2 = sqrt(1.0 - m.c1 * m.c1);
     std::vector<double> xs((size_t)3 * N), vs((size_t)3 * N, 0.0), ms(N), sg(N);
@@ -2570,9 +2697,21 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
 {
     if (!h || nevals <= 0 || !evals_done) return fail(SGPR_E_INVALID, "sgpr_md_run: bad arguments");
     MdState &m = h->md;
-    if (!m.active || h->N != m.N) return fail(SGPR_E_INVALID, "sgpr_md_run: call sgpr_md_begin first");
+    if (!m.active) return fail(SGPR_E_INVALID, "sgpr_md_run: call sgpr_md_begin first");
     if (!(h->m > 0 && h->has_mu)) return fail(SGPR_E_NOMODEL, "sgpr_md_run: the model has no weights");
     HIPCHK(hipSetDevice(h->device));
+    {   // whatever ran on the handle since sgpr_md_begin (a model update computes the training rows of stored frames and
+        // trial models evaluate them: each rebinds the handle) — the run's own system is bound again before it goes on
+        bool same = h->N == m.N && h->rank == m.rank && h->world == m.world && (int)h->numbers.size() == m.N;
+        for (int i = 0; i < m.N && same; i++) same = h->numbers[i] == m.numbers[i];
+        for (int k = 0; k < 3 && same; k++) same = h->pbc[k] == (m.pbc[k] != 0);
+        if (!same) {
+            const int rb = sgpr_bind_system(h, m.N, m.numbers.data(), m.pbc, m.rank, m.world);   // (warm = false: the checked pass below)
+            if (rb) return rb;
+        }
+        if (m.world > 1 && !(peer_on(h) && h->peer.world == m.world && h->peer.rank == m.rank))
+            return fail(SGPR_E_UNSUPPORTED, "sgpr_md_run: the run was begun on %d ranks, the exchange between them is gone", m.world);
+    }
     hipStream_t st = h->stream;
     const int N = m.N;
     const size_t plen = (size_t)sgpr_packed_len(N);
@@ -2615,6 +2754,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     // (a run that halted has left the bin populations of a step that never ran)
     HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
     const unsigned step0 = h->step_count;
+    const unsigned epoch0 = h->peer.epoch;
     const bool pend0 = m.t > 0;   // (the closing half kick of the first configuration: due unless it is the start of the trajectory)
     // The host runs AHEAD of the device by at most `LA` evaluations: before evaluation j is enqueued, evaluation j - LA must
     // have set its mark (one int per evaluation in mapped host memory, written by the reducer of the overflow word: the ONLY
@@ -2683,6 +2823,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+    if (const int pc = peer_check(h)) return pc;
     int hv[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(hv, m.halt.p, sizeof(hv), hipMemcpyDeviceToHost));
     int done = enq, code = 0;
@@ -2691,6 +2832,10 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         if (k < 0 || k >= enq) return fail(SGPR_E_INVALID, "sgpr_md_run: inconsistent halt record (%d of %d)", k, enq);
         code = (m.halt_host[1] != halt_none && m.halt_host[1] == hv[0]) ? 2 : 1;
         done = k + 1;
+        // exchanges that took place: the ranks have enqueued different numbers of evaluations behind the halt, all of them
+        // skipped on the device (peer_push_kernel): a covloss halt at evaluation k is seen by evaluation k + 1 (or by the
+        // tail kernel when k is the last), an overflow by evaluation k itself — the same count on every rank
+        if (peer_on(h)) h->peer.epoch = epoch0 + (unsigned)(code == 2 ? k + 1 : std::min(nevals, k + 2));
         m.t += k;                           // the state is configuration k, not evaluated (as far as the NEXT call goes)
         if (code == 2) { h->warm = false; }  // a capacity overflowed: the next call's checked pass grows it
     } else {
@@ -2725,15 +2870,16 @@ extern "C" int sgpr_md_state(sgpr_model *h, double *positions, double *velocitie
     const int N = m.N;
     const int sl = (int)((m.t + which + 3) % 3);
     std::vector<double> buf((size_t)3 * N);
+    // (the run's OWN permutation: the handle may be bound to another frame by now)
     if (positions) {
         HIPCHK(hipMemcpy(buf.data(), m.X.p + (size_t)3 * N * sl, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
         for (int i = 0; i < N; i++)
-            for (int k = 0; k < 3; k++) positions[3 * (size_t)h->perm[i] + k] = buf[3 * (size_t)i + k];
+            for (int k = 0; k < 3; k++) positions[3 * (size_t)m.perm[i] + k] = buf[3 * (size_t)i + k];
     }
     if (velocities_pre) {
         HIPCHK(hipMemcpy(buf.data(), m.V.p + (size_t)3 * N * sl, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
         for (int i = 0; i < N; i++)
-            for (int k = 0; k < 3; k++) velocities_pre[3 * (size_t)h->perm[i] + k] = buf[3 * (size_t)i + k];
+            for (int k = 0; k < 3; k++) velocities_pre[3 * (size_t)m.perm[i] + k] = buf[3 * (size_t)i + k];
     }
     if (pending) *pending = (m.t + which) > 0 ? 1 : 0;   // (every configuration but the start of the trajectory)
     if (packed) HIPCHK(hipMemcpy(packed, m.P.p + (size_t)sgpr_packed_len(N) * sl, sizeof(double) * sgpr_packed_len(N), hipMemcpyDeviceToHost));
@@ -2757,7 +2903,7 @@ extern "C" int sgpr_md_deviates(sgpr_model *h, int64_t t_first, int count, doubl
     MdState &m = h->md;
     if (!m.active || m.seed == 0) return fail(SGPR_E_INVALID, "sgpr_md_deviates: call sgpr_md_begin and sgpr_md_seed first");
     HIPCHK(hipSetDevice(h->device));
-    DevBuf<double> d;
+    ScopedBuf<double> d;
     if (d.alloc((size_t)count * 3 * m.N, false)) return fail(SGPR_E_NODEVICE, "sgpr_md_deviates: device allocation failed");
     hipLaunchKernelGGL(md_deviates_kernel, dim3(1024), dim3(256), 0, h->stream, m.N, count, m.seed, (long long)t_first, d.p);
     HIPCHK(hipMemcpy(out, d.p, sizeof(double) * (size_t)count * 3 * m.N, hipMemcpyDeviceToHost));
@@ -2801,7 +2947,7 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
                     stat[2], h->t_stride);
     }
     h->nn_max_seen = stat[0];
-    return SGPR_OK;
+    return peer_check(h);
 }
 
 extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
@@ -2818,6 +2964,11 @@ extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
     if (!strcmp(name, "gemm_fused")) { h->gemm_fused = value != 0; return SGPR_OK; }
     if (!strcmp(name, "fuse_next")) { h->fuse_next = value != 0; h->pre_valid = false; h->lists_valid = false; return SGPR_OK; }
     if (!strcmp(name, "zero_copy_out")) { h->zero_copy_out = value != 0; return SGPR_OK; }
+    if (!strcmp(name, "reverse_scatter")) {
+        h->force_scatter = value != 0; h->gather_ok = !h->force_scatter; h->warm = false; h->lists_valid = false; h->pre_valid = false;
+        drop_graph(h);
+        return SGPR_OK;
+    }
     if (!strcmp(name, "ignore_unknown_species")) { h->ignore_unknown = value != 0; return SGPR_OK; }
     if (!strcmp(name, "lone_atom_weight")) {
         if (value < 1) return fail(SGPR_E_INVALID, "sgpr_set_option: lone_atom_weight >= 1");

@@ -73,6 +73,7 @@ class SGPRModel:
         self.generation = 0   # counts the frames the device evaluated (predict, training rows): whoever caches
                               # something about "the last frame" (calc.cov) can tell when it moved on
         self.comm_world = 1   # > 1 once an RCCL communicator is attached (comm_init)
+        self.peer_world = 1   # > 1 once the library's own exchange is attached (peer_attach)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -122,6 +123,29 @@ class SGPRModel:
     def comm_destroy(self):
         check(_lib.load().sgpr_comm_destroy(self._h))
         self.comm_world = 1
+
+    PEER_HANDLE_BYTES = 128
+
+    def peer_export(self, rank, world, capacity):
+        """This rank's receive buffers of the library's own exchange (hipIpc all-gather + local sum in rank order,
+        include/sgpr_hip.h): `capacity` doubles per source rank (>= 7 N + 11 for frames of N atoms).  Returns the bytes
+        every peer needs for peer_attach."""
+        buf = C.create_string_buffer(self.PEER_HANDLE_BYTES)
+        check(_lib.load().sgpr_peer_export(self._h, int(rank), int(world), int(capacity), C.addressof(buf)))
+        return buf.raw
+
+    def peer_attach(self, handles):
+        """handles: the peer_export bytes of ALL ranks in rank order.  From now on sharded predict() / step / md_run
+        combine the ranks' partial sums through this exchange: the same bits on every rank, independent of the number of
+        ranks (the reference's collectives: calculator/active.py:562,600-602,770-777)."""
+        blob = b"".join(bytes(x) for x in handles)
+        buf = C.create_string_buffer(blob, len(blob))
+        check(_lib.load().sgpr_peer_attach(self._h, C.addressof(buf)))
+        self.peer_world = self.comm_world = len(handles)   # (comm_world: "the library combines the ranks itself")
+
+    def peer_destroy(self):
+        check(_lib.load().sgpr_peer_destroy(self._h))
+        self.peer_world = self.comm_world = 1
 
     def scratch(self):
         """A second, empty model with the same kernel on the same device (used for one-off

@@ -154,9 +154,49 @@ def calculate_wall_big(device, sigma):
         _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
     torch.cuda.synchronize(dev)
     dstep = (time.perf_counter() - t0) / 30
+    # roofline of the same frame: per-kernel hip-event times of eager steps, the dominant kernel against its bound
+    mdl.profile(True)
+    acc = {}
+    for _ in range(16):
+        _lib.check(lib.sgpr_step_dev(h, pos_d.data_ptr(), cell_d.data_ptr(), packed.data_ptr(), sp))
+        torch.cuda.synchronize(dev)
+        for k, v in mdl.stage_times().items():
+            acc.setdefault(k, []).append(v)
+    mdl.profile(False)
+    stage_ms = {k: float(np.median(v)) for k, v in acc.items() if len(v) >= 8}
+    dims = mdl.dims
+    ptr, _, _ = mdl.neighbors(N)
+    nn_mean = float(ptr[-1]) / N
+    ab = algorithmic_bytes(N, nn_mean, dims["Dc"], 1024, dims["S"] * 64)
+    af = algorithmic_flops(numbers, [x.number for x in mdl.X], dims["Dpad"], 1)
+    dom = max((k for k in stage_ms if k in ab), key=lambda k: stage_ms[k])
+    dom_s = stage_ms[dom] * 1e-3
+    if dom in af:
+        head = {"bound": "mfma", "achieved": af[dom] / dom_s / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": af[dom] / dom_s / 1e12 / FP64_MFMA_PEAK_TF, "algorithmic_flops": af[dom]}
+    else:
+        head = {"bound": "hbm", "achieved": ab[dom] / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ab[dom] / dom_s / 1e9 / HBM_PEAK_GBS}
+    traffic, traffic_source = None, "null: no PMC pass was committed for this frame"
+    tpath = latest_profile("r*_pmc_traffic_oxide16384_m1024.json")
+    if tpath:
+        tj = json.load(open(tpath))
+        if tj.get("csrc_sha") == csrc_sha():
+            traffic = tj["kernels"].get(dom, {}).get("fetch_x2_plus_write")
+            traffic_source = f"profiles/{os.path.basename(tpath)} ({tj.get('source', 'builder run')})"
+        else:
+            traffic_source = f"null: profiles/{os.path.basename(tpath)} was collected on other kernel sources"
+    roof = {"kernel": dom, **head, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": ab[dom],
+            "avg_launch_us": stage_ms[dom] * 1e3,
+            "timing": "hip events on the launch stream, 16 eager steps (marker overhead ~1 us per stage not subtracted)",
+            "stage_us": {k: round(v * 1e3, 2) for k, v in stage_ms.items()},
+            "gemm_TFLOPs": {k: round(af[k] / (stage_ms[k] * 1e-3) / 1e12, 2) for k in af if stage_ms.get(k)},
+            "gemm_frac": {k: round(af[k] / (stage_ms[k] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF, 4) for k in af if stage_ms.get(k)},
+            "hbm_GBs": {k: round(ab[k] / (stage_ms[k] * 1e-3) / 1e9, 1) for k in ab if stage_ms.get(k)},
+            "mean_neighbors": round(nn_mean, 2)}
     mdl.close()
     return {"median_ms": w * 1e3, "atom_steps_per_s": N / w, "device_step_ms": dstep * 1e3, "wall_over_device": w / dstep,
-            "atoms": N, "inducing": 1024, "calls": len(walls) - 5}
+            "atoms": N, "inducing": 1024, "calls": len(walls) - 5, "roofline": roof}
 
 
 def cpu_baseline(numbers, pos, cell, pbc, mdl, mu, sample_atoms, min_seconds=12.0):
@@ -203,9 +243,11 @@ def main():
     ap.add_argument("--md-steps", type=int, default=400, help="steps of the device-resident Langevin loop behind `md_loop` (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-big-wall", action="store_true", help="skip the calculate() wall time of the 16384-atom / 1024 frame")
-    ap.add_argument("--collective", default="native", choices=["native", "torch"],
-                    help="native: the library's own RCCL all-reduce on the step's stream (default); torch: "
-                         "torch.distributed all_reduce of the packed buffer (dry runs of several ranks on one GPU)")
+    ap.add_argument("--collective", default="auto", choices=["auto", "ipc", "native", "torch"],
+                    help="auto (default): the library's own exchange through hipIpc-mapped buffers (all-gather of the ranks' "
+                         "partial sums + local sum in rank order: deterministic, also runs with several ranks on one device, the "
+                         "MD loop runs sharded on it), else RCCL, else host staged; ipc / native (= RCCL all-reduce on the step's "
+                         "stream) / torch (torch.distributed all_reduce of the packed buffer, host staged): only that one")
     ap.add_argument("--cpu-sample", type=int, default=0, help="atoms in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -260,7 +302,34 @@ def main():
                                     rank, world))
     stream = torch.cuda.current_stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
-    native = world > 1 and args.collective == "native"
+    backend = "none"
+    if world > 1 and args.collective in ("auto", "ipc"):
+        # the library's own exchange: every rank exports its receive buffers, the handles travel over the CPU group,
+        # everybody maps everybody's; the outcome is agreed on (MIN over ranks) before anyone steps
+        ok, blob = 1, None
+        try:
+            blob = mdl.peer_export(rank, world, 7 * N + 11)
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: sgpr_peer_export failed ({exc})", file=sys.stderr, flush=True)
+            ok = 0
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob)
+        if ok and all(b is not None for b in blobs):
+            try:
+                mdl.peer_attach(blobs)
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] rank {rank}: sgpr_peer_attach failed ({exc})", file=sys.stderr, flush=True)
+                ok = 0
+        else:
+            ok = 0
+        t = torch.tensor([ok])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 0:
+            if blob is not None:
+                mdl.peer_destroy()
+        else:
+            backend = "ipc"
+    native = world > 1 and backend == "none" and args.collective in ("auto", "native")
     if native:
         # every rank takes the same branch: the outcome of the attempt is agreed on before anyone steps
         ok = 1
@@ -281,6 +350,9 @@ def main():
             native = False
             if ok:
                 mdl.comm_destroy()
+        else:
+            backend = "rccl"
+    native = backend != "none"   # the library combines the ranks' partial sums itself
 
     frame_ptr = [frames_d[k].data_ptr() for k in range(nframes)]
     counter = [0]
@@ -436,8 +508,10 @@ def main():
     # with positions and velocities in device memory (sgpr_md_*): the wall time of K dependent steps, noise upload
     # included.  (The bench model's weights are random: scaled by 0.01 for this loop so that the forces are of the size a
     # fitted model gives — the work per step does not depend on their values.)
-    md_loop = None
-    if world == 1 and args.md_steps > 0:
+    md_loop, md_head = None, None
+    # (several ranks: the loop runs sharded over the library's own exchange — every rank integrates all atoms from the
+    # summed forces —; with RCCL or the host-staged collective only the resident-frames figure exists)
+    if args.md_steps > 0 and (world == 1 or backend == "ipc"):
         from autoforce_amd.ase_shim import kB
         from autoforce_amd.workloads import FS, MASS, fit_to_teacher
         snap = mdl.snapshot_weights()
@@ -449,9 +523,9 @@ def main():
         v0 = mrng.normal(size=(N, 3)) * np.sqrt(kB * 600.0 / mass[:, None])
         K = args.md_steps
         mdl.md_begin(numbers, pos, cell, pbc, mass, v0, dt=1.0 * FS, friction=1e-3, kT=kB * 600.0, seed=11)
-        mdl.md_run(200, None)  # (sizes the capacities; the start lattice relaxes under the fitted model)
+        mdl.md_run(max(200, args.warmup), None)  # (warm-up: sizes the capacities; the start lattice relaxes under the fitted model)
 
-        def md_timed(noise):
+        def md_timed(noise, K=K):
             rows, resizes = [], 0
             tm = time.perf_counter()
             while sum(len(r) for r in rows) < K and resizes <= 8:
@@ -461,10 +535,25 @@ def main():
                 resizes += code == 2   # a neighbour capacity outgrown on the way: the next call re-sizes and goes on
             return time.perf_counter() - tm, np.concatenate(rows), resizes
 
+        # THE HEADLINE: exactly --steps dependent MD steps between two fences, max over the ranks
+        fence()
+        th = time.perf_counter()
+        _, sc_h, rz_h = md_timed(None, args.steps)
+        fence()
+        dt_md = time.perf_counter() - th
+        if world > 1:
+            t = torch.tensor([dt_md], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_md = float(t.item())
+        if len(sc_h) == args.steps:
+            md_head = {"ms_per_step": dt_md / args.steps * 1e3, "value": N * args.steps / dt_md, "capacity_resizes": int(rz_h)}
         rbm0 = mdl.list_rebuilds()
         tmd, sc, resizes = md_timed(None)                       # deviates drawn on the device
         rbm1 = mdl.list_rebuilds()
-        t_rows, sc_rows, _ = md_timed(mrng.normal(size=(K, N, 3)))   # numpy's deviates, uploaded (the host loop's stream)
+        if world == 1:
+            t_rows, sc_rows, _ = md_timed(mrng.normal(size=(K, N, 3)))   # numpy's deviates, uploaded (the host loop's stream)
+        else:
+            t_rows, sc_rows = tmd, sc
         T_md = sc[:, 12] / (3 * N * kB)
         md_loop = {"steps": int(len(sc)), "capacity_resizes": int(resizes), "ms_per_step": tmd / max(len(sc), 1) * 1e3,
                    "atom_steps_per_s": N * len(sc) / tmd, "list_rebuilds": int(rbm1 - rbm0),
@@ -548,16 +637,22 @@ def main():
             "pass_GBs_packed": sum(v for k, v in ab.items() if k in stage_ms) / (sum(stage_ms[k] for k in ab if k in stage_ms) * 1e-3) / 1e9,
         }
         result = {
-            "metric": "MD-step atoms*steps/sec (SGPR predict: NL + descriptors + K_nm + E/F/stress + covloss); `value`: steps "
-                      "over frames resident in HBM, enqueued back to back; `md_loop`: a Langevin loop on the device, every step "
-                      "from the forces of the one before; `value_calculate_wall`: SURVEY 8(d)'s t_step = wall of one "
-                      "synchronised ActiveCalculator.calculate()",
-            "value": value,
+            "metric": "MD-step atoms*steps/sec (SGPR predict: NL + descriptors + K_nm + E/F/stress + covloss); `value`: a Langevin "
+                      "MD loop on the device, every step from the forces of the one before (sgpr_md_run; --steps dependent steps "
+                      "between two fences); `value_resident_frames`: steps over independent frames resident in HBM, enqueued "
+                      "back to back; `md_loop`: the same MD loop over --md-steps steps; `value_calculate_wall`: SURVEY 8(d)'s "
+                      "t_step = wall of one synchronised ActiveCalculator.calculate()"
+                      + ("" if md_head else "  [no device MD loop in this configuration: `value` is the resident-frames figure]"),
+            "value": md_head["value"] if md_head else value,
             "unit": "atom*steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": md_head["ms_per_step"] if md_head else ms_per_step,
+            "value_is": "md_loop (dependent steps)" if md_head else "resident frames",
+            "value_resident_frames": value,
+            "ms_per_step_resident_frames": ms_per_step,
+            "collective": backend if world > 1 else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -566,14 +661,18 @@ def main():
             "config": {
                 "workload": f"LiPS {N} atoms (3 species), {m} inducing points, lmax=nmax=3, eta=4, rc=6.0",
                 "atoms": N, "inducing": m, "mean_neighbors": round(nn_mean, 2), "max_neighbors": dims["nn_max"],
-                "packed_row": Dc, "graph": bool(args.graph), "launches_per_step": 5 if args.fuse_next else 6,
+                "packed_row": Dc, "graph": bool(args.graph), "launches_per_step": (5 if args.fuse_next else 6) if world == 1 else len(stage_ms),
                 "input": (f"closed Gaussian random walk, sigma {args.walk_sigma} A per component per step, {nframes} frames "
                           f"resident in HBM" if nframes > 1 else "static frame"),
                 "neighbor_skin_A": args.skin,
                 "list_rebuilds_in_timed_steps": int(rb1.value - rb0.value),
                 "host_array_path_atom_steps_per_s": host_rate,
-                "parallelism": f"atoms sharded x{world}, one RCCL all-reduce of {len(out_host)} doubles per step "
-                               f"({'issued by libsgpr_hip on the step stream' if native else 'torch.distributed, host staged' if world > 1 else 'single rank: none'})",
+                "parallelism": f"atoms sharded x{world}, " + (
+                    "single rank: no collective" if world == 1 else
+                    f"the library's own exchange per step: all-gather of {7 * N + 11} words of partial sums into hipIpc-mapped "
+                    "peer buffers + local sum in rank order" if backend == "ipc" else
+                    f"one RCCL all-reduce of {len(out_host)} doubles per step, issued by libsgpr_hip on the step stream"
+                    if backend == "rccl" else f"torch.distributed all-reduce of {len(out_host)} doubles, host staged"),
             },
             "roofline": roof,
             "per_rank": per_rank,
@@ -584,6 +683,7 @@ def main():
             "warmup_batches_ms": [round(1e3 * b, 4) for b in warm_batches],
             "calculate_wall": calc_wall,
             "calculate_wall_ms": None if calc_wall is None else calc_wall["median_ms"],
+            "roofline_16384": None if calc_wall_big is None else calc_wall_big.pop("roofline", None),
             "calculate_wall_16384": calc_wall_big,
             "energy": float(out_host[4 * N]),
             "max_force": float(np.abs(out_host[:3 * N]).max()),

@@ -347,6 +347,30 @@ int sgpr_comm_init(sgpr_model *h, const void *id, int rank, int world);
 int sgpr_comm_destroy(sgpr_model *h);
 int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_max, void *stream);
 
+/*
+ * The library's own exchange between the ranks of ONE node — an alternative to RCCL that also runs when several ranks
+ * share one device (RCCL refuses that) and that gives every rank the SAME bits: every rank owns a receive buffer with
+ * one slice per source rank, exported through hipIpcGetMemHandle; a step's partial sums are pushed into the slice of every
+ * peer (one hop on the fully connected xGMI mesh: the all-gather BASELINE.json words, the zero-padded all-reduces of
+ * calculator/active.py:770-777), released by one flag store per peer, and summed locally in rank order.  The force sums of
+ * the sharded reverse pass travel as fixed-point integers and are added as integers: the total force on an atom is the same
+ * bits for every number of ranks.
+ *   sgpr_peer_export   allocates this rank's buffers for `world` ranks and `capacity` doubles per slice (>= 7 N + 11 for
+ *                      frames of N atoms) and writes SGPR_PEER_HANDLE_BYTES bytes for the peers
+ *   sgpr_peer_attach   handles[world][SGPR_PEER_HANDLE_BYTES] of all ranks in rank order (the host passes them by any means);
+ *                      from then on sgpr_compute / sgpr_step_dev / sgpr_step_dev_next combine a sharded step through this
+ *                      exchange (preferred over a communicator of sgpr_comm_init), sgpr_comm_allreduce works over it, and
+ *                      sgpr_md_begin / sgpr_md_run run SHARDED: every rank evaluates its share, and after the exchange
+ *                      integrates all atoms from the summed forces (the deviates are counter-based or uploaded alike), so the
+ *                      ranks' states stay identical; the covloss gate and capacity overflows halt every rank at the same step.
+ * A peer that never arrives is a time-out (SGPR_PEER_TIMEOUT_MS, default 2000) reported by the next synchronising call,
+ * not a hang.  Exchanges are collective: every rank issues the same sequence of them.
+ */
+#define SGPR_PEER_HANDLE_BYTES 128
+int sgpr_peer_export(sgpr_model *h, int rank, int world, int64_t capacity, void *handle_out);
+int sgpr_peer_attach(sgpr_model *h, const void *handles);
+int sgpr_peer_destroy(sgpr_model *h);
+
 /* Synchronise `stream` (NULL = the handle's own) and verify that no step since the last
  * check overflowed the neighbour-list capacity.  Returns SGPR_E_OVERFLOW if one did (those
  * steps' results are invalid; capacity has been grown, the next step re-sizes eagerly). */
@@ -385,6 +409,8 @@ int sgpr_sync_check(sgpr_model *h, void *stream);
  *                           Environment: SGPR_FUSE_NEXT
  *  "gemm_fused" = 1/0       K_nm, W and covloss of a step in ONE launch (consumer tiles wait on per-panel counters;
  *                           same bits, measured slower at 4096 atoms: default 0).  Environment: SGPR_GEMM_FUSED
+ *  "reverse_scatter" = 0/1  the scatter form of the reverse pass (fixed-point force sums; what sharded frames use) on a
+ *                           single rank too: the twin a sharded run is compared with bit for bit (default 0: gather form)
  *  "spin_wait" = 1/0        sgpr_compute polls its stream for the end of a step instead of a blocking wait
  *                           (default 1: one host thread spins for the ~0.1 ms of a step, 16 us less wall time per
  *                           call on a 4096-atom frame; 0: hipStreamSynchronize).  Environment: SGPR_SPIN_WAIT */

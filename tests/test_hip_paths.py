@@ -381,3 +381,8 @@ def test_bench_line_keeps_its_contract():
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
     assert d["config"]["launches_per_step"] == 5 and d["value_md_loop"] > 0 and d["value_calculate_wall"] > 0
+    # the headline is the dependent MD loop (every step from the forces of the one before); the resident-frames pipeline is
+    # reported beside it and is the faster of the two
+    assert d["value_is"].startswith("md_loop") and d["value_resident_frames"] > 0 and d["ms_per_step_resident_frames"] > 0
+    assert abs(d["value_resident_frames"] - atoms / (d["ms_per_step_resident_frames"] * 1e-3)) <= 1e-6 * d["value_resident_frames"]
+    assert d["value"] <= 1.05 * d["value_resident_frames"]
