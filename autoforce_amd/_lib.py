@@ -68,8 +68,10 @@ SIGNATURES = {
     "sgpr_md_begin": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl]),
     "sgpr_md_run": (C.c_int, [_vp, C.c_int, _vp, _dbl, C.c_int, _vp, _vp, _vp]),
     "sgpr_md_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "sgpr_md_velocities": (C.c_int, [_vp, _vp]),
     "sgpr_md_end": (C.c_int, [_vp]),
     "sgpr_md_seed": (C.c_int, [_vp, C.c_uint64]),
+    "sgpr_md_thermostat": (C.c_int, [_vp, C.c_int, _dbl, _dbl]),
     "sgpr_md_deviates": (C.c_int, [_vp, _i64, C.c_int, _vp]),
     "sgpr_sync_check": (C.c_int, [_vp, _vp]),
     "sgpr_comm_unique_id": (C.c_int, [_vp]),

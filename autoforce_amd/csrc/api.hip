@@ -157,6 +157,13 @@ struct MdState {
     int rank = 0, world = 1;
     long long t = 0;               // evaluations completed (= index of the configuration to evaluate next)
     double hdt = 0.0, c1 = 1.0, dt = 0.0;
+    int ring = 3;                  // slots of the X / V / P / KE rings in use: 3 (Langevin / velocity Verlet), 4 (Nose-Hoover: the
+                                   //   speculative step behind a halt must not overwrite x_(k-1), which the restart needs)
+    // Nose-Hoover NVT (sgpr_md_thermostat): zeta_(n+1) = zeta_(n-1) + 2 dt tfact (KE_n - K0), rings of four in `zeta`
+    bool nh = false;
+    double nh_c1 = 0.0, nh_c2 = 0.0, nh_K0 = 0.0;   // dt tfact, 2 dt tfact, desired kinetic energy
+    DevBuf<double> zeta;           // [4] zeta by evaluation index & 3 | [4] its time integral
+    bool evaluated = false;        // the current configuration has been evaluated by the last sgpr_md_run (halted / final)
     unsigned long long seed = 0;   // != 0: the integrator draws its own deviates (sgpr_md_seed)
     DevBuf<double> X, V, P, KE, mass, sig, noise, noise_raw, cell;
     DevBuf<int> halt;
@@ -449,6 +456,10 @@ struct FinNext {
     unsigned long long seed;       // != 0 and noise == null: counter-based deviates (Philox4x32-10 + Box-Muller) of
     long long t_index;             //   (seed; configuration index t_index, caller atom, component)
     double hdt, c1;                // dt / 2, exp(-friction dt)
+    int nh, nh_first;              // Nose-Hoover (Melchionna) step instead of BAOAB; the first evaluation of the trajectory
+    const double *x_prev;          // nh: positions of the configuration before this one
+    double *v_now;                 // nh: the centred velocity (x_next - x_prev) / 2 dt of THIS configuration, known once it is evaluated
+    const double *nh_zeta;         // nh: zeta of this configuration (device: written by md_nh_kernel behind the previous evaluation)
     int pending;                   // the closing half kick of this step is due (0 only for the very first evaluation)
     double *ke_cur;                // [N][2] m v^2 of this step: after the closing half kick | before it
     const double *ke_prev, *packed_prev;   // the same / the packed results of step s - 1 (null: no such step in this run)
@@ -875,6 +886,57 @@ __global__ void md_deviates_kernel(int N, int rows, unsigned long long seed, lon
     }
 }
 
+// One Nose-Hoover step of a coordinate (constant cell): the scheme of Melchionna, Ciccotti and Holian (1993) as ase.md.npt.NPT
+// integrates it with pfactor = None — what the reference's default md(dynamics="NPT", bulk_modulus=None) runs, cl/md.py:17,
+// :131-166 (ASE is a third-party dependency absent here: restated from its published algorithm) —
+//     x_(n+1) = (2 x_n - x_(n-1) (1 - b) + dt^2 F_n / m) / (1 + b),   b = dt zeta_n / 2,
+//     v_n = (x_(n+1) - x_(n-1)) / (2 dt)          (the momenta ASE sets at the end of its step: the kinetic energy of the log line)
+// and, the first time, x_(-1) = x_0 - dt v_0 + dt^2 F_0 / (2 m) (its _calculate_q_past_and_future with zeta = 0).
+// Operations and their order are those of workloads.nose_hoover_nvt: no contraction, true divisions.  Returns v_n.
+__device__ __forceinline__ double md_nh_advance(const FinNext &x, double F, double ms, double xc, double v0, double xprev, double zeta, double &xn)
+{
+#pragma clang fp contract(off)
+    const double dt = 2.0 * x.hdt;
+    const double a = __ddiv_rn((dt * dt) * F, ms);
+    double xp = xprev;
+    if (x.nh_first) xp = (xc - dt * v0) + 0.5 * a;
+    const double b = x.hdt * zeta;
+    const double num = ((2.0 * xc) - xp * (1.0 - b)) + a;
+    xn = __ddiv_rn(num, 1.0 + b);
+    // (the first time v_0 is the caller's own: ASE's first thermostat step takes the kinetic energy of the initial momenta)
+    return x.nh_first ? v0 : __ddiv_rn(xn - xp, 2.0 * dt);
+}
+
+// zeta_(n+1) = zeta_(n-1) + 2 dt tfact (KE_n - K0) behind evaluation n (ONE workgroup; its own launch: the integrating waves of
+// evaluation n + 1 all need the sum over the atoms of evaluation n).  Fixed order: thread t sums the atoms t, t + 256, ...,
+// then a pairwise tree in natural order — workloads.nose_hoover_nvt adds in the same order.
+__global__ __launch_bounds__(256) void md_nh_kernel(int N, const double *ke, double *zeta, int n, double dt, double c1, double c2, double K0,
+                                                    const int *halt, int step, double *scal_row)
+{
+    if (*halt < step) return;
+    __shared__ double wsum[4];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int k = tid; k < N; k += 256) s += ke[2 * (size_t)k];
+    s = fin_wave_sum(s);
+    if ((tid & 63) == 0) wsum[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+#pragma clang fp contract(off)
+        const double KE = 0.5 * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        const int sc = n & 3, sn = (n + 1) & 3, sp = (n + 3) & 3;
+        const double d = KE - K0;
+        const double zprev = n == 0 ? -(c1 * d) : zeta[sp];   // (ASE's initialize(): zeta_past = -dt tfact (KE - K0), zeta = 0)
+        const double zcur = n == 0 ? 0.0 : zeta[sc];
+        const double zint = n == 0 ? 0.0 : zeta[4 + sc];
+        const double znew = zprev + c2 * d;
+        zeta[sn] = znew;
+        zeta[4 + sn] = zint + dt * znew;                      // (ASE: zeta_integrated += dt * zeta, after the shift)
+        scal_row[14] = zcur;
+        scal_row[15] = zint;
+    }
+}
+
 // The same gather, and with it the first kernel of the NEXT step (FinNext): a wave takes an atom to its next position —
 // read from the next frame (MODE 1) or integrated (MODE 2) —, bins it there and takes part in the rebuild decision.
 // Grid: ceil(N / 4) gather workgroups, 11 reducers of this step, 2 lagged reducers.
@@ -931,6 +993,8 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
         sg = x.sig[ia];
         nz = x.noise ? x.noise[3 * (size_t)ia + l3] : 0.0;   // (wave-uniform condition)
     }
+    double xpv = 0.0, zeta = 0.0;
+    if (MODE == 2 && x.nh) { xpv = x.x_prev[3 * (size_t)ia + l3]; zeta = *x.nh_zeta; }   // (wave-uniform condition)
     double csv = f.has_beta ? f.csq[(size_t)ia * f.csq_slots + lc] : 0.0;   // (wave-uniform condition)
     if (lane >= f.csq_slots) csv = 0.0;
     if (f.has_beta)
@@ -1004,7 +1068,15 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
     }
     // ---- the next step
     double ke = 0.0, kp = 0.0;
-    if (MODE == 2 && lane < 3) {
+    if (MODE == 2 && x.nh) {
+        if (lane < 3) {
+            const double vnow = md_nh_advance(x, Fv, ms, xc, vc, xpv, zeta, xn);
+            ke = ms * (vnow * vnow);
+            kp = ke;
+            x.x_next[3 * (size_t)i + lane] = xn;
+            x.v_now[3 * (size_t)i + lane] = vnow;
+        }
+    } else if (MODE == 2 && lane < 3) {
         // BAOAB, exactly the operations (and their order) of workloads.langevin_nvt: no contraction into fused
         // multiply-adds, a true division
 #pragma clang fp contract(off)
@@ -1293,6 +1365,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
         DevBuf<double> *mdb[] = {&m.X, &m.V, &m.P, &m.KE, &m.mass, &m.sig, &m.noise, &m.noise_raw, &m.cell, &m.scal_d};
         for (auto b : mdb) b->release();
         m.halt.release();
+        m.zeta.release();
         DevBuf<int4> *tb[] = {&h->t_knm, &h->t_w, &h->t_cov, &h->t_kmm, &h->t_wcov, &h->t_fused};
         for (auto b : tb) b->release();
         h->d_panel_cnt.release();
@@ -2626,9 +2699,9 @@ static int md_alloc(sgpr_model *h, int N)
 {
     MdState &m = h->md;
     bool bad = false;
-    bad |= m.X.alloc((size_t)9 * N); bad |= m.V.alloc((size_t)9 * N); bad |= m.P.alloc(3 * (size_t)sgpr_packed_len(N));
-    bad |= m.KE.alloc((size_t)6 * N); bad |= m.mass.alloc(N); bad |= m.sig.alloc(N); bad |= m.cell.alloc(9);
-    bad |= m.halt.alloc(4);
+    bad |= m.X.alloc((size_t)12 * N); bad |= m.V.alloc((size_t)12 * N); bad |= m.P.alloc(4 * (size_t)sgpr_packed_len(N));
+    bad |= m.KE.alloc((size_t)8 * N); bad |= m.mass.alloc(N); bad |= m.sig.alloc(N); bad |= m.cell.alloc(9);
+    bad |= m.halt.alloc(4); bad |= m.zeta.alloc(8);
     if (bad) return fail(SGPR_E_NODEVICE, "sgpr_md_begin: device allocation failed");
     if (!m.halt_host) {
         if (hipHostMalloc((void **)&m.halt_host, 64, hipHostMallocMapped) != hipSuccess ||
@@ -2662,6 +2735,7 @@ extern "C" int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const
     for (int k = 0; k < 3; k++) m.pbc[k] = pbc ? (pbc[k] != 0) : 1;
     m.rank = tr; m.world = tw;
     m.N = N; m.t = 0; m.dt = dt; m.hdt = 0.5 * dt; m.c1 = exp(-friction * dt);
+    m.ring = 3; m.nh = false; m.evaluated = false;
     const double c2 = sqrt(1.0 - m.c1 * m.c1);
     std::vector<double> xs((size_t)3 * N), vs((size_t)3 * N, 0.0), ms(N), sg(N);
     for (int i = 0; i < N; i++) {
@@ -2682,6 +2756,27 @@ extern "C" int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const
     HIPCHK(hipMemcpy(m.cell.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice));
     m.active = true;
     h->pre_valid = false;
+    return SGPR_OK;
+}
+
+// Nose-Hoover NVT for the run begun by sgpr_md_begin (kind = 1; 0 = back to the Langevin / velocity-Verlet step of
+// sgpr_md_begin's friction): what the reference's default md(dynamics="NPT", bulk_modulus=None) is — ase.md.npt.NPT with
+// pfactor = None and ttime = tdamp fs (cl/md.py:17, :131-166) — restated in md_nh_advance / md_nh_kernel.  kT as given to
+// sgpr_md_begin; tfact = 2 / (3 N kT ttime^2), desired kinetic energy 1.5 (N - 1) kT (ASE's constants).  Before the first
+// sgpr_md_run of the run.
+extern "C" int sgpr_md_thermostat(sgpr_model *h, int kind, double ttime, double kT)
+{
+    if (!h || (kind != 0 && kind != 1)) return fail(SGPR_E_INVALID, "sgpr_md_thermostat: kind is 0 (Langevin / velocity Verlet) or 1 (Nose-Hoover)");
+    MdState &m = h->md;
+    if (!m.active) return fail(SGPR_E_INVALID, "sgpr_md_thermostat: call sgpr_md_begin first");
+    if (m.t != 0) return fail(SGPR_E_INVALID, "sgpr_md_thermostat: the run has started");
+    if (kind == 0) { m.nh = false; m.ring = 3; return SGPR_OK; }
+    if (!(ttime > 0.0) || !(kT > 0.0)) return fail(SGPR_E_INVALID, "sgpr_md_thermostat: ttime > 0 and kT > 0");
+    const double tfact = 2.0 / ((double)(3 * m.N) * kT * ttime * ttime);
+    m.nh = true; m.ring = 4;
+    m.nh_c1 = m.dt * tfact; m.nh_c2 = 2.0 * m.dt * tfact; m.nh_K0 = 1.5 * (double)(m.N - 1) * kT;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemset(m.zeta.p, 0, 8 * sizeof(double)));
     return SGPR_OK;
 }
 
@@ -2743,7 +2838,8 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     h->bin_identity = true;
     struct Restore { sgpr_model *h; ~Restore() { h->bin_identity = false; h->pre_valid = false; } } restore{h};
     // the first evaluation sizes the capacities for this configuration if nothing has yet (synchronised, results discarded)
-    const int s0 = (int)(m.t % 3);
+    const int RG = m.ring;
+    const int s0 = (int)(m.t % RG);
     if (!h->warm) {
         const int rc_ = run_checked(h, m.X.p + (size_t)3 * N * s0, m.cell.p, m.P.p + plen * s0, st);
         if (rc_) return rc_;
@@ -2781,7 +2877,7 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
             if (rc_) break;
             if (hh[0] != halt_none || hh[1] != halt_none) { halted = true; break; }
         }
-        const int sl = (int)((m.t + j) % 3), sn = (sl + 1) % 3, sp = (sl + 2) % 3;
+        const int sl = (int)((m.t + j) % RG), sn = (sl + 1) % RG, sp = (sl + RG - 1) % RG;
         StepNext nx;
         const bool integrate = !(final_eval && j == nevals - 1);
         nx.mode = 2;
@@ -2792,6 +2888,14 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         x.x_next = m.X.p + (size_t)3 * N * sn; x.v_next = m.V.p + (size_t)3 * N * sn;
         x.mass = m.mass.p; x.sig = m.sig.p; x.noise = noise ? m.noise.p + (size_t)j * 3 * N : nullptr;
         x.hdt = m.hdt; x.c1 = m.c1; x.pending = (j > 0 || pend0) ? 1 : 0;
+        if (m.nh) {
+            x.nh = 1; x.nh_first = (m.t + j) == 0 ? 1 : 0;
+            x.x_prev = m.X.p + (size_t)3 * N * sp; x.v_now = m.V.p + (size_t)3 * N * sl;
+            // (v_cur: what the integrator holds when it asks for the forces — ASE sets the momenta of step n after its force
+            // call: v_(n-1), the caller's v_0 the first time; its kinetic energy is scalars[13], the calculator's log line)
+            if (m.t + j > 0) x.v_cur = m.V.p + (size_t)3 * N * sp;
+            x.nh_zeta = m.zeta.p + ((m.t + j) & 3);
+        }
         x.seed = noise ? 0ull : m.seed; x.t_index = m.t + j;
         x.ke_cur = m.KE.p + (size_t)2 * N * sl; x.ke_prev = j > 0 ? m.KE.p + (size_t)2 * N * sp : nullptr;
         x.packed_prev = j > 0 ? m.P.p + plen * sp : nullptr;
@@ -2803,15 +2907,18 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         rc_ = enqueue_step(h, x.x_cur, m.cell.p, m.P.p + plen * sl, st, &nx);
         if (rc_) break;
         h->lists_valid = true;  // (the first evaluation rebuilt the candidates; an overflow halts the run: FinNext)
-        if (!h->pre_valid) { rc_ = fail(SGPR_E_UNSUPPORTED, "sgpr_md_run: the fused last kernel is not available for this model / frame (sharded, "
-                                        "scatter-form reverse pass, graph capture or a zero skin)"); break; }
+        if (!h->pre_valid) { rc_ = fail(SGPR_E_UNSUPPORTED, "sgpr_md_run: the fused last kernel is not available for this model / frame (sharded "
+                                        "without the library's own exchange, graph capture or a zero skin)"); break; }
+        if (m.nh)   // zeta of the next configuration from this one's kinetic energy (every integrating wave of the next launch needs it)
+            hipLaunchKernelGGL(md_nh_kernel, dim3(1), dim3(256), 0, st, N, m.KE.p + (size_t)2 * N * sl, m.zeta.p, (int)((m.t + j) & 0x3fffffff),
+                               m.dt, m.nh_c1, m.nh_c2, m.nh_K0, m.halt.p, (int)(step0 + j), m.scal_d.p + (size_t)SGPR_MD_SCAL * j);
         enq = j + 1;
     }
     if (rc_) { (void)hipStreamSynchronize(st); return rc_; }
     if (enq > 0) {  // the lagged reductions of the last evaluation enqueued
         FinArgs f = {};
         f.N = N;
-        const int sl = (int)((m.t + enq - 1) % 3);
+        const int sl = (int)((m.t + enq - 1) % RG);
         f.nx.mode = 3; f.nx.step = (int)(step0 + enq);
         f.nx.ke_prev = m.KE.p + (size_t)2 * N * sl; f.nx.packed_prev = m.P.p + plen * sl;
         f.nx.ediff = ediff > 0.0 ? ediff : 1e300; f.nx.halt = m.halt.p; f.nx.halt_host = m.halt_host_dev;
@@ -2846,8 +2953,10 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     if (code == 2) done -= 1;  // (the overflowing evaluation's own results are void)
     if (scalars && done > 0) {
         HIPCHK(hipMemcpy(scalars, m.scal_d.p, sizeof(double) * SGPR_MD_SCAL * (size_t)done, hipMemcpyDeviceToHost));
-        for (int r = 0; r < done; r++) scalars[(size_t)SGPR_MD_SCAL * r + 14] = scalars[(size_t)SGPR_MD_SCAL * r + 15] = 0.0;  // (spare)
+        if (!m.nh)   // (Nose-Hoover: zeta and its time integral of the evaluation's configuration; else spare)
+            for (int r = 0; r < done; r++) scalars[(size_t)SGPR_MD_SCAL * r + 14] = scalars[(size_t)SGPR_MD_SCAL * r + 15] = 0.0;
     }
+    m.evaluated = code == 1 || (code == 0 && final_eval != 0);
     *evals_done = done;
     if (halt_code) *halt_code = code;
     h->lists_valid = false;
@@ -2868,7 +2977,7 @@ extern "C" int sgpr_md_state(sgpr_model *h, double *positions, double *velocitie
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N = m.N;
-    const int sl = (int)((m.t + which + 3) % 3);
+    const int sl = (int)((m.t + which + m.ring) % m.ring);
     std::vector<double> buf((size_t)3 * N);
     // (the run's OWN permutation: the handle may be bound to another frame by now)
     if (positions) {
@@ -2881,8 +2990,43 @@ extern "C" int sgpr_md_state(sgpr_model *h, double *positions, double *velocitie
         for (int i = 0; i < N; i++)
             for (int k = 0; k < 3; k++) velocities_pre[3 * (size_t)m.perm[i] + k] = buf[3 * (size_t)i + k];
     }
-    if (pending) *pending = (m.t + which) > 0 ? 1 : 0;   // (every configuration but the start of the trajectory)
+    if (pending) *pending = (!m.nh && (m.t + which) > 0) ? 1 : 0;   // (every configuration but the start of the trajectory)
+    if (m.nh && velocities_pre && (m.t + which) > 0) {
+        // Nose-Hoover: what the integrator holds when it asks for the forces of configuration n is the centred velocity of
+        // configuration n - 1 (ASE sets the momenta of a step after its force call); sgpr_md_velocities has v_n itself
+        const int sp = (sl + m.ring - 1) % m.ring;
+        HIPCHK(hipMemcpy(buf.data(), m.V.p + (size_t)3 * N * sp, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; i++)
+            for (int k = 0; k < 3; k++) velocities_pre[3 * (size_t)m.perm[i] + k] = buf[3 * (size_t)i + k];
+    }
     if (packed) HIPCHK(hipMemcpy(packed, m.P.p + (size_t)sgpr_packed_len(N) * sl, sizeof(double) * sgpr_packed_len(N), hipMemcpyDeviceToHost));
+    return SGPR_OK;
+}
+
+// The velocities an observer of the trajectory sees at the current configuration, which the last sgpr_md_run must have
+// evaluated (it halted there, or ran with final_eval): Langevin / velocity Verlet: the closing half kick applied; Nose-Hoover:
+// the centred velocity (x_(n+1) - x_(n-1)) / 2 dt.  Caller atom order.
+extern "C" int sgpr_md_velocities(sgpr_model *h, double *velocities)
+{
+    if (!h || !velocities) return fail(SGPR_E_INVALID, "sgpr_md_velocities: bad arguments");
+    MdState &m = h->md;
+    if (!m.active) return fail(SGPR_E_INVALID, "sgpr_md_velocities: call sgpr_md_begin first");
+    if (!m.evaluated) return fail(SGPR_E_INVALID, "sgpr_md_velocities: the current configuration has not been evaluated (run with final_eval, or after a halt)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N = m.N, sl = (int)(m.t % m.ring);
+    std::vector<double> v((size_t)3 * N), F;
+    HIPCHK(hipMemcpy(v.data(), m.V.p + (size_t)3 * N * sl, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+    const bool kick = !m.nh && m.t > 0;
+    if (kick) {
+        F.resize((size_t)3 * N);   // (packed forces are in caller order)
+        HIPCHK(hipMemcpy(F.data(), m.P.p + (size_t)sgpr_packed_len(N) * sl, sizeof(double) * 3 * N, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < N; i++) {
+        const int c = m.perm[i];
+        for (int k = 0; k < 3; k++)
+            velocities[3 * (size_t)c + k] = kick ? v[3 * (size_t)i + k] + m.hdt * F[3 * (size_t)c + k] / m.mass_sorted[i] : v[3 * (size_t)i + k];
+    }
     return SGPR_OK;
 }
 

@@ -519,7 +519,7 @@ class SGPRModel:
     # ------------------------------------------------------------------ device-resident molecular dynamics
     MD_SCALARS = 16  # per evaluation: E, virial[9], overflow word, largest covloss, sum m v^2, 3 spare
 
-    def md_begin(self, numbers, positions, cell, pbc, masses, velocities=None, dt=1.0, friction=0.0, kT=0.0, seed=0):
+    def md_begin(self, numbers, positions, cell, pbc, masses, velocities=None, dt=1.0, friction=0.0, kT=0.0, seed=0, ttime=None):
         """State of an MD run into device memory (cl/md.py:117-128 drives ase.md.langevin around calculate();
         here the integrator is part of the step's last kernel).  dt, friction and kT in the caller's units
         (workloads.FS / ase_shim.kB for fs / K)."""
@@ -533,6 +533,11 @@ class SGPRModel:
                                         float(dt), float(friction), float(kT)))
         # seed != 0: md_run(noise=None) draws the Langevin deviates on the device (counter-based, md_deviates returns them)
         check(_lib.load().sgpr_md_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+        # ttime: Nose-Hoover NVT with that time constant instead of the Langevin / velocity-Verlet step (the reference's
+        # default dynamics, cl/md.py:131-166: ase.md.npt.NPT with pfactor = None)
+        if ttime is not None:
+            check(_lib.load().sgpr_md_thermostat(self._h, 1, float(ttime), float(kT)))
+            self._md["nh"] = True
         self._md["t"] = 0
 
     def md_deviates(self, t_first, count):
@@ -571,7 +576,12 @@ class SGPRModel:
             stress = np.zeros(6)
             check(_lib.load().sgpr_stress_from_virial(ptr(f64(packed[4 * N + 1:4 * N + 10])), ptr(self._md["cell"]), ptr(stress)))
             out.update(forces=F, beta=packed[3 * N:4 * N].copy(), energy=float(packed[4 * N]), stress=stress)
-            out["velocities"] = v + self._md["hdt"] * F / self._md["masses"][:, None] if pend.value else v.copy()
+            if self._md.get("nh"):   # Nose-Hoover: the centred velocity of this configuration (v is the one before it)
+                vn = np.empty((N, 3))
+                check(_lib.load().sgpr_md_velocities(self._h, ptr(vn)))
+                out["velocities"] = vn
+            else:
+                out["velocities"] = v + self._md["hdt"] * F / self._md["masses"][:, None] if pend.value else v.copy()
         return out
 
     def md_end(self):

@@ -182,6 +182,74 @@ def langevin_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=
         yield step, E, float((mass * vel ** 2).sum() / (3 * N * kB)), time.time() - t0, pos, vel
 
 
+def _device_order_sum(x):
+    """Sum of x in the order of md_nh_kernel (api.hip): 256 strided partial sums (thread t adds the elements t, t + 256, ...
+    one after the other), then a pairwise tree in natural order."""
+    x = np.asarray(x, float)
+    pad = (-len(x)) % 256
+    rows = np.concatenate([x, np.zeros(pad)]).reshape(-1, 256)
+    p = np.zeros(256)
+    for r in rows:
+        p = p + r
+    while len(p) > 1:
+        p = p[0::2] + p[1::2]
+    return float(p[0])
+
+
+def nose_hoover_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, tdamp_fs=25.0, vel=None, seed=1):
+    """Nose-Hoover NVT in numpy around any calculator with the ASE surface: the reference's DEFAULT dynamics —
+    md(dynamics="NPT", bulk_modulus=None) = ase.md.npt.NPT(pfactor=None, ttime=tdamp fs), cl/md.py:17, :131-166 — restated
+    from ASE's published algorithm (Melchionna, Ciccotti, Holian 1993; ASE is absent here):
+        x_(n+1) = (2 x_n - x_(n-1) (1 - b) + dt^2 F_n / m) / (1 + b),  b = dt zeta_n / 2,  v_n = (x_(n+1) - x_(n-1)) / 2 dt
+        zeta_(n+1) = zeta_(n-1) + 2 dt tfact (KE_n - 1.5 (N - 1) kT),  tfact = 2 / (3 N kT ttime^2)
+    started with x_(-1) = x_0 - dt v_0 + dt^2 F_0 / 2m, zeta_0 = 0, zeta_(-1) = -dt tfact (KE_0 - ...).  The host twin of the
+    device loop (sgpr_md_thermostat): same operations in the same order, bit for bit.  Yields (step, energy, temperature,
+    wall seconds, positions, velocities, zeta, integral of zeta) per evaluated configuration."""
+    import time
+    from .ase_shim import Atoms, kB
+    N = len(numbers)
+    mass = np.array([MASS[int(z)] for z in numbers])[:, None]
+    kT = kB * temperature
+    if vel is None:
+        rng = np.random.default_rng(seed)
+        vel = rng.normal(size=(N, 3)) * np.sqrt(kT / mass)
+        vel -= (mass * vel).sum(0) / mass.sum()
+    v0 = np.array(vel, float)
+    dt = dt_fs * FS
+    hdt = 0.5 * dt
+    dt = 2.0 * hdt
+    ttime = tdamp_fs * FS
+    tfact = 2.0 / (float(3 * N) * kT * ttime * ttime)
+    c1, c2, K0 = dt * tfact, 2.0 * dt * tfact, 1.5 * float(N - 1) * kT
+    x = np.array(pos, float)
+    xp = None
+    zeta, zint = {0: 0.0}, {0: 0.0}
+
+    def forces(p, v):
+        at = Atoms(numbers, p, cell, pbc, velocities=v, masses=mass[:, 0])
+        at.calc = calc
+        return at.get_forces(), at.get_potential_energy()
+
+    for n in range(steps + 1):
+        t0 = time.time()
+        F, E = forces(x, v0 if n == 0 else v)   # (the velocities the integrator holds when it asks for forces: v_(n-1))
+        a = ((dt * dt) * F) / mass
+        if n == 0:
+            xp = (x - dt * v0) + 0.5 * a
+        b = hdt * zeta[n]
+        xn = (((2.0 * x) - xp * (1.0 - b)) + a) / (1.0 + b)
+        v = v0 if n == 0 else (xn - xp) / (2.0 * dt)
+        ke3 = mass * (v * v)
+        ke_atom = (ke3[:, 0] + ke3[:, 1]) + ke3[:, 2]
+        KE = 0.5 * _device_order_sum(ke_atom)
+        d = KE - K0
+        zprev = -(c1 * d) if n == 0 else zeta[n - 1]
+        zeta[n + 1] = zprev + c2 * d
+        zint[n + 1] = zint[n] + dt * zeta[n + 1]
+        yield n, E, float(2.0 * KE / (3 * N * kB)), time.time() - t0, x, v, zeta[n], zint[n]
+        xp, x = x, xn
+
+
 def langevin_nvt_device(model, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, friction=1e-3, seed=1, vel=None,
                         ediff=0.0, chunk=256, on_halt=None, device_rng=False):
     """langevin_nvt with the state in device memory (SGPRModel.md_begin / md_run): same scheme, same random stream

@@ -323,6 +323,10 @@ int sgpr_md_begin(sgpr_model *h, int N, const int32_t *numbers, const double *po
 int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, double ediff, int final_eval, double *scalars,
                 int *evals_done, int *halt_code);
 int sgpr_md_state(sgpr_model *h, double *positions, double *velocities_pre, int *pending, double *packed, int which);
+/* The velocities an observer sees at the current configuration (evaluated by the last sgpr_md_run: a halt, or final_eval):
+ * the closing half kick applied (Langevin / velocity Verlet), or the centred velocity (Nose-Hoover, sgpr_md_thermostat — there
+ * sgpr_md_state's velocities_pre of configuration n is v_(n-1): what the integrator holds when it asks for F_n). */
+int sgpr_md_velocities(sgpr_model *h, double *velocities);
 int sgpr_md_end(sgpr_model *h);
 /* Deviates drawn on the device: with a seed != 0, sgpr_md_run called with noise = NULL draws xi itself — deviate
  * (configuration index, atom, component) of a counter-based generator (Philox4x32-10, Box-Muller), so a run does not
@@ -330,6 +334,18 @@ int sgpr_md_end(sgpr_model *h);
  * and no upload on the step's path (the reference draws from numpy inside ase.md.langevin, cl/md.py:117-128).
  * sgpr_md_deviates returns the rows of configurations [t_first, t_first + count): out[count][N][3], caller atom order. */
 int sgpr_md_seed(sgpr_model *h, uint64_t seed);
+/* Nose-Hoover NVT instead of the Langevin / velocity-Verlet step (kind = 1; 0 = back): the reference's DEFAULT dynamics,
+ * md(dynamics="NPT", bulk_modulus=None) = ase.md.npt.NPT with pfactor = None, ttime = tdamp fs (cl/md.py:17, :131-166;
+ * Melchionna, Ciccotti, Holian 1993 as ASE integrates it):
+ *     x_(n+1) = (2 x_n - x_(n-1) (1 - b) + dt^2 F_n / m) / (1 + b),  b = dt zeta_n / 2,  v_n = (x_(n+1) - x_(n-1)) / 2 dt,
+ *     zeta_(n+1) = zeta_(n-1) + 2 dt tfact (KE_n - 1.5 (N - 1) kT),  tfact = 2 / (3 N kT ttime^2),
+ * started with x_(-1) = x_0 - dt v_0 + dt^2 F_0 / 2m, zeta_0 = 0, zeta_(-1) = -dt tfact (KE_0 - ...).  The integrator stays
+ * in the step's last kernel; zeta_(n+1) needs the kinetic energy of ALL atoms at step n, reduced by one small launch
+ * behind each evaluation.  Call between sgpr_md_begin and the first sgpr_md_run.  scalars[.][12] = [13] = sum m v_n^2 with
+ * the centred velocities, [14] = zeta_n, [15] = its time integral (the conserved quantity is
+ * E + KE + 1.5 N kT (ttime zeta)^2 + 3 (N - 1) kT int zeta dt, ASE's get_gibbs_free_energy).  sgpr_md_state returns the
+ * centred velocities (pending = 0). */
+int sgpr_md_thermostat(sgpr_model *h, int kind, double ttime, double kT);
 int sgpr_md_deviates(sgpr_model *h, int64_t t_first, int count, double *out);
 /*
  * Multi-GPU (one process per GPU, atoms sharded as in sgpr_bind_system): the reference combines the
