@@ -471,7 +471,8 @@ class ActiveCalculator(Calculator):
             return EPS
         return float(min(self._ediff_lb.values))
 
-    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256, seed=1, sync_every=None):
+    def run_md(self, atoms, steps, temperature_K, dt_fs=1.0, friction=1e-3, rng=None, chunk=256, seed=1, sync_every=None,
+               tdamp_fs=None):
         """`steps` steps of Langevin NVT (friction = 0: NVE) from atoms.positions / velocities, as cl/md.py:117-128 sets
         it up around this calculator — but the state stays in device memory between model updates: the integrator runs
         inside the step's last kernel (SGPRModel.md_run), the host reads 16 scalars per step and writes the same log
@@ -484,16 +485,20 @@ class ActiveCalculator(Calculator):
         generator and no upload on the step's path, same trajectory however the run is batched).  sync_every: steps
         k = 0 mod sync_every end a batch and atoms.positions / velocities are theirs when they are yielded (a trajectory
         writer's loginterval, cl/md.py:24); atoms.positions / velocities are current at every yield that follows an update
-        and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no."""
+        and at the end.  Falls back to the host loop (workloads.langevin_nvt) where md_on_device_ok() says no.
+        tdamp_fs: Nose-Hoover NVT with that damping time instead of Langevin — the reference's DEFAULT dynamics,
+        md(dynamics="NPT", bulk_modulus=None) = ase.md.npt.NPT(pfactor=None, ttime=tdamp fs) (cl/md.py:17, :131-166); no
+        deviates, `friction` / `rng` / `seed` unused; host loop: workloads.nose_hoover_nvt."""
         from .ase_shim import kB
-        from .workloads import FS, MASS, langevin_nvt
+        from .workloads import FS, MASS, langevin_nvt, nose_hoover_nvt
+        nh = tdamp_fs is not None
         if len(getattr(atoms, "constraints", None) or ()):
             # (neither integrator of this method knows ASE's constraints: an ASE dynamics object around calculate() does)
             raise NotImplementedError("run_md integrates unconstrained atoms; with atoms.constraints set, drive calculate() "
                                       "from an ase.md dynamics object as theforce/cl/md.py does")
         numbers, pos, cell, pbc = self._system(atoms)
         N = len(numbers)
-        on_device_rng = rng is None and friction > 0.0
+        on_device_rng = rng is None and friction > 0.0 and not nh
         rng = np.random.default_rng(seed) if rng is None else rng
         if getattr(atoms, "_masses", "ase") is None:  # (the stand-in Atoms without masses; ase.Atoms knows its own)
             masses = np.array([MASS[int(z)] for z in numbers])
@@ -508,16 +513,17 @@ class ActiveCalculator(Calculator):
             atoms.calc = self
             atoms.get_forces()
             if not self.md_on_device_ok():
-                for st, E, T, _, p, v in langevin_nvt(self, numbers, pos, cell, pbc, steps, temperature_K, dt_fs, friction, vel=vel,
-                                                      rng=rng):
+                loop = (nose_hoover_nvt(self, numbers, pos, cell, pbc, steps, temperature_K, dt_fs, tdamp_fs, vel=vel) if nh else
+                        langevin_nvt(self, numbers, pos, cell, pbc, steps, temperature_K, dt_fs, friction, vel=vel, rng=rng))
+                for st, E, T, _, p, v, *rest in loop:
                     atoms.positions = p
                     atoms.set_velocities(v)
                     yield st, E, T, bool(self.updated), _
                 return
         eng = self.engine
         kT = kB * temperature_K
-        eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=friction, kT=kT,
-                     seed=(int(seed) or 1) if on_device_rng else 0)
+        eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=0.0 if nh else friction, kT=kT,
+                     seed=(int(seed) or 1) if on_device_rng else 0, ttime=tdamp_fs * FS if nh else None)
         # (skip_gate: the configuration has been through calculate() — logged, counted, the model updated if need be —
         # and is evaluated once more on the device, whatever its covloss, to move on from it)
         done, rows, skip_gate, t_host = 0, np.empty((0, N, 3)), first_on_host, 0.0
@@ -527,10 +533,10 @@ class ActiveCalculator(Calculator):
             if sync_every and not skip_gate:
                 n = min(n, sync_every - done % sync_every if done % sync_every else 1)   # (… a batch ends on a multiple)
             final = done + n == steps + 1
-            need = 0 if on_device_rng else (n - 1 if final else n)
+            need = 0 if (on_device_rng or nh) else (n - 1 if final else n)
             if len(rows) < need:
                 rows = np.concatenate([rows, rng.normal(size=(need - len(rows), N, 3))])
-            noise = None if on_device_rng else (rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))]))
+            noise = None if (on_device_rng or nh) else (rows[:n] if len(rows) >= n else np.concatenate([rows, np.zeros((n - len(rows), N, 3))]))
             gate = 0.0 if skip_gate else self._md_gate(numbers)
             t_run = time.time()
             sc, code = eng.md_run(n, noise, ediff=gate, final=final)

@@ -2,9 +2,10 @@
 
     python -m autoforce_amd.cl.md -i start.xyz -o final.xyz        # keywords from ./ARGS
 
-Langevin dynamics (the reference's `dynamics = 'Langevin'`, cl/md.py:117-128) runs with positions and velocities in
-device memory (ActiveCalculator.run_md); `dynamics = 'NPT'` (cl/md.py:131-166) is ase.md.npt.NPT around the calculator
-and needs ASE.  Structures are read and written as extended XYZ (ASE's own format; without ASE no other reader exists
+Langevin dynamics (the reference's `dynamics = 'Langevin'`, cl/md.py:117-128) and the reference's DEFAULT — `dynamics =
+'NPT'` without a bulk modulus: Nose-Hoover NVT, ase.md.npt.NPT(pfactor=None, ttime=tdamp fs), cl/md.py:17, :131-166 — run with
+positions and velocities in device memory (ActiveCalculator.run_md); NPT with a bulk modulus (a cell that moves) is
+ase.md.npt.NPT around the calculator and needs ASE.  Structures are read and written as extended XYZ (ASE's own format; without ASE no other reader exists
 here), the trajectory likewise (`trajectory = 'md.xyz'`)."""
 import argparse
 
@@ -73,10 +74,11 @@ def manual_steps(atoms, calc, eps, rng):
     calc._logpref = ""
 
 
-def md(atoms, calc=None, dynamics="Langevin", dt=None, tem=300.0, picos=100, trajectory="md.xyz", loginterval=1, append=False,
+def md(atoms, calc=None, dynamics="NPT", dt=None, tem=300.0, picos=100, trajectory="md.xyz", loginterval=1, append=False,
        rattle=0.0, friction=1e-3, eps_pos=0.05, seed=None, bulk_modulus=None, stress=0.0, mask=None, iso=False, tdamp=25, pdamp=100,
        ml_filter=0.8, eps_cell=0.05):
-    """The keywords of theforce/cl/md.py::md (same names, same defaults except `dynamics`: the reference defaults to NPT).
+    """The keywords of theforce/cl/md.py::md (same names, same defaults: `dynamics = 'NPT'` with `bulk_modulus = None` is
+    Nose-Hoover NVT with the damping time `tdamp` fs).
     picos > 0: pico-seconds per temperature; picos < 0: -picos steps (cl/md.py:100)."""
     rng = np.random.default_rng(seed)
     numbers = np.asarray(atoms.numbers)
@@ -97,14 +99,19 @@ def md(atoms, calc=None, dynamics="Langevin", dt=None, tem=300.0, picos=100, tra
         atoms.set_velocities(init_velocities(numbers, masses, temperatures[0], rng))
     if dt is None:
         dt = 0.25 if (numbers == 1).any() else 1.0          # cl/md.py:70-74
-    if dynamics.upper() != "LANGEVIN":
-        raise NotImplementedError("dynamics = 'NPT' is ase.md.npt.NPT around this calculator (cl/md.py:131-166): install ASE and "
-                                  "use the reference's driver with autoforce_amd.calculator.ActiveCalculator; here: 'Langevin'")
+    if dynamics.upper() not in ("LANGEVIN", "NPT"):
+        raise ValueError(f"dynamics = {dynamics!r}: 'NPT' or 'Langevin' (cl/md.py:84-101)")
+    if dynamics.upper() == "NPT" and bulk_modulus:
+        raise NotImplementedError("NPT with a bulk modulus (a cell that moves) is ase.md.npt.NPT around this calculator "
+                                  "(cl/md.py:131-166): install ASE and use the reference's driver with "
+                                  "autoforce_amd.calculator.ActiveCalculator; here: bulk_modulus = None (Nose-Hoover NVT) or 'Langevin'")
+    tdamp_fs = float(tdamp) if dynamics.upper() == "NPT" else None
     out = open(trajectory, "a" if append else "w") if (trajectory and calc.rank == 0) else None
     for T in temperatures:
         steps = int(picos * 1000 / dt) if picos > 0 else int(-picos)
         for step, energy, temperature, updated, wall in calc.run_md(atoms, steps, T, dt_fs=dt, friction=friction, rng=None,
-                                                                    seed=int(rng.integers(1, 2 ** 62)), sync_every=loginterval or None):
+                                                                    seed=int(rng.integers(1, 2 ** 62)), sync_every=loginterval or None,
+                                                                    tdamp_fs=tdamp_fs):
             if out is not None and loginterval and step % loginterval == 0:
                 # (the state lives on the device: run_md brings the positions back at the steps a trajectory wants them)
                 out.writelines(format_extxyz(Frame(numbers, atoms.positions, atoms.cell, atoms.pbc, energy, None, None)))

@@ -196,15 +196,16 @@ def _device_order_sum(x):
     return float(p[0])
 
 
-def nose_hoover_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, tdamp_fs=25.0, vel=None, seed=1):
+def nose_hoover_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_fs=1.0, tdamp_fs=25.0, vel=None, seed=1, species=None):
     """Nose-Hoover NVT in numpy around any calculator with the ASE surface: the reference's DEFAULT dynamics —
     md(dynamics="NPT", bulk_modulus=None) = ase.md.npt.NPT(pfactor=None, ttime=tdamp fs), cl/md.py:17, :131-166 — restated
     from ASE's published algorithm (Melchionna, Ciccotti, Holian 1993; ASE is absent here):
         x_(n+1) = (2 x_n - x_(n-1) (1 - b) + dt^2 F_n / m) / (1 + b),  b = dt zeta_n / 2,  v_n = (x_(n+1) - x_(n-1)) / 2 dt
         zeta_(n+1) = zeta_(n-1) + 2 dt tfact (KE_n - 1.5 (N - 1) kT),  tfact = 2 / (3 N kT ttime^2)
     started with x_(-1) = x_0 - dt v_0 + dt^2 F_0 / 2m, zeta_0 = 0, zeta_(-1) = -dt tfact (KE_0 - ...).  The host twin of the
-    device loop (sgpr_md_thermostat): same operations in the same order, bit for bit.  Yields (step, energy, temperature,
-    wall seconds, positions, velocities, zeta, integral of zeta) per evaluated configuration."""
+    device loop (sgpr_md_thermostat): same operations in the same order, bit for bit (the kinetic energy is summed over the
+    atoms in the library's species-sorted order: `species` = the model's table, default the sorted atomic numbers).  Yields
+    (step, energy, temperature, wall seconds, positions, velocities, zeta, integral of zeta) per evaluated configuration."""
     import time
     from .ase_shim import Atoms, kB
     N = len(numbers)
@@ -224,6 +225,8 @@ def nose_hoover_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_
     x = np.array(pos, float)
     xp = None
     zeta, zint = {0: 0.0}, {0: 0.0}
+    table = sorted(set(int(z) for z in numbers)) if species is None else [int(z) for z in species]
+    order = np.argsort([table.index(int(z)) if int(z) in table else len(table) for z in numbers], kind="stable")
 
     def forces(p, v):
         at = Atoms(numbers, p, cell, pbc, velocities=v, masses=mass[:, 0])
@@ -241,7 +244,7 @@ def nose_hoover_nvt(calc, numbers, pos, cell, pbc, steps, temperature=600.0, dt_
         v = v0 if n == 0 else (xn - xp) / (2.0 * dt)
         ke3 = mass * (v * v)
         ke_atom = (ke3[:, 0] + ke3[:, 1]) + ke3[:, 2]
-        KE = 0.5 * _device_order_sum(ke_atom)
+        KE = 0.5 * _device_order_sum(ke_atom[order])
         d = KE - K0
         zprev = -(c1 * d) if n == 0 else zeta[n - 1]
         zeta[n + 1] = zprev + c2 * d

@@ -430,3 +430,130 @@ def test_a_capacity_outgrown_inside_the_device_loop_is_resized_and_the_run_goes_
     st = dev_mdl.md_state(results=True)
     assert np.array_equal(st["positions"], host[-1][2]) and np.array_equal(st["velocities"], host[-1][3])
     mdl.close(); dev_mdl.close()
+
+
+def test_device_nose_hoover_equals_the_host_twin_bit_for_bit_and_survives_halts():
+    """Nose-Hoover NVT (the reference's default dynamics: ase.md.npt.NPT with pfactor = None, cl/md.py:17, :131-166) inside the
+    step's last kernel against workloads.nose_hoover_nvt around the same library: positions, centred velocities, zeta and
+    its integral after 60 steps bit for bit, however the run is batched; a covloss halt in the middle hands back exactly the
+    host loop's configuration and the run goes on along the same trajectory."""
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS, nose_hoover_nvt
+    mdl, (numbers, pos, cell, pbc) = _model()
+    N, steps, T, tdamp = len(numbers), 60, 700.0, 20.0
+    mass = np.array([MASS[int(z)] for z in numbers])
+    rng = np.random.default_rng(8)
+    vel = rng.normal(size=(N, 3)) * np.sqrt(kB * T / mass[:, None])
+    calc = _PredictCalc(mdl)
+    host = [(s, E, Tk, p.copy(), v.copy(), z, zi) for s, E, Tk, w, p, v, z, zi in
+            nose_hoover_nvt(calc, numbers, pos, cell, pbc, steps, temperature=T, dt_fs=1.0, tdamp_fs=tdamp, vel=vel)]
+    b = np.array(calc.betas)
+
+    def begin():
+        mdl.md_begin(numbers, pos, cell, pbc, mass, vel, dt=1.0 * FS, friction=0.0, kT=kB * T, ttime=tdamp * FS)
+
+    begin()
+    rows = []
+    for n in (7, 1, 20, 33):
+        sc, code = mdl.md_run(n, None, final=(len(rows) + n == steps + 1))
+        assert code == 0 and len(sc) == n
+        rows.extend(sc)
+    sc = np.array(rows)
+    assert len(sc) == steps + 1
+    assert [r[0] for r in sc] == [h[1] for h in host]                         # energies: same positions, same step
+    assert np.array_equal(sc[:, 14], np.array([h[5] for h in host]))           # zeta
+    assert np.array_equal(sc[:, 15], np.array([h[6] for h in host]))           # its integral
+    np.testing.assert_allclose(sc[:, 12] / (3 * N * kB), [h[2] for h in host], rtol=1e-12)
+    st = mdl.md_state(results=True)
+    assert np.array_equal(st["positions"], host[-1][3]) and np.array_equal(st["velocities"], host[-1][4])
+    assert np.array_equal(st["velocities_pre"], host[-2][4])                   # what the integrator held when it asked for F
+    # the thermostat acts: zeta leaves zero, the temperature stays near the target
+    assert np.abs(sc[:, 14]).max() > 0 and abs(np.mean(sc[20:, 12]) / (3 * N * kB) - T) < 0.25 * T
+    # a halt in the middle
+    later = np.nonzero(b > b[:3].max())[0]
+    assert len(later), "the covloss never exceeds its starting value on this walk"
+    k = int(later[0])
+    ediff = 0.5 * (b[:k].max() + b[k])
+    begin()
+    sc1, code = mdl.md_run(steps + 1, None, ediff=ediff, final=True)
+    assert code == 1 and len(sc1) == k + 1
+    sth = mdl.md_state(results=True)
+    assert np.array_equal(sth["positions"], host[k][3]) and np.array_equal(sth["velocities"], host[k][4])
+    assert np.array_equal(sth["velocities_pre"], host[k - 1][4] if k else vel)
+    sc2, code = mdl.md_run(steps + 1 - k, None, ediff=0.0, final=True)         # the halted configuration again, then on
+    assert code == 0 and [r[0] for r in sc2] == [h[1] for h in host[k:]]
+    assert np.array_equal(sc2[:, 14], np.array([h[5] for h in host[k:]]))
+    st2 = mdl.md_state(results=True)
+    assert np.array_equal(st2["positions"], host[-1][3]) and np.array_equal(st2["velocities"], host[-1][4])
+    mdl.close()
+
+
+def test_nose_hoover_conserves_its_extended_energy():
+    """E + KE + 1.5 N kT (ttime zeta)^2 + 3 (N - 1) kT int zeta dt (ase.md.npt.NPT.get_gibbs_free_energy without the cell
+    terms) over 1500 steps: its drift is a small fraction of what the thermostat moves in and out of the system."""
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS, fit_to_teacher
+    mdl, (numbers, pos, cell, pbc) = _model(scale=0.05)
+    fit_to_teacher(mdl, numbers, pos, cell, pbc)
+    mdl.set_weights(mdl.mu, choli=mdl.choli, vscale=mdl.make_vscale())
+    N, T, tdamp = len(numbers), 600.0, 25.0
+    mass = np.array([MASS[int(z)] for z in numbers])
+    rng = np.random.default_rng(1)
+    vel = rng.normal(size=(N, 3)) * np.sqrt(kB * 300.0 / mass[:, None])   # starts cold: the thermostat has work to do
+    mdl.md_begin(numbers, pos, cell, pbc, mass, vel, dt=1.0 * FS, friction=0.0, kT=kB * T, ttime=tdamp * FS)
+    rows = []
+    while len(rows) < 1500:
+        sc, code = mdl.md_run(min(500, 1500 - len(rows)), None)
+        assert code in (0, 2)
+        rows.extend(sc)
+    sc = np.array(rows)
+    ttime, kT = tdamp * FS, kB * T
+    thermostat = 1.5 * N * kT * (ttime * sc[:, 14]) ** 2 + 3 * (N - 1) * kT * sc[:, 15]
+    H = sc[:, 0] + 0.5 * sc[:, 12] + thermostat
+    Tk = sc[:, 12] / (3 * N * kB)
+    assert abs(Tk[500:].mean() - T) < 0.08 * T, Tk[500:].mean()
+    assert np.ptp(thermostat) > 0.5 * 1.5 * N * kB * 300.0            # it pumped a good part of the missing kinetic energy in
+    assert np.abs(H - H[0]).max() < 0.02 * np.ptp(thermostat), (np.abs(H - H[0]).max(), np.ptp(thermostat))
+    mdl.close()
+
+
+def test_run_md_nose_hoover_on_the_device_equals_the_host_loop(tmp_path):
+    """ActiveCalculator.run_md(tdamp_fs=...) — the reference CLI's default dynamics — with the state on the device against
+    the host loop (workloads.nose_hoover_nvt around calculate()) of the same calculator class: same updates at the same
+    steps, same energies, same final state."""
+    import active_common as ac
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from helpers import PairTeacher
+    from autoforce_amd.workloads import nose_hoover_nvt
+
+    def run(device):
+        np.random.seed(5)
+        rng0, numbers, pos, cell = ac.start(0)
+        d = tmp_path / ("dev" if device else "host")
+        d.mkdir()
+        calc = ActiveCalculator(engine=SGPRModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=PairTeacher(rc=4.0),
+                                logfile=str(d / "active.log"), pckl=None, tape=None, **ac.KW)
+        at = Atoms(numbers, pos, cell, True)
+        vel = np.random.default_rng(3).normal(size=pos.shape) * 0.02
+        at.set_velocities(vel)
+        steps = 40
+        if device:
+            out = [(s, E, bool(u)) for s, E, T, u, w in calc.run_md(at, steps, 300.0, dt_fs=1.0, tdamp_fs=20.0, chunk=16)]
+            return out, at.positions.copy(), at.get_velocities(), calc.size
+        out = []
+        numbers_, pos_, cell_, pbc_ = calc._system(at)
+        for s, E, T, w, p, v, z, zi in nose_hoover_nvt(calc, numbers_, pos_, cell_, pbc_, steps, 300.0, 1.0, 20.0, vel=vel):
+            out.append((s, E, bool(calc.updated)))
+            last = (p.copy(), v.copy())
+        return out, last[0], last[1], calc.size
+
+    dev, xd, vd, sized = run(True)
+    host, xh, vh, sizeh = run(False)
+    assert sized == sizeh and sized[1] > 2
+    assert [d[0] for d in dev] == [h[0] for h in host]
+    np.testing.assert_allclose([d[1] for d in dev], [h[1] for h in host], rtol=0, atol=1e-9)
+    assert [d[2] for d in dev] == [h[2] for h in host]
+    np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(vd, vh, rtol=0, atol=1e-9)
