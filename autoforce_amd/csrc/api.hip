@@ -661,6 +661,22 @@ __device__ __forceinline__ void finalize_reduce_prev(const FinArgs &f, int q)
     }
 }
 
+// A fused last kernel decides the NEXT step's rebuild by |x - pos0| <= skin / 2, the constant-cell rule.  If the cell of this
+// step is not the one the candidates were built in (a caller strained it between two steps without a rebuild), that rule
+// under-counts (the binning kernel's affine rule, neighbor.hip, is what applies): the next step then simply rebuilds.  One
+// lane, 18 loads; on a step that rebuilt, cell0 is being set to this very cell by the reducer.
+__device__ __forceinline__ void fin_cell_guard(const FinArgs &f, int rebuilt, int s1)
+{
+    if (rebuilt || !f.cell0 || !f.cell) return;
+    double a[9], b[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { a[k] = f.cell[k]; b[k] = f.cell0[k]; }
+    bool differ = false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) differ |= a[k] != b[k];
+    if (differ) atomicMax(&f.nx.flags[s1 & 3], 1);
+}
+
 // scatter form (sharded frames): F = atomic part + own part, one thread per atom
 __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
 {
@@ -739,6 +755,7 @@ __global__ __launch_bounds__(256) void finalize_scatter_next_kernel(FinArgs f)
     if (i == 0) {
         if (x.force) atomicMax(&x.flags[s1 & 3], 1);
         x.flags[(s1 + 2) & 3] = 0;
+        fin_cell_guard(f, rebuilt, s1);
     }
     if (!act) return;
 #pragma unroll
@@ -1015,6 +1032,7 @@ __global__ __launch_bounds__(256) void finalize_next_kernel(FinArgs f)
         // step s + 3 is cleared for the binning after the next (neighbor.hip does the same with its cycle)
         if (x.force) atomicMax(&x.flags[s1 & 3], 1);
         x.flags[(s1 + 2) & 3] = 0;
+        fin_cell_guard(f, rebuilt, s1);
     }
     if (!act) return;
     if (f.has_beta)
@@ -3076,6 +3094,12 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
         h->warm = false; h->gemm_fused = false;
         return fail(SGPR_E_OVERFLOW, "the fused GEMM launch timed out waiting for its K_nm tiles (separate launches from now on); "
                     "results since the last check are invalid");
+    }
+    if (stat[3] == 3) {
+        h->warm = false;
+        h->lists_valid = false;
+        return fail(SGPR_E_OVERFLOW, "a pair force beyond 1024 eV/A left the fixed-point range of the sharded (scatter-form) reverse pass: "
+                    "two atoms are unphysically close; results since the last check are invalid (the unsharded gather form has no such limit)");
     }
     if (stat[3]) {
         h->warm = false;

@@ -262,6 +262,9 @@ int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *pos
  *   packed[4N]         energy (partial; mean term added on rank 0 only)
  *   packed[4N+1..+9)   virial sum_pairs r (x) dE/dr (partial), row-major 3x3
  *   packed[4N+10]      1 if this rank's step overflowed a capacity (results invalid), else 0
+ * (Sharded steps accumulate the forces neighbours receive as 64-bit fixed-point integers, 2^-46 eV/A per unit, so that a
+ * rank's partial sums do not depend on the order the atomics land in: a single pair force beyond 1024 eV/A — two atoms
+ * unphysically close — is outside that format and fails the step with SGPR_E_OVERFLOW; the unsharded path has no such limit.)
  * i.e. exactly what one all-reduce(SUM) over ranks must combine (the reference's four
  * collectives calculator/active.py:562,601,602,777 fused into one buffer).  With a communicator
  * attached (sgpr_comm_init) the step ends with that all-reduce, enqueued on the same stream: the
@@ -281,7 +284,9 @@ int sgpr_step_dev(sgpr_model *h, const double *positions_dev, const double *cell
  * pass exactly `positions_next_dev` — starts with the list filter instead of a binning launch (6 -> 5 launches per
  * step).  A call that passes anything else is served as usual.  positions_next_dev = NULL: sgpr_step_dev.
  * The next step is binned with the cell AS IT IS NOW: a driver that changes the contents of `cell_dev` between two steps
- * (NPT) passes NULL for the step in front of the change — every step of such a run bins for itself.
+ * (NPT) passes NULL for the step in front of the change — every step of such a run bins for itself.  (A chain that runs in
+ * another cell than the one its candidate lists were built in notices — the last kernel compares the two — and rebuilds
+ * them at its next step.)
  * (The reference asks ASE for a fresh list inside every calculate(), descriptor/atoms.py:348-363, :402.)
  */
 int sgpr_step_dev_next(sgpr_model *h, const double *positions_dev, const double *cell_dev,

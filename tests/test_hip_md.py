@@ -557,3 +557,69 @@ def test_run_md_nose_hoover_on_the_device_equals_the_host_loop(tmp_path):
     assert [d[2] for d in dev] == [h[2] for h in host]
     np.testing.assert_allclose(xd, xh, rtol=0, atol=1e-9)
     np.testing.assert_allclose(vd, vh, rtol=0, atol=1e-9)
+
+
+def test_device_loop_survives_other_frames_on_the_handle_between_its_calls():
+    """A model update between two sgpr_md_run calls evaluates OTHER frames on the same handle (the training rows of stored
+    frames, trial models): the handle is then bound to a system of another size or composition.  The run binds its own
+    system back (and sgpr_md_state reads the run's own permutation): the trajectory is the uninterrupted one, bit for bit."""
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS, lips
+    mdl, (numbers, pos, cell, pbc) = _model()
+    N = len(numbers)
+    mass = np.array([MASS[int(z)] for z in numbers])
+    vel = np.random.default_rng(6).normal(size=(N, 3)) * np.sqrt(kB * 600.0 / mass[:, None])
+
+    def begin():
+        mdl.md_begin(numbers, pos, cell, pbc, mass, vel, dt=1.0 * FS, friction=0.02, kT=kB * 600.0, seed=5)
+
+    begin()
+    sc, _ = mdl.md_run(30, None, final=True)
+    ref = mdl.md_state(results=True)
+    begin()
+    sc1, _ = mdl.md_run(12, None)
+    # another system on the handle: fewer atoms, and one of the same size with another composition
+    n2, p2, c2, b2 = lips(6, seed=3)
+    mdl.predict(n2, p2, c2, b2)
+    shuffled = np.random.default_rng(1).permutation(numbers)
+    mdl.predict(shuffled, pos, cell, pbc)
+    mid = mdl.md_state()                                  # (while the handle is bound elsewhere)
+    sc2, _ = mdl.md_run(18, None, final=True)
+    st = mdl.md_state(results=True)
+    assert np.array_equal(np.concatenate([sc1, sc2])[:, 0], sc[:, 0])
+    assert np.array_equal(st["positions"], ref["positions"]) and np.array_equal(st["velocities"], ref["velocities"])
+    begin()
+    mdl.md_run(12, None)
+    assert np.array_equal(mdl.md_state()["positions"], mid["positions"])
+    mdl.close()
+
+
+def test_one_off_entry_points_give_their_device_memory_back():
+    """sgpr_jitcholesky and sgpr_md_deviates work in buffers of their own: given back on every way out."""
+    import torch
+    from autoforce_amd.ase_shim import kB
+    from autoforce_amd.workloads import FS, MASS
+    mdl, (numbers, pos, cell, pbc) = _model()
+    mass = np.array([MASS[int(z)] for z in numbers])
+    mdl.md_begin(numbers, pos, cell, pbc, mass, None, dt=FS, friction=1e-3, kT=kB * 300.0, seed=3)
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(700, 700))
+    A = A @ A.T + 700 * np.eye(700)
+
+    def cycle():
+        mdl.jitcholesky(A)
+        mdl.md_deviates(0, 64)
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(8):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (4 << 20), (free0, free1)   # (eight leaked calls were 80 MB)
+    with pytest.raises(Exception):
+        mdl.jitcholesky(-np.eye(300))                   # the error path, too
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (4 << 20)
+    mdl.close()
