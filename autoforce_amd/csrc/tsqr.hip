@@ -723,6 +723,7 @@ size_t lstsq_qr_blocked_work_doubles(int rows, int cols)
     tsqr_levels(std::max(rows, 1), ch);
     size_t total = 0;
     for (int c : ch) total += (size_t)c * (2 * TNB * TCH + TNB * TNB);  // V, stacked R of the level above, T
+    total = std::max(total, (size_t)2 * (32 * 1088 + 32 * 32));          // (the flat-panel form of banded problems: bandqr.inc)
     return total + (size_t)cols * cols + cols + 64;
 }
 
@@ -838,10 +839,22 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
     }
 }
 
+#include "bandqr.inc"
+int g_bandqr_force = -1;   // tools/bandqr_test.hip: 0 / 1 overrides the environment
+static bool band_qr_on()
+{
+    static const bool on = !(getenv("SGPR_BANDQR") && atoi(getenv("SGPR_BANDQR")) == 0);   // SGPR_BANDQR=0: the tree form everywhere
+    return g_bandqr_force >= 0 ? g_bandqr_force != 0 : on;
+}
+
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band,
                             double *keep, std::vector<TsqrPanel> *panels, int extra, int band_off)
 {
     if (cols > 2048 || rows < cols || ldr < rows) return -1;
+    // banded problems whose panels fit one workgroup's registers: one launch per panel (bandqr.inc)
+    if (band > 0 && !keep && !panels && band_qr_on() &&
+        launch_band_qr(rows, cols, At, ldr, x, work, st, band, band_off, extra, 1, 0, 0) == 0)
+        return 0;
     tsqr_attrs();
     size_t scratch = 0;
     {
@@ -878,6 +891,8 @@ int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_m
     if (cols > 2048 || rows < cols || ldr < rows || batch < 1) return -1;
     tsqr_attrs();
     const size_t bs_work = lstsq_qr_blocked_work_doubles(rows, cols);
+    if (band > 0 && band_qr_on() && launch_band_qr(rows, cols, At, ldr, x, work, st, band, 0, 0, batch, bs_mat, bs_work) == 0)
+        return 0;
     size_t scratch = 0;
     {
         std::vector<int> ch;

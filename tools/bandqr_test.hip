@@ -1,0 +1,110 @@
+// bandqr_test.hip — the flat-panel band QR (csrc/bandqr.inc) against the tree form and a CPU Householder QR on random
+// interleaved [R1; sigma L^T | z] problems: correctness (R, x) and time per solve.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -o tools/bandqr_test tools/bandqr_test.hip
+//   tools/bandqr_test [m ...]
+#include "../autoforce_amd/csrc/tsqr.hip"
+#include <math.h>
+#include <stdio.h>
+#include <random>
+void host_build_harm_coef(HarmCoef *) {}
+extern int g_bandqr_force;
+
+static void cpu_lstsq(int R, int m, std::vector<double> A /*col-major R x (m+1)*/, std::vector<double> &x, std::vector<double> &Rout)
+{
+    for (int j = 0; j < m; j++) {
+        double s2 = 0.0;
+        for (int r = j; r < R; r++) s2 += A[(size_t)j * R + r] * A[(size_t)j * R + r];
+        const double nrm = sqrt(s2), akk = A[(size_t)j * R + j];
+        if (nrm == 0.0) continue;
+        const double alpha = akk > 0 ? -nrm : nrm;
+        std::vector<double> v(R, 0.0);
+        for (int r = j; r < R; r++) v[r] = A[(size_t)j * R + r];
+        v[j] -= alpha;
+        double vv = 0.0;
+        for (int r = j; r < R; r++) vv += v[r] * v[r];
+        for (int c = j; c <= m; c++) {
+            double d = 0.0;
+            for (int r = j; r < R; r++) d += v[r] * A[(size_t)c * R + r];
+            const double f = 2.0 * d / vv;
+            for (int r = j; r < R; r++) A[(size_t)c * R + r] -= f * v[r];
+        }
+    }
+    x.assign(m, 0.0);
+    for (int i = m - 1; i >= 0; i--) {
+        double s = A[(size_t)m * R + i];
+        for (int c = i + 1; c < m; c++) s -= A[(size_t)c * R + i] * x[c];
+        x[i] = s / A[(size_t)i * R + i];
+    }
+    Rout.assign((size_t)m * m, 0.0);
+    for (int c = 0; c < m; c++)
+        for (int i = 0; i <= c; i++) Rout[(size_t)c * m + i] = A[(size_t)c * R + i];
+}
+
+int main(int argc, char **argv)
+{
+    std::vector<int> ms;
+    for (int k = 1; k < argc; k++) ms.push_back(atoi(argv[k]));
+    if (ms.empty()) ms = {1, 2, 5, 12, 31, 32, 33, 64, 100, 257, 512, 1024};
+    hipStream_t st;
+    hipStreamCreate(&st);
+    for (int m : ms) {
+        const int R = 2 * m, ldr = (R + 63) / 64 * 64, cpad = (m + 1 + 63) / 64 * 64 + 64;
+        std::mt19937_64 gen(m);
+        std::normal_distribution<double> nd;
+        std::vector<double> A((size_t)cpad * ldr, 0.0), Ad((size_t)R * (m + 1), 0.0);
+        for (int c = 0; c < m; c++)
+            for (int i = 0; i <= c; i++) {
+                A[(size_t)c * ldr + 2 * i] = nd(gen) + (i == c ? 3.0 : 0.0);        // R1 row i
+                A[(size_t)c * ldr + 2 * i + 1] = 0.05 * (nd(gen) + (i == c ? 3.0 : 0.0));   // sigma L^T row i
+            }
+        for (int i = 0; i < m; i++) A[(size_t)m * ldr + 2 * i] = nd(gen);
+        for (int c = 0; c <= m; c++)
+            for (int r = 0; r < R; r++) Ad[(size_t)c * R + r] = A[(size_t)c * ldr + r];
+        std::vector<double> xref, Rref;
+        if (m <= 300) cpu_lstsq(R, m, Ad, xref, Rref);
+        double *dA, *dx, *dw;
+        const size_t wd = lstsq_qr_blocked_work_doubles(R, m);
+        hipMalloc((void **)&dA, sizeof(double) * A.size());
+        hipMalloc((void **)&dx, sizeof(double) * m);
+        hipMalloc((void **)&dw, sizeof(double) * wd);
+        std::vector<double> xs[2], Rs[2];
+        for (int form = 0; form < 2; form++) {
+            g_bandqr_force = form;
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; rep++) {
+                hipMemcpy(dA, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice);
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0, st);
+                const int rc = launch_lstsq_qr_blocked(R, m, dA, ldr, dx, dw, st, 2);
+                hipEventRecord(e1, st);
+                hipStreamSynchronize(st);
+                if (rc || hipGetLastError() != hipSuccess) { printf("m %d form %d: launch failed %d\n", m, form, rc); return 1; }
+                float ms_ = 0;
+                hipEventElapsedTime(&ms_, e0, e1);
+                best = std::min(best, ms_);
+            }
+            xs[form].resize(m);
+            hipMemcpy(xs[form].data(), dx, sizeof(double) * m, hipMemcpyDeviceToHost);
+            std::vector<double> Af(A.size());
+            hipMemcpy(Af.data(), dA, sizeof(double) * A.size(), hipMemcpyDeviceToHost);
+            Rs[form].assign((size_t)m * m, 0.0);
+            for (int c = 0; c < m; c++)
+                for (int i = 0; i <= c; i++) Rs[form][(size_t)c * m + i] = Af[(size_t)c * ldr + i];
+            printf("m %4d %s: %.3f ms", m, form ? "flat panels" : "tree       ", best);
+            if (!xref.empty()) {
+                double ex = 0, er = 0, nx = 0;
+                for (int i = 0; i < m; i++) { ex = std::max(ex, fabs(xs[form][i] - xref[i])); nx = std::max(nx, fabs(xref[i])); }
+                // R rows are defined up to a sign: compare |R|
+                for (size_t e = 0; e < Rref.size(); e++) er = std::max(er, fabs(fabs(Rs[form][e]) - fabs(Rref[e])));
+                printf("  |x - cpu| %.2e (max |x| %.2e)  ||R| - |R cpu|| %.2e", ex, nx, er);
+            }
+            printf("\n");
+        }
+        double dxm = 0, nxm = 0;
+        for (int i = 0; i < m; i++) { dxm = std::max(dxm, fabs(xs[0][i] - xs[1][i])); nxm = std::max(nxm, fabs(xs[0][i])); }
+        printf("        flat vs tree: max |dx| %.2e of %.2e\n", dxm, nxm);
+        hipFree(dA); hipFree(dx); hipFree(dw);
+    }
+    return 0;
+}
