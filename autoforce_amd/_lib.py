@@ -61,6 +61,7 @@ SIGNATURES = {
     "sgpr_select_inducing": (C.c_int, [_vp, C.c_int, _vp]),
     "sgpr_kernel_local": (C.c_int, [_vp, _i32, C.c_int, _vp, _vp, _vp, _vp]),
     "sgpr_compute": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "sgpr_compute_view": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "sgpr_bind_system": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int]),
     "sgpr_packed_len": (_i64, [C.c_int]),
     "sgpr_step_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -95,12 +95,31 @@ class Calculator:
 
     def _changed(self, atoms):
         a = self.atoms
-        return (a is None or len(a) != len(atoms) or not np.array_equal(a.numbers, atoms.numbers)
-                or not np.array_equal(a.positions, atoms.positions) or not np.array_equal(a.cell, atoms.cell)
+        # (positions first: in a loop they are what has changed — and of them the first coordinate, one scalar comparison,
+        # before 3N of them)
+        if a is None or len(a) != len(atoms) or (len(a) and a.positions[0, 0] != atoms.positions[0, 0]):
+            return True
+        return (not np.array_equal(a.positions, atoms.positions)
+                or not np.array_equal(a.numbers, atoms.numbers) or not np.array_equal(a.cell, atoms.cell)
                 or not np.array_equal(a.pbc, atoms.pbc))
 
     def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes):
-        if atoms is not None:
+        """ase.calculators.calculator.Calculator.calculate: the calculator keeps a COPY of the atoms it was asked about.  The
+        copy of the previous call is re-used when the frame is the same system (same numbers): its arrays are overwritten in
+        place instead of six fresh allocations per step."""
+        if atoms is None:
+            return
+        a = self.atoms
+        if (a is not None and a is not atoms and len(a) == len(atoms) and np.array_equal(a.numbers, atoms.numbers)
+                and (a._velocities is None) == (atoms._velocities is None) and (a._masses is None) == (atoms._masses is None)):
+            np.copyto(a.positions, atoms.positions)
+            np.copyto(a.cell, atoms.cell)
+            np.copyto(a.pbc, atoms.pbc)
+            if atoms._velocities is not None:
+                np.copyto(a._velocities, atoms._velocities)
+            if atoms._masses is not None:
+                np.copyto(a._masses, atoms._masses)
+        else:
             self.atoms = atoms.copy()
 
     def get_property(self, name, atoms=None):

@@ -113,6 +113,7 @@ class ActiveCalculator(Calculator):
         self._wildcard = False
         self._comm_note, self._hello = "", False
         self._peer_atoms = 0
+        self._sys_cache = None
         self.get_model(engine if engine is not None else covariance, kernel_kw or {})
         self.ediff = ediff
         self.ediff_lb = ediff_lb or ediff
@@ -265,6 +266,19 @@ class ActiveCalculator(Calculator):
         return True
 
     @property
+    def maximum_force(self):
+        """max |F| of the frame in `results` (active.py:573-576; what the Switch thresholds depend on), computed when
+        somebody asks: a prediction-only step never does."""
+        if self._maxf is None:
+            f = self.results.get("forces")
+            self._maxf = inf if f is None else (float(np.abs(f).max()) if len(f) else 0.0)
+        return self._maxf
+
+    @maximum_force.setter
+    def maximum_force(self, value):
+        self._maxf = value
+
+    @property
     def engine(self):
         return self.model.engine
 
@@ -307,8 +321,13 @@ class ActiveCalculator(Calculator):
     # ------------------------------------------------------------------ the hot path
     def _system(self, atoms):
         cell = np.asarray(getattr(atoms.cell, "array", atoms.cell), dtype=float).reshape(3, 3)
-        return (np.asarray(atoms.numbers, dtype=np.int32), np.asarray(atoms.positions, dtype=float), cell,
-                np.asarray(atoms.pbc, dtype=bool))
+        # (the int32 copy of the atomic numbers is kept while the frame's numbers array is the same object with the same
+        # content: the conversion of 4096 numbers is 2-3 us of a 130-us step)
+        src = atoms.numbers
+        c = self._sys_cache
+        if c is None or c[0] is not src or len(c[1]) != len(src):   # (the calculator's copy of the atoms keeps ONE numbers array per system)
+            c = self._sys_cache = (src, np.asarray(src, dtype=np.int32))
+        return (c[1], np.asarray(atoms.positions, dtype=float), cell, np.asarray(atoms.pbc, dtype=bool))
 
     def _evaluate_engine(self, engine):
         """One device pass of `engine` over the current atoms (sharded + all-reduced when a process
@@ -321,7 +340,13 @@ class ActiveCalculator(Calculator):
             return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf), ready=False)
         if world > 1 and getattr(engine, "peer_world", 1) == world and N > self._peer_atoms and engine is self.engine:
             self._attach_peer(2 * N)   # (a larger frame than the exchange buffers hold: every rank sees the same N)
-        out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=False, beta=True)
+        fast = getattr(engine, "predict_view", None)
+        if fast is not None and (world == 1 or getattr(engine, "comm_world", 1) == world):
+            # results as views of the buffer the device wrote (valid until the call after next): copied where they are kept
+            v = fast(numbers, positions, cell, pbc, rank=rank, world=world)
+            out = dict(energy=float(v["energy"]), forces=np.array(v["forces"]), stress=np.array(v["stress"]), beta=np.array(v["beta"]))
+        else:
+            out = engine.predict(numbers, positions, cell, pbc, rank=rank, world=world, cov=False, beta=True)
         if world > 1 and getattr(engine, "comm_world", 1) == world:
             pass  # the library's own RCCL all-reduce already combined the ranks (totals on every rank)
         elif world > 1:
@@ -374,7 +399,7 @@ class ActiveCalculator(Calculator):
         self.results["energy"] = np.asarray(out["energy"])
         self.results["forces"] = np.asarray(out["forces"])
         self.results["stress"] = np.asarray(out["stress"])
-        self.maximum_force = float(np.abs(self.results["forces"]).max()) if len(self.atoms) else 0.0
+        self._maxf = None   # (maximum_force: computed when somebody asks, from these forces)
 
     def _ensure_species(self, numbers):
         """Wildcard mode (no `species` in kernel_kw): extend the model's table to the species met."""

@@ -352,6 +352,7 @@ struct sgpr_model {
     double *pin_dev = nullptr; // the same buffer as the device addresses it (zero-copy results)
     double *pin = nullptr;     // page-locked staging of sgpr_compute: [3N + 9] in | [4N + 11] out
     size_t pin_doubles = 0;
+    int pin_flip = 0;          // which of the two output halves of `pin` the last sgpr_compute wrote
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
@@ -2518,63 +2519,67 @@ static void poison_peers(sgpr_model *h, int N)
     memcpy(g_err, keep, sizeof(keep));
 }
 
-extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
-                            const double *cell, const int32_t *pbc, int rank, int world, double *energy,
-                            double *forces, double *stress, double *beta, double *cov)
+// One evaluation with host arrays in, results left in page-locked host memory: *po_out points at [F 3N | beta N | E | virial 9 |
+// overflow | stress 6] of THIS call (caller atom order).  Two output buffers alternate, so the results of the previous call stay
+// intact while this one runs.  The body of sgpr_compute (which copies them out) and of sgpr_compute_view (which hands them out).
+static int compute_core(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell, const int32_t *pbc,
+                        int rank, int world, bool want_cov, double **po_out)
 {
-    if (!h || N < 0 || !numbers || !positions || !cell) return fail(SGPR_E_INVALID, "sgpr_compute: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     bool same = (N == h->N && rank == h->rank && world == h->world && (int)h->numbers.size() == N);
-    if (same)
-        for (int i = 0; i < N && same; i++) same = h->numbers[i] == numbers[i];
+    if (same && memcmp(h->numbers.data(), numbers, sizeof(int32_t) * (size_t)N) != 0) same = false;
     if (same && pbc)
         for (int k = 0; k < 3; k++) same = same && (h->pbc[k] == (pbc[k] != 0));
     if (!same) {
         const int rc_ = sgpr_bind_system(h, N, numbers, pbc, rank, world);
         if (rc_) return rc_;
     }
-    if (N == 0) {
-        if (energy) *energy = 0.0;
-        if (stress) memset(stress, 0, sizeof(double) * 6);
-        return SGPR_OK;
-    }
     // warm path (capacities already sized for this system by a checked pass): one page-locked staging buffer each
     // way, ONE synchronisation; the step's own overflow word (packed[4N+10], finalize) says whether the capacities
     // held — if not, or on the first call, the checked path below re-sizes and repeats
-    const size_t n_in = (size_t)3 * N + 9, n_out = (size_t)4 * N + 11;
-    if (h->pin_doubles < n_in + n_out) {
+    const size_t n_in = (size_t)3 * N + 9, n_out = (size_t)4 * N + 11 + 6;
+    if (h->pin_doubles < n_in + 2 * n_out) {
         if (h->pin) (void)hipHostFree(h->pin);
         h->pin = nullptr; h->pin_doubles = 0;
-        if (hipHostMalloc((void **)&h->pin, sizeof(double) * (n_in + n_out + 64), hipHostMallocMapped) == hipSuccess) {
-            h->pin_doubles = n_in + n_out + 64;
+        if (hipHostMalloc((void **)&h->pin, sizeof(double) * (n_in + 2 * n_out + 64), hipHostMallocMapped) == hipSuccess) {
+            h->pin_doubles = n_in + 2 * n_out + 64;
             h->pin_dev = nullptr;
             if (hipHostGetDevicePointer((void **)&h->pin_dev, h->pin, 0) != hipSuccess) h->pin_dev = nullptr;
         }
     }
-    if (h->warm && h->pin && !cov) {
+    if (!h->pin) return fail(SGPR_E_NODEVICE, "sgpr_compute: no page-locked host memory");
+    h->pin_flip ^= 1;
+    const size_t off_out = n_in + (size_t)h->pin_flip * n_out;
+    double *pi = h->pin, *po = h->pin + off_out;
+    *po_out = po;
+    auto finish = [&]() {   // stress behind the packed results (calculator/active.py:604-610)
+        sgpr_stress_from_virial(po + 4 * (size_t)N + 1, cell, po + 4 * (size_t)N + 11);
+    };
+    if (h->warm && !want_cov) {
         static const bool tl = getenv("SGPR_COMPUTE_TIMELINE") != nullptr;  // diagnostic: host-side timeline of the warm path
         auto nowus = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
         double tls[6] = {0, 0, 0, 0, 0, 0};
         if (tl) tls[0] = nowus();
-        double *pi = h->pin, *po = h->pin + n_in;
         memcpy(pi, positions, sizeof(double) * 3 * N);
         memcpy(pi + 3 * (size_t)N, cell, sizeof(double) * 9);
-        // positions and cell travel as ONE copy (a second 72-byte copy is a whole DMA command of its own)
+        // positions and cell travel as ONE copy (a second 72-byte copy is a whole DMA command of its own) — or, by default,
+        // as none: the binning kernel reads them from the page-locked buffer itself (mapped into the device's address space;
+        // SGPR_ZERO_COPY_IN=0: the copy command), which takes a DMA command and its enqueue out of every call
         if (tl) tls[1] = nowus();
-        static const bool zin = getenv("SGPR_ZERO_COPY_IN") && atoi(getenv("SGPR_ZERO_COPY_IN")) != 0;  // experiment
+        static const bool zin = !(getenv("SGPR_ZERO_COPY_IN") && atoi(getenv("SGPR_ZERO_COPY_IN")) == 0);
         const bool in_direct = zin && h->pin_dev;
         if (!in_direct) HIPCHK(hipMemcpyAsync(h->d_pos_in.p, pi, sizeof(double) * n_in, hipMemcpyHostToDevice, h->stream));
         if (tl) tls[2] = nowus();
         // single rank: the last kernel writes the packed results straight into the page-locked buffer (host memory
         // mapped into the device's address space: posted PCIe writes inside the kernel) — no device-to-host copy
         // command behind the step, one synchronisation point less on the way out (option "zero_copy_out")
-        const bool direct = h->zero_copy_out && !h->comm && h->world == 1 && h->pin_dev;
+        const bool direct = h->zero_copy_out && !h->comm && !peer_on(h) && h->world == 1 && h->pin_dev;
         const double *pos_src = in_direct ? h->pin_dev : h->d_pos_in.p;
-        int rf = enqueue_step(h, pos_src, pos_src + 3 * (size_t)N, direct ? h->pin_dev + n_in : h->d_packed.p, h->stream);
+        int rf = enqueue_step(h, pos_src, pos_src + 3 * (size_t)N, direct ? h->pin_dev + off_out : h->d_packed.p, h->stream);
         if (rf) { poison_peers(h, N); return rf; }   // (a local enqueue failure: the peers are about to enter the all-reduce)
         rf = reduce_packed(h, h->d_packed.p, h->stream);
         if (rf) { h->warm = false; h->lists_valid = false; return rf; }
-        if (!direct) HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * n_out, hipMemcpyDeviceToHost, h->stream));
+        if (!direct) HIPCHK(hipMemcpyAsync(po, h->d_packed.p, sizeof(double) * ((size_t)4 * N + 11), hipMemcpyDeviceToHost, h->stream));
         if (tl) tls[3] = nowus();
         if (h->spin_wait) {  // option "spin_wait": poll the stream instead of a blocking wait
             hipError_t q;
@@ -2585,17 +2590,14 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         HIPCHK(hipGetLastError());
         if (tl) tls[4] = nowus();
         if (po[4 * (size_t)N + 10] == 0.0) {
-            if (forces) memcpy(forces, po, sizeof(double) * 3 * N);
-            if (beta) memcpy(beta, po + 3 * (size_t)N, sizeof(double) * N);
-            if (energy) *energy = po[4 * (size_t)N];
-            if (stress) sgpr_stress_from_virial(po + 4 * (size_t)N + 1, cell, stress);
+            finish();
             if (tl) {
                 tls[5] = nowus();
                 static double acc[5] = {0, 0, 0, 0, 0};
                 static int cnt = 0;
                 for (int k = 0; k < 5; k++) acc[k] += tls[k + 1] - tls[k];
                 if (++cnt % 200 == 0) {
-                    fprintf(stderr, "[sgpr timeline] warm sgpr_compute, mean of 200 (us): copy in %.1f | H2D enqueue %.1f | kernels enqueue %.1f | wait %.1f | copy out %.1f\n",
+                    fprintf(stderr, "[sgpr timeline] warm sgpr_compute, mean of 200 (us): copy in %.1f | H2D enqueue %.1f | kernels enqueue %.1f | wait %.1f | stress %.1f\n",
                             acc[0] / 200, acc[1] / 200, acc[2] / 200, acc[3] / 200, acc[4] / 200);
                     for (double &v : acc) v = 0.0;
                 }
@@ -2614,21 +2616,53 @@ extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const 
         const int rr = reduce_packed(h, h->d_packed.p, h->stream);
         if (rr) return rr;
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (const int pc = peer_check(h)) return pc;
     }
-    std::vector<double> out((size_t)4 * N + 11);
-    HIPCHK(hipMemcpy(out.data(), h->d_packed.p, sizeof(double) * out.size(), hipMemcpyDeviceToHost));
-    if (out[4 * (size_t)N + 10] >= 0.5 * SGPR_PEER_POISON) {
+    HIPCHK(hipMemcpy(po, h->d_packed.p, sizeof(double) * ((size_t)4 * N + 11), hipMemcpyDeviceToHost));
+    if (po[4 * (size_t)N + 10] >= 0.5 * SGPR_PEER_POISON) {
         h->warm = false;
         h->lists_valid = false;
         return fail(SGPR_E_OVERFLOW, "sgpr_compute: another rank of the communicator failed this step (its own error "
                     "message says why); the call fails on every rank");
     }
-    if (forces) memcpy(forces, out.data(), sizeof(double) * 3 * N);
-    if (beta) memcpy(beta, out.data() + 3 * (size_t)N, sizeof(double) * N);
-    if (energy) *energy = out[4 * (size_t)N];
-    if (stress) sgpr_stress_from_virial(out.data() + 4 * (size_t)N + 1, cell, stress);
+    finish();
+    return SGPR_OK;
+}
+
+extern "C" int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *positions,
+                            const double *cell, const int32_t *pbc, int rank, int world, double *energy,
+                            double *forces, double *stress, double *beta, double *cov)
+{
+    if (!h || N < 0 || !numbers || !positions || !cell) return fail(SGPR_E_INVALID, "sgpr_compute: bad arguments");
+    if (N == 0) {
+        HIPCHK(hipSetDevice(h->device));
+        const int rc_ = sgpr_bind_system(h, 0, numbers, pbc, rank, world);
+        if (rc_) return rc_;
+        if (energy) *energy = 0.0;
+        if (stress) memset(stress, 0, sizeof(double) * 6);
+        return SGPR_OK;
+    }
+    double *po = nullptr;
+    const int rc_ = compute_core(h, N, numbers, positions, cell, pbc, rank, world, cov != nullptr, &po);
+    if (rc_) return rc_;
+    if (forces) memcpy(forces, po, sizeof(double) * 3 * N);
+    if (beta) memcpy(beta, po + 3 * (size_t)N, sizeof(double) * N);
+    if (energy) *energy = po[4 * (size_t)N];
+    if (stress) memcpy(stress, po + 4 * (size_t)N + 11, sizeof(double) * 6);
     if (cov && h->m > 0) return sgpr_get_cov(h, N, h->m, cov);
     return SGPR_OK;
+}
+
+// sgpr_compute without the copies out: *packed_out points at this call's [F 3N | beta N | E | virial 9 | overflow | stress 6] in
+// page-locked host memory owned by the handle (caller atom order), valid until the call AFTER THE NEXT on this handle.
+extern "C" int sgpr_compute_view(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
+                                 const int32_t *pbc, int rank, int world, const double **packed_out)
+{
+    if (!h || N <= 0 || !numbers || !positions || !cell || !packed_out) return fail(SGPR_E_INVALID, "sgpr_compute_view: bad arguments");
+    double *po = nullptr;
+    const int rc_ = compute_core(h, N, numbers, positions, cell, pbc, rank, world, false, &po);
+    *packed_out = rc_ ? nullptr : po;
+    return rc_;
 }
 
 extern "C" int sgpr_get_cov(sgpr_model *h, int N_expected, int m_expected, double *cov)

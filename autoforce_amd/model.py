@@ -72,6 +72,7 @@ class SGPRModel:
         self._vscale = {}
         self.generation = 0   # counts the frames the device evaluated (predict, training rows): whoever caches
                               # something about "the last frame" (calc.cov) can tell when it moved on
+        self._pv = None       # predict_view's per-system cache
         self.comm_world = 1   # > 1 once an RCCL communicator is attached (comm_init)
         self.peer_world = 1   # > 1 once the library's own exchange is attached (peer_attach)
 
@@ -515,6 +516,40 @@ class SGPRModel:
         check(_lib.load().sgpr_compute(self._h, N, ptr(numbers), ptr(positions), ptr(cell), ptr(pbc), rank, world,
                                        C.addressof(E), ptr(F), ptr(stress), ptr(b), ptr(K)))
         return dict(energy=E.value, forces=F, stress=stress, beta=b, cov=K)
+
+    def predict_view(self, numbers, positions, cell, pbc, rank=0, world=1):
+        """predict() for callers in a loop (ActiveCalculator.calculate): the same pass, but forces / beta / stress come
+        back as numpy VIEWS of the page-locked buffer the device wrote them to (include/sgpr_hip.h: sgpr_compute_view) — valid
+        until the call after next —, and what does not change between calls (the int32 numbers, pbc, the views themselves)
+        is kept instead of being rebuilt: ~20 us less per call at 4096 atoms."""
+        N = len(numbers)
+        c = self._pv
+        if c is None or c["N"] != N or c["src"] is not numbers:
+            n32 = i32(numbers)
+            if c is not None and c["N"] == N and np.array_equal(c["n32"], n32):
+                c["src"] = numbers
+            else:
+                c = self._pv = dict(N=N, src=numbers, n32=n32, n32p=ptr(n32), views={}, out=C.c_void_p(0))
+                c["outp"] = C.addressof(c["out"])
+        if positions.dtype != np.float64 or not positions.flags.c_contiguous:
+            positions = f64(positions)
+        if cell.dtype != np.float64 or not cell.flags.c_contiguous:
+            cell = f64(cell)
+        pb = (bool(pbc[0]), bool(pbc[1]), bool(pbc[2]))
+        if c.get("pb") != pb:
+            c["pb"], c["pbc32"] = pb, i32(np.asarray(pb, np.int32))
+            c["pbcp"] = ptr(c["pbc32"])
+        self.generation += 1
+        code = _lib.load().sgpr_compute_view(self._h, N, c["n32p"], positions.ctypes.data, cell.ctypes.data, c["pbcp"], rank, world,
+                                             c["outp"])
+        if code:
+            check(code)
+        addr = c["out"].value
+        v = c["views"].get(addr)
+        if v is None:
+            buf = np.frombuffer((C.c_double * (4 * N + 17)).from_address(addr), dtype=np.float64)
+            v = c["views"][addr] = (buf[:3 * N].reshape(N, 3), buf[3 * N:4 * N], buf[4 * N:4 * N + 1].reshape(()), buf[4 * N + 11:4 * N + 17])
+        return dict(energy=v[2], forces=v[0], stress=v[3], beta=v[1], cov=None)
 
     # ------------------------------------------------------------------ device-resident molecular dynamics
     MD_SCALARS = 16  # per evaluation: E, virial[9], overflow word, largest covloss, sum m v^2, 3 spare

@@ -252,6 +252,14 @@ int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *pos
                  const double *cell, const int32_t *pbc, int rank, int world, double *energy,
                  double *forces, double *stress, double *beta, double *cov);
 
+/* sgpr_compute without the copies out: *packed_out points at this call's results where the device wrote them — page-locked
+ * host memory owned by the handle, [F 3N | beta N | E | virial 9 (row-major) | overflow word | stress 6 (Voigt)], caller atom
+ * order — valid until the call AFTER THE NEXT on this handle (two buffers alternate: the previous call's results stay
+ * intact while this one runs).  What ActiveCalculator.results hands out as views (the reference's results are views of
+ * tensors the calculator owns, calculator/active.py:572-574; ASE copies what it passes on). */
+int sgpr_compute_view(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
+                      const int32_t *pbc, int rank, int world, const double **packed_out);
+
 /*
  * Device-resident form for MD loops and benchmarks: no host copies, no synchronisation.
  * sgpr_bind_system fixes N, numbers, pbc and the sharding (host arrays; may be called again

@@ -26,6 +26,7 @@ def raw(x):
     lib.sgpr_compute(mdl._h, N, _lib.ptr(nz), _lib.ptr(x), _lib.ptr(cz), _lib.ptr(pz), 0, 1, C.addressof(E), _lib.ptr(F), _lib.ptr(s), _lib.ptr(b), None)
 print("bare sgpr_compute            %.1f us" % med(raw))
 print("SGPRModel.predict            %.1f us" % med(lambda x: mdl.predict(numbers, x, cell, pbc)))
+print("SGPRModel.predict_view       %.1f us" % med(lambda x: mdl.predict_view(numbers, x, cell, pbc)))
 calc = ActiveCalculator(covariance=mdl, logfile=None)
 atoms = Atoms(numbers, pos.copy(), cell, pbc); atoms.calc = calc
 def viacalc(x):
