@@ -164,6 +164,13 @@ struct MdState {
     double nh_c1 = 0.0, nh_c2 = 0.0, nh_K0 = 0.0;   // dt tfact, 2 dt tfact, desired kinetic energy
     DevBuf<double> zeta;           // [4] zeta by evaluation index & 3 | [4] its time integral
     bool evaluated = false;        // the current configuration has been evaluated by the last sgpr_md_run (halted / final)
+    // a run that is cut into several sgpr_md_run calls goes on where the last call stopped — candidate lists, the bins its last
+    // kernel filled for the next configuration — when nothing else has touched the handle in between
+    bool chain_ok = false;
+    unsigned chain_step = 0, chain_bind = 0, chain_opt = 0;
+    long long chain_t = 0;
+    const double *chain_pos = nullptr;
+    double *scal_pin = nullptr;    // [rows][SGPR_MD_SCAL] page-locked: the scalars of a call travel behind its last kernel, one wait
     unsigned long long seed = 0;   // != 0: the integrator draws its own deviates (sgpr_md_seed)
     DevBuf<double> X, V, P, KE, mass, sig, noise, noise_raw, cell;
     DevBuf<int> halt;
@@ -234,6 +241,7 @@ struct sgpr_model {
     double skin = 0.5;          // Angstrom; 0: rebuild every step (option "skin_milliangstrom")
     bool lists_valid = false;   // false: the next step is told to rebuild (new frame, capacity change)
     unsigned step_count = 0;
+    unsigned bind_gen = 0, opt_gen = 0;   // sgpr_bind_system calls / option changes that void kept lists (MdState::chain_*)
     DevBuf<int> d_flag, d_ncand, d_cand_j, d_cand_code, d_cidx;
     DevBuf<double> d_pos0, d_cell0;
     DevBuf<unsigned long long> d_hm;
@@ -1379,6 +1387,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->md.halt_host) (void)hipHostFree(h->md.halt_host);
     if (h->md.mark) (void)hipHostFree(h->md.mark);
+    if (h->md.scal_pin) (void)hipHostFree(h->md.scal_pin);
     {   // (a DevBuf has no destructor — handles are copied around as plain structs —: every buffer is released by name)
         MdState &m = h->md;
         DevBuf<double> *mdb[] = {&m.X, &m.V, &m.P, &m.KE, &m.mass, &m.sig, &m.noise, &m.noise_raw, &m.cell, &m.scal_d};
@@ -2048,6 +2057,7 @@ extern "C" int sgpr_bind_system(sgpr_model *h, int N, const int32_t *numbers, co
     h->t_stride = 0;
     h->gather_ok = !h->force_scatter;
     h->warm = false;
+    h->bind_gen++;
     return alloc_work(h);
 }
 
@@ -2867,10 +2877,12 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
     // scalar ring in mapped host memory
     if (m.scal_rows < (size_t)nevals + 1) {
         if (m.mark) (void)hipHostFree(m.mark);
-        m.mark = nullptr; m.scal_rows = 0;
+        if (m.scal_pin) (void)hipHostFree(m.scal_pin);
+        m.mark = nullptr; m.scal_pin = nullptr; m.scal_rows = 0;
         if (m.scal_d.alloc((size_t)SGPR_MD_SCAL * ((size_t)nevals + 1), false) ||
             hipHostMalloc((void **)&m.mark, sizeof(int) * ((size_t)nevals + 1), hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer((void **)&m.mark_dev, m.mark, 0) != hipSuccess)
+            hipHostGetDevicePointer((void **)&m.mark_dev, m.mark, 0) != hipSuccess ||
+            hipHostMalloc((void **)&m.scal_pin, sizeof(double) * SGPR_MD_SCAL * ((size_t)nevals + 1), hipHostMallocDefault) != hipSuccess)
             return fail(SGPR_E_NODEVICE, "sgpr_md_run: no memory for the scalar ring");
         m.scal_rows = (size_t)nevals + 1;
     }
@@ -2897,10 +2909,21 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         if (rc_) return rc_;
         h->warm = true;
     }
-    h->lists_valid = false;  // (whatever ran on this handle in between — a model update evaluates other frames)
-    h->pre_valid = false;
-    // (a run that halted has left the bin populations of a step that never ran)
-    HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
+    // the continuation of the last call (nothing else ran on the handle since, no re-binding, no option touched): its candidate
+    // lists stand and its last kernel has binned this call's first configuration.  Otherwise: whatever ran in between — a model
+    // update evaluates other frames — may have left other lists and bin populations (a run that halted: those of a step that
+    // never ran)
+    const bool chain = m.chain_ok && h->warm && h->step_count == m.chain_step && h->bind_gen == m.chain_bind && h->opt_gen == m.chain_opt &&
+                       m.t == m.chain_t && m.chain_pos == m.X.p + (size_t)3 * N * s0;
+    m.chain_ok = false;
+    if (chain) {
+        h->lists_valid = true;
+        h->pre_valid = true; h->pre_pos = m.chain_pos; h->pre_cell = m.cell.p; h->pre_step = h->step_count;
+    } else {
+        h->lists_valid = false;
+        h->pre_valid = false;
+        HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
+    }
     const unsigned step0 = h->step_count;
     const unsigned epoch0 = h->peer.epoch;
     const bool pend0 = m.t > 0;   // (the closing half kick of the first configuration: due unless it is the start of the trajectory)
@@ -2977,14 +3000,21 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         f.nx.scal_prev = m.scal_d.p + (size_t)SGPR_MD_SCAL * (enq - 1);
         hipLaunchKernelGGL(finalize_tail_kernel, dim3(2), dim3(256), 0, st, f);
     }
-    // (the last kernel enqueued has binned a step that will not run — or, after a halt, the bins are those of a discarded
-    // speculative step: whoever uses the handle next starts from clean bin populations)
-    HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
+    // the scalars travel behind the last kernel: ONE wait for the whole call (the halt words are in mapped host memory)
+    if (scalars && enq > 0)
+        HIPCHK(hipMemcpyAsync(m.scal_pin, m.scal_d.p, sizeof(double) * SGPR_MD_SCAL * (size_t)enq, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     if (const int pc = peer_check(h)) return pc;
-    int hv[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(hv, m.halt.p, sizeof(hv), hipMemcpyDeviceToHost));
+    // (covloss halts and capacity overflows each leave the evaluation in their own mapped word; the earlier one halted the run)
+    int hv[4] = {std::min(m.halt_host[0], m.halt_host[1]), 0, 0, 0};
+    // Where the run goes on: when every evaluation stands and the last one was integrated, the handle is left as the last kernel
+    // left it — the next sgpr_md_run continues from there (chain, above).  Otherwise the last kernel enqueued has binned a step
+    // that will not run — or, after a halt, the bins are those of a discarded speculative step: whoever uses the handle next
+    // starts from clean bin populations.
+    const bool keep_chain = hv[0] == halt_none && !final_eval && enq == nevals && h->pre_valid;
+    const double *keep_pos = h->pre_pos;
+    if (!keep_chain) HIPCHK(hipMemsetAsync(h->d_bin_count.p, 0, 2 * SGPR_BIN_INTS * sizeof(int), st));
     int done = enq, code = 0;
     if (hv[0] != halt_none) {
         const int k = hv[0] - (int)step0;   // evaluation (relative to this call) that halted the run
@@ -3003,8 +3033,12 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         m.t += adv;
     }
     if (code == 2) done -= 1;  // (the overflowing evaluation's own results are void)
+    if (keep_chain) {
+        m.chain_ok = true; m.chain_step = h->step_count; m.chain_bind = h->bind_gen; m.chain_opt = h->opt_gen; m.chain_t = m.t;
+        m.chain_pos = keep_pos;
+    }
     if (scalars && done > 0) {
-        HIPCHK(hipMemcpy(scalars, m.scal_d.p, sizeof(double) * SGPR_MD_SCAL * (size_t)done, hipMemcpyDeviceToHost));
+        memcpy(scalars, m.scal_pin, sizeof(double) * SGPR_MD_SCAL * (size_t)done);
         if (!m.nh)   // (Nose-Hoover: zeta and its time integral of the evaluation's configuration; else spare)
             for (int r = 0; r < done; r++) scalars[(size_t)SGPR_MD_SCAL * r + 14] = scalars[(size_t)SGPR_MD_SCAL * r + 15] = 0.0;
     }
@@ -3155,6 +3189,7 @@ extern "C" int sgpr_sync_check(sgpr_model *h, void *stream)
 extern "C" int sgpr_set_option(sgpr_model *h, const char *name, int value)
 {
     if (!h || !name) return fail(SGPR_E_INVALID, "sgpr_set_option: bad arguments");
+    h->opt_gen++;
     if (!strcmp(name, "graph")) {
         // the effective list cutoff switches between rc (graph: rebuild every step) and rc + skin: candidates and
         // the cached bin grid of the other mode must not be reused
