@@ -915,21 +915,120 @@ int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_m
     return 0;
 }
 
+// ---- ONE column through kept reflectors.  tsqr_apply_kernel is built for tiles of 32 trailing columns (137 KB of LDS, three
+// MFMA products, five barriers): for the single column a kept factorisation is asked about — an appended inducing LCE, new
+// targets — that machinery was 23 us per launch and 128 launches per column (32 panels x 4 levels at 49k rows: 3 ms for
+// 0.4 GB of reflectors).  Here a chunk is a 256-thread workgroup doing what one column needs: w = V^T a with the 32 dot
+// products dealt to the four waves (coalesced rows, eight independent wave reductions each), z = T^T w by 32 threads,
+// a -= V z; and the small upper levels of a panel's tree (four chunks or fewer) run one after the other in ONE workgroup.
+struct VecLevel { const double *V, *T; int n, chunks, stride; };
+struct TsqrVec {
+    double *a;            // the column over the physical rows
+    int row0, row_end;
+    int nlev;             // levels this launch works through (> 1: one workgroup, level after level)
+    VecLevel lv[4];
+};
+
+__device__ __forceinline__ void apply_vec_chunk(double *a, int row0, int row_end, const VecLevel &L, int chunk, double *ws /*[32]*/, double *zs /*[32]*/)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const double *V = L.V + (size_t)chunk * TNB * TCH, *T = L.T + (size_t)chunk * TNB * TNB;
+    // this thread's row of the chunk for the update; the wave's rows lane, lane + 64, ... for the products
+    double av[4];
+    int ph[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int rho = chunk * TCH + lane + 64 * j;
+        const int phys = row0 + (rho >> 5) * L.stride + (rho & 31);
+        const bool live = rho < L.n && phys < row_end;
+        ph[j] = live ? phys : -1;
+        av[j] = live ? a[phys] : 0.0;
+    }
+    double w[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const double *vi = V + (size_t)(8 * wave + u) * TCH + lane;
+        w[u] = (vi[0] * av[0] + vi[64] * av[1]) + (vi[128] * av[2] + vi[192] * av[3]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) w[u] = wave_sum64(w[u]);
+    if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) ws[8 * wave + u] = w[u];
+    }
+    __syncthreads();
+    if (tid < TNB) {   // z_i = sum_l T[l][i] w_l
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int l = 0; l < TNB; l++) s4[l & 3] += T[l * TNB + tid] * ws[l];
+        zs[tid] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    __syncthreads();
+    {   // a_r -= sum_i V[r][i] z_i: thread = row (wave-major, so that the four rows of the products' layout are covered)
+        const int rho = chunk * TCH + tid;
+        const int phys = row0 + (rho >> 5) * L.stride + (rho & 31);
+        if (rho < L.n && phys < row_end) {
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < TNB; i++) s4[i & 3] += V[(size_t)i * TCH + tid] * zs[i];
+            a[phys] -= (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+    }
+    (void)ph;
+}
+
+__global__ __launch_bounds__(TCH) void tsqr_apply_vec_kernel(TsqrVec q)
+{
+    __shared__ double ws[TNB], zs[TNB];
+    if (q.nlev == 1) {
+        apply_vec_chunk(q.a, q.row0, q.row_end, q.lv[0], blockIdx.x, ws, zs);
+        return;
+    }
+    for (int l = 0; l < q.nlev; l++)
+        for (int c = 0; c < q.lv[l].chunks; c++) {
+            apply_vec_chunk(q.a, q.row0, q.row_end, q.lv[l], c, ws, zs);
+            __threadfence();      // (the next chunk / level reads rows this one wrote, through other threads)
+            __syncthreads();
+        }
+}
+
 // vec <- Q_p^T vec for the kept panels p = first .. first + count - 1, in order (vec: one column over the physical rows)
 void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st)
 {
-    tsqr_attrs();
+    static const bool tiles = getenv("SGPR_APPLY_VEC") && atoi(getenv("SGPR_APPLY_VEC")) == 0;   // SGPR_APPLY_VEC=0: the tile kernel
+    if (tiles) tsqr_attrs();
     for (int p = 0; p < count; p++) {
         const TsqrPanel &pn = panels[p];
-        for (int l = 0; l < pn.nlev; l++) {
-            TsqrApply ap = {};
-            ap.A = vec;
-            ap.ldr = 0; ap.ntrail = 1;
-            ap.row0 = pn.k0; ap.row_end = pn.row_end;
-            ap.n = pn.lv[l].n; ap.stride = pn.lv[l].stride;
-            ap.V = pn.lv[l].V; ap.T = pn.lv[l].T;
-            ap.tpw = 1;
-            hipLaunchKernelGGL(tsqr_apply_kernel, dim3(1, pn.lv[l].chunks), dim3(TCH), lds_apply_bytes(), st, ap);
+        if (tiles) {
+            for (int l = 0; l < pn.nlev; l++) {
+                TsqrApply ap = {};
+                ap.A = vec;
+                ap.ldr = 0; ap.ntrail = 1;
+                ap.row0 = pn.k0; ap.row_end = pn.row_end;
+                ap.n = pn.lv[l].n; ap.stride = pn.lv[l].stride;
+                ap.V = pn.lv[l].V; ap.T = pn.lv[l].T;
+                ap.tpw = 1;
+                hipLaunchKernelGGL(tsqr_apply_kernel, dim3(1, pn.lv[l].chunks), dim3(TCH), lds_apply_bytes(), st, ap);
+            }
+            continue;
+        }
+        int l = 0;
+        while (l < pn.nlev) {
+            TsqrVec q = {};
+            q.a = vec; q.row0 = pn.k0; q.row_end = pn.row_end;
+            // the levels from here on in one workgroup when they are small (<= 4 chunks in all, <= 4 levels)
+            int tail_chunks = 0;
+            for (int k = l; k < pn.nlev; k++) tail_chunks += pn.lv[k].chunks;
+            if (tail_chunks <= 4 && pn.nlev - l <= 4 && pn.nlev - l > 1) {
+                q.nlev = pn.nlev - l;
+                for (int k = 0; k < q.nlev; k++) q.lv[k] = {pn.lv[l + k].V, pn.lv[l + k].T, pn.lv[l + k].n, pn.lv[l + k].chunks, pn.lv[l + k].stride};
+                hipLaunchKernelGGL(tsqr_apply_vec_kernel, dim3(1), dim3(TCH), 0, st, q);
+                break;
+            }
+            q.nlev = 1;
+            q.lv[0] = {pn.lv[l].V, pn.lv[l].T, pn.lv[l].n, pn.lv[l].chunks, pn.lv[l].stride};
+            hipLaunchKernelGGL(tsqr_apply_vec_kernel, dim3(pn.lv[l].chunks), dim3(TCH), 0, st, q);
+            l++;
         }
     }
 }
