@@ -341,6 +341,19 @@ struct sgpr_model {
         uint64_t age = 0;
     };
     QrKeep qr_keep[4];
+    // the banded second stage of the last resident-matrix solve, kept with its reflectors (solve.inc::solve_stage2): an
+    // inducing trial's refit is that factorisation asked about one more column
+    struct S2Keep {
+        bool valid = false;
+        int m = 0, with_energies = -1;
+        double noise0 = 0.0, sigma = 0.0, ridge = 0.0;
+        std::vector<int64_t> col_ids, frame_ids;
+        DevBuf<double> VT, R1;   // the panels' reflectors; the first-stage factor it was made for (m x m, column-major)
+    };
+    S2Keep s2k;
+    const char *info_stage2 = "none";
+    DevBuf<double> sc_s2W;
+    DevBuf<int> sc_s2flag;
     int qr_keep_mode = 1;  // option "qr_keep" (environment SGPR_QR_KEEP at creation): 1 on, 0 off, 2 verify
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
@@ -1415,6 +1428,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
         h->sc_ise.release();
     }
     for (auto &e : h->r1_cache) e.r1.release();
+    h->s2k.VT.release(); h->s2k.R1.release(); h->sc_s2W.release(); h->sc_s2flag.release();
     for (auto &k : h->qr_keep) { k.clear_ops(); k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
     h->t_covl.release();

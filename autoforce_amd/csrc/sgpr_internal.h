@@ -256,6 +256,12 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x /
 int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_mat, double *x, double *work, int batch,
                             hipStream_t st, int band);
 void tsqr_apply_panels(const TsqrPanel *panels, int count, double *vec, hipStream_t st);
+// the banded 2m x m second stage on flat register panels (bandqr.inc) with its reflectors KEPT, and the same factorisation
+// asked about new targets / one appended column (an inducing trial's refit: O(m^2))
+size_t band_qr_keep_doubles(int cols);
+int launch_band2_keep(int rows, int cols, double *At, int ldr, double *x, double *work, double *keepVT, hipStream_t st);
+int launch_band2_append(int m_old, int nnew, double *W, int ldw, const double *keepVT, const double *At_kept, int ldr_kept, double *x,
+                        double *tmp, hipStream_t st);
 // one-column Householder reflectors over n elements (appended columns of a kept factorisation)
 size_t flat_part_doubles(int n);
 void flat_reflector_make(const double *x, int n, double *v, double *sc, double *alpha, double *part, hipStream_t st);

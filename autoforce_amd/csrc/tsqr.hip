@@ -839,13 +839,13 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
     }
 }
 
-#include "bandqr.inc"
 int g_bandqr_force = -1;   // tools/bandqr_test.hip: 0 / 1 overrides the environment
 static bool band_qr_on()
 {
     static const bool on = !(getenv("SGPR_BANDQR") && atoi(getenv("SGPR_BANDQR")) == 0);   // SGPR_BANDQR=0: the tree form everywhere
     return g_bandqr_force >= 0 ? g_bandqr_force != 0 : on;
 }
+#include "bandqr.inc"
 
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band,
                             double *keep, std::vector<TsqrPanel> *panels, int extra, int band_off)

@@ -202,7 +202,8 @@ int sgpr_data_factor(sgpr_model *h, const double *Y, int with_energies);
 /* Diagnostics of the last sgpr_data_solve / sgpr_data_factor: which route the first stage took ("full factorisation",
  * "columns appended / popped through the kept reflectors", "kept", "rows of the new frame appended to the kept
  * factor", "found in the cache", "from scratch") and how many species blocks of K_mm were factored, as text
- * ("stage1=...; kmm_blocks=a/b; rows=...").  The reference always refits from scratch (gppotential.py:548-605); tests use
+ * ("stage1=...; stage2=...; kmm_blocks=a/b; rows=...": stage2 = "factorisation" or, for the model a kept second stage was
+ * made for asked again / with one appended column, "kept reflectors, ...").  The reference always refits from scratch (gppotential.py:548-605); tests use
  * this to assert that an edit (append, pop, select / downsize) was followed incrementally.  "rows=" names the kernel
  * form of the last rows / columns call: "sixteen columns per workgroup pass" (lmax and nmax <= 3, <= 4 species, lists of
  * <= 64 neighbours) or "one column per wave". */

@@ -101,6 +101,40 @@ int main(int argc, char **argv)
             }
             printf("\n");
         }
+        {   // the kept factorisation of the first m - 1 columns asked about the m-th: against the full solve
+            const int mo = m - 1;
+            if (mo >= 1) {
+                const int Ro = 2 * mo, ldro = (Ro + 63) / 64 * 64, cpo = (mo + 1 + 63) / 64 * 64 + 64, ldw = (2 * m + 2 + 63) / 64 * 64;
+                std::vector<double> Ao((size_t)cpo * ldro, 0.0), W((size_t)2 * ldw + mo + 64, 0.0);
+                for (int c = 0; c < mo; c++)
+                    for (int r = 0; r < Ro; r++) Ao[(size_t)c * ldro + r] = A[(size_t)c * ldr + r];
+                for (int r = 0; r < Ro; r++) Ao[(size_t)mo * ldro + r] = A[(size_t)m * ldr + r];   // (targets of the old model: unused)
+                for (int r = 0; r < 2 * m; r++) { W[r] = A[(size_t)mo * ldr + r]; W[ldw + r] = A[(size_t)m * ldr + r]; }
+                double *dAo, *dW, *dk, *dxo;
+                hipMalloc((void **)&dAo, sizeof(double) * Ao.size());
+                hipMalloc((void **)&dW, sizeof(double) * W.size());
+                hipMalloc((void **)&dk, sizeof(double) * band_qr_keep_doubles(mo));
+                hipMalloc((void **)&dxo, sizeof(double) * (m + 1));
+                hipMemcpy(dAo, Ao.data(), sizeof(double) * Ao.size(), hipMemcpyHostToDevice);
+                hipMemcpy(dW, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice);
+                g_bandqr_force = 1;
+                const int rk = launch_band2_keep(Ro, mo, dAo, ldro, dxo, dw, dk, st);
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0, st);
+                if (rk == 0) launch_band2_append(mo, 1, dW, ldw, dk, dAo, ldro, dxo, dW + (size_t)2 * ldw, st);
+                hipEventRecord(e1, st);
+                hipStreamSynchronize(st);
+                float ms_ = 0;
+                hipEventElapsedTime(&ms_, e0, e1);
+                std::vector<double> xa(m);
+                hipMemcpy(xa.data(), dxo, sizeof(double) * m, hipMemcpyDeviceToHost);
+                double da = 0;
+                for (int i = 0; i < m; i++) da = std::max(da, fabs(xa[i] - xs[1][i]));
+                printf("        kept m-1 columns + 1 appended (rc %d): %.3f ms, max |dx| vs the full solve %.2e\n", rk, ms_, da);
+                hipFree(dAo); hipFree(dW); hipFree(dk); hipFree(dxo);
+            }
+        }
         double dxm = 0, nxm = 0;
         for (int i = 0; i < m; i++) { dxm = std::max(dxm, fabs(xs[0][i] - xs[1][i])); nxm = std::max(nxm, fabs(xs[0][i])); }
         printf("        flat vs tree: max |dx| %.2e of %.2e\n", dxm, nxm);
