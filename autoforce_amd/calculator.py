@@ -251,6 +251,11 @@ class ActiveCalculator(Calculator):
                 ok, why = 0, str(exc)
         else:
             ok = 0
+        # every rank tries the exchange once before anybody relies on it (collective: all ranks that attached take part)
+        att = torch.tensor([ok])
+        dist.all_reduce(att, op=dist.ReduceOp.MIN, group=self.process_group)
+        if int(att.item()) == 1 and not eng.peer_selftest(rank, world):
+            ok, why = 0, "the self-test exchange did not return the expected sum"
         flag = torch.tensor([ok])
         if dist.get_backend(self.process_group) == "nccl":
             flag = flag.cuda()

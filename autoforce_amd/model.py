@@ -144,6 +144,20 @@ class SGPRModel:
         check(_lib.load().sgpr_peer_attach(self._h, C.addressof(buf)))
         self.peer_world = self.comm_world = len(handles)   # (comm_world: "the library combines the ranks itself")
 
+    def peer_selftest(self, rank, world):
+        """One small exchange with a known answer (every rank contributes rank + 1 in eight doubles): True when the sum came
+        back on this rank.  The hosts call it right after peer_attach and agree on the outcome before they rely on the
+        exchange (a rank whose stores are not seen by a peer would otherwise surface as a time-out in the first step)."""
+        import torch
+        buf = torch.full((8,), float(rank + 1), dtype=torch.float64, device=f"cuda:{self.device}")
+        lib = _lib.load()
+        try:
+            check(lib.sgpr_comm_allreduce(self._h, buf.data_ptr(), 8, 0, None))
+            check(lib.sgpr_sync_check(self._h, None))
+        except _lib.SgprError:
+            return False
+        return bool((buf.cpu().numpy() == world * (world + 1) / 2).all())
+
     def peer_destroy(self):
         check(_lib.load().sgpr_peer_destroy(self._h))
         self.peer_world = self.comm_world = 1

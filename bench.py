@@ -324,6 +324,15 @@ def main():
             ok = 0
         t = torch.tensor([ok])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            # one small exchange with a known answer on every rank before the bench relies on it (a peer whose stores are
+            # not seen is a time-out here, once, not a lost measurement)
+            with Watchdog("self-test of the exchange between the ranks", seconds=120, rank=rank):
+                if not mdl.peer_selftest(rank, world):
+                    print(f"[bench] rank {rank}: the exchange's self-test failed", file=sys.stderr, flush=True)
+                    ok = 0
+            t = torch.tensor([ok])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if int(t.item()) == 0:
             if blob is not None:
                 mdl.peer_destroy()
