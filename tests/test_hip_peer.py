@@ -21,6 +21,41 @@ pytestmark = pytest.mark.gpu
 STEPS = 40
 
 
+def _otf_worker(rank, world, port, tmp, q, tdamp):
+    """On-the-fly learning with the MD state on the devices of `world` ranks (ActiveCalculator.run_md over the exchange)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import pathlib
+    import torch.distributed as dist
+    import active_common as ac
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.watchdog import Watchdog
+    from helpers import PairTeacher
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SGPR_PEER_TIMEOUT_MS"] = "20000"
+    with Watchdog(f"sharded on-the-fly MD, rank {rank} of {world}", seconds=240, rank=rank):
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        np.random.seed(1234)
+        rng0, numbers, pos, cell = ac.start(0)
+        d = pathlib.Path(tmp) / f"w{world}r{rank}"
+        d.mkdir()
+        calc = ActiveCalculator(engine=SGPRModel(3, 3, 4, 4.5, species=ac.SPECIES), calculator=PairTeacher(rc=4.0),
+                                logfile=str(d / "active.log"), pckl=None, tape=None,
+                                process_group=dist.group.WORLD if world > 1 else None, **ac.KW)
+        at = Atoms(numbers, pos, cell, True, velocities=0.02 * np.random.default_rng(3).normal(size=pos.shape))
+        out = [(s, E, bool(u)) for s, E, T, u, w in calc.run_md(at, 40, 300.0, dt_fs=1.0, friction=0.02, seed=7, chunk=16, tdamp_fs=tdamp)]
+        on_device = calc.md_on_device_ok()
+        q.put((rank, out, at.positions.copy(), at.get_velocities(), calc.size, on_device, int(getattr(calc.engine, "peer_world", 1))))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
 def _build(side=8, m=48, scale=0.02, seed=1, scatter=False):
     from autoforce_amd import SGPRModel, _lib
     from autoforce_amd.workloads import inducing_from_frame, lips
@@ -47,15 +82,16 @@ def _md(mdl, system, steps, batches, ediff=0.0):
     vel = rng.normal(size=pos.shape) * np.sqrt(kB * 600.0 / masses)[:, None]
     mdl.md_begin(numbers, pos, cell, pbc, masses, vel, dt=1.0 * FS, friction=0.02, kT=kB * 600.0, seed=11)
     rows, code, left = [], 0, steps
-    for n in batches:
-        n = min(n, left)
-        if n <= 0:
-            break
-        sc, code = mdl.md_run(n, None, ediff=ediff, final=False)
+    sizes = iter(list(batches) + [100] * 8)
+    n = next(sizes)
+    while left > 0:
+        sc, code = mdl.md_run(min(n, left), None, ediff=ediff, final=False)
         rows.append(sc)
         left -= len(sc)
-        if code:
+        if code == 1:      # the covloss gate
             break
+        if code == 0:      # (2: a neighbour capacity was outgrown on some rank — the next call re-sizes and repeats the evaluation)
+            n = next(sizes)
     st = mdl.md_state(results=False)
     return st["positions"], st["velocities_pre"], np.concatenate(rows), code
 
@@ -125,7 +161,7 @@ def single():
     return dict(ref=ref, ref2=ref2, x=x, v=v, sc=sc, ediff=ediff, xh=xh, vh=vh, sch=sch, gat=gat, xg=xg, vg=vg)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_exchange_and_sharded_md_equal_the_single_process_bit_for_bit(world, single):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -203,3 +239,35 @@ def test_bench_two_ranks_over_the_exchange_on_one_gpu():
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert len(d["per_rank"]) == 2 and all(r["local_atoms"] == 2048 for r in d["per_rank"])
     assert d["allreduce_us"] is not None and d["allreduce_us"] > 0
+
+
+@pytest.mark.parametrize("tdamp", [None, 20.0])
+def test_on_the_fly_learning_with_the_md_state_on_two_ranks(tmp_path, tdamp):
+    """BASELINE configs[4] in small: on-the-fly inducing-set updates inside NVT MD with the atoms SHARDED — the MD state on the
+    devices of two ranks (both on the one GPU of the test box), the covloss gate halting both at the same step, the model
+    update on the host path of every rank, Langevin and Nose-Hoover — against the single process: the same updates at the
+    same steps, energies and the final state to rounding (the single process sums its forces in the gather form)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 29850 + ((os.getpid() + 17 * world + (0 if tdamp is None else 5)) % 90)
+        procs = [ctx.Process(target=_otf_worker, args=(r, world, port, str(tmp_path), q, tdamp)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    ref = res[1][0]
+    assert ref[4][1] > 2 and sum(1 for o in ref[1] if o[2]) >= 2         # the model grew, several updates
+    for rank, out, x, v, size, on_device, peer_world in res[2]:
+        assert on_device and peer_world == 2                              # the device loop ran sharded over the exchange
+        assert size == ref[4]
+        assert [o[0] for o in out] == [o[0] for o in ref[1]] and [o[2] for o in out] == [o[2] for o in ref[1]]
+        np.testing.assert_allclose([o[1] for o in out], [o[1] for o in ref[1]], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(x, ref[2], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(v, ref[3], rtol=0, atol=1e-7)
+    np.testing.assert_array_equal(res[2][0][2], res[2][1][2])            # both ranks end in the same bits
+    np.testing.assert_array_equal(res[2][0][3], res[2][1][3])
