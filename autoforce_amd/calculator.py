@@ -270,6 +270,13 @@ class ActiveCalculator(Calculator):
         self._peer_atoms = int(atoms_cap)
         return True
 
+    def _peer_fit(self, engine, N):
+        """A frame larger than the buffers of the library's own exchange hold: export and attach again (collective: every
+        rank sees the same N and takes the same branch)."""
+        world = self._dist()[1]
+        if world > 1 and getattr(engine, "peer_world", 1) == world and N > self._peer_atoms and engine is self.engine:
+            self._attach_peer(2 * N)
+
     @property
     def maximum_force(self):
         """max |F| of the frame in `results` (active.py:573-576; what the Switch thresholds depend on), computed when
@@ -343,8 +350,7 @@ class ActiveCalculator(Calculator):
         if not (engine.m > 0 and engine.mu is not None):
             # an empty model predicts its mean (zeros) and knows nothing: covloss = inf
             return dict(energy=0.0, forces=np.zeros((N, 3)), stress=np.zeros(6), beta=np.full(N, inf), ready=False)
-        if world > 1 and getattr(engine, "peer_world", 1) == world and N > self._peer_atoms and engine is self.engine:
-            self._attach_peer(2 * N)   # (a larger frame than the exchange buffers hold: every rank sees the same N)
+        self._peer_fit(engine, N)
         fast = getattr(engine, "predict_view", None)
         if fast is not None and (world == 1 or getattr(engine, "comm_world", 1) == world):
             # results as views of the buffer the device wrote (valid until the call after next): copied where they are kept
@@ -552,6 +558,7 @@ class ActiveCalculator(Calculator):
                 return
         eng = self.engine
         kT = kB * temperature_K
+        self._peer_fit(eng, N)
         eng.md_begin(numbers, pos, cell, pbc, masses, vel, dt=dt_fs * FS, friction=0.0 if nh else friction, kT=kT,
                      seed=(int(seed) or 1) if on_device_rng else 0, ttime=tdamp_fs * FS if nh else None)
         # (skip_gate: the configuration has been through calculate() — logged, counted, the model updated if need be —

@@ -6,6 +6,9 @@ max_inducing = 1024, Langevin 600 K, 1 fs.  Every update step past the limit end
 K_mm factor per species block, kept first-stage QR through the reflectors of R1[:, idx].
 
     python examples/md_nvt_config5.py --steps 250            # prints one line per step and a summary
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 examples/md_nvt_config5.py
+                                                             # the config as worded: atoms sharded over 8 ranks, the MD state
+                                                             # on every device (the library's own exchange)
 
 `run()` is also what tests/test_hip_config5.py drives.
 """
@@ -22,13 +25,14 @@ from autoforce_amd import workloads  # noqa: E402
 
 
 def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=0.1, temperature=600.0, n_exceed=8,
-        verbose=False, stop_after_downsizes=None, min_steps=0, device_md=True, host_rng=False):
+        verbose=False, stop_after_downsizes=None, min_steps=0, device_md=True, host_rng=False, process_group=None, device=0):
     """friction: per ASE time unit.  The reference CLI's default, 1e-3 (cl/md.py:31), is a 10-ps coupling: invisible
     in a few hundred fs.  The default here (0.1: 0.1 ps) lets a short run show whether the thermostat HOLDS the
     temperature while the model is edited under it."""
     t_setup = time.time()
-    calc, teacher, (numbers, pos, cell, pbc), vel = workloads.config5_preseeded(shape, m_seed, max_inducing, n_exceed,
-                                                                                temperature=temperature, friction=friction)
+    extra = {} if process_group is None else dict(process_group=process_group)
+    calc, teacher, (numbers, pos, cell, pbc), vel = workloads.config5_preseeded(shape, m_seed, max_inducing, n_exceed, device=device,
+                                                                                temperature=temperature, friction=friction, **extra)
     np.random.seed(1)
     model = calc.model
     stats = dict(downsizes=0, downsize_ms=[], routes=[], pending=False)
@@ -128,8 +132,20 @@ def main():
     ap.add_argument("--host-rng", action="store_true", help="device loop with numpy's deviates uploaded (the host loop's trajectory, bit for bit)")
     args = ap.parse_args()
     t0 = time.time()
-    res = run(args.steps, tuple(args.side), args.m_seed, args.max_inducing, args.friction, n_exceed=args.n_exceed, verbose=True,
-              device_md=not args.host_loop, host_rng=args.host_rng)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    group, device = None, 0
+    if world > 1:   # launched by torch.distributed.run: one rank per GPU (several per GPU when there are fewer GPUs than ranks)
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        group, device = dist.group.WORLD, int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    res = run(args.steps, tuple(args.side), args.m_seed, args.max_inducing, args.friction, n_exceed=args.n_exceed, verbose=rank == 0,
+              device_md=not args.host_loop, host_rng=args.host_rng, process_group=group, device=device)
+    if rank != 0:
+        verify(res)
+        dist.barrier()
+        return
     rows = res["rows"]
     upd = [1e3 * r["wall"] - r["teacher_ms"] for r in rows[1:] if r["updated"]]
     capped = [1e3 * r["wall"] - r["teacher_ms"] for r in rows[1:] if r["updated"] and r["size"][1] >= args.max_inducing]
@@ -144,6 +160,12 @@ def main():
     T = np.array([r["T"] for r in rows])
     print(f"# temperature over the last 100 steps: mean {T[-100:].mean():.1f} K, min {T[-100:].min():.1f}, max {T[-100:].max():.1f}")
     print("# against a from-scratch model:", verify(res))
+    if world > 1:
+        eng = res["calc"].engine
+        how = ("the library's own exchange" if getattr(eng, "peer_world", 1) == world else
+               "RCCL" if getattr(eng, "comm_world", 1) == world else "host-staged")
+        print(f"# {world} ranks: collective = {how}; MD state on the devices: {res['calc'].md_on_device_ok()}")
+        dist.barrier()
 
 
 if __name__ == "__main__":

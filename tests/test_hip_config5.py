@@ -66,3 +66,25 @@ def test_config5_downsizes_inside_nvt_md():
     print(f"config 5: {len(rows) - 1} steps, {stats['downsizes']} downsizes (median {np.median(stats['downsize_ms']):.1f} ms), "
           f"update steps at the limit: median {np.median(upd):.1f} ms; total {time.time() - t0:.1f} s; {chk}")
     res["teacher"].close()
+
+
+def test_config5_with_the_atoms_sharded_over_two_ranks():
+    """configs[4] is worded for atoms sharded over several GPUs: the same run launched as `torch.distributed.run` launches it,
+    two ranks (both on the one GPU of the test box), 16384 atoms / max_inducing 1024 — the ranks' partial sums combined by the
+    library's own exchange, the MD state on the devices of both ranks, model updates on the way up to the size limit; every rank
+    checks its edited model against a from-scratch one (examples/md_nvt_config5.py::verify)."""
+    import subprocess
+    import sys
+    port = 29440 + (os.getpid() % 50)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SGPR_PEER_TIMEOUT_MS="30000")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "examples", "md_nvt_config5.py"), "--steps", "60",
+                          "--m-seed", "1016"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    tail = [ln for ln in out.stdout.splitlines() if ln.startswith("#")]
+    text = "\n".join(tail)
+    assert "2 ranks: collective = the library's own exchange; MD state on the devices: True" in text, text
+    assert "kmm_equal': True" in text, text
+    import re
+    m = re.search(r"model-update steps: (\d+)", text)
+    assert m and int(m.group(1)) >= 3, text       # (the model was edited several times under the sharded device loop)
