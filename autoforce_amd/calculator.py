@@ -453,7 +453,7 @@ class ActiveCalculator(Calculator):
         else:
             covloss_max = float(np.max(self.get_covloss())) if len(self.atoms) else 0.0
             self.covlog = f"{covloss_max}"
-            if covloss_max > self.ediff and HAVE_ASE and self.rank == 0:  # pragma: no cover
+            if HAVE_ASE and self.rank == 0 and covloss_max > self.ediff:  # pragma: no cover  (ediff last: a Switch asks for max |F|)
                 import ase.io
                 tmp = self.atoms.copy()
                 tmp.calc = None
