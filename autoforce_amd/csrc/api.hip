@@ -354,6 +354,7 @@ struct sgpr_model {
     const char *info_stage2 = "none";
     DevBuf<double> sc_s2W;
     DevBuf<int> sc_s2flag;
+    DevBuf<double> sc_potrf;   // [2][64][64]: where the Cholesky panels park their diagonal blocks (linalg.hip)
     int qr_keep_mode = 1;  // option "qr_keep" (environment SGPR_QR_KEEP at creation): 1 on, 0 off, 2 verify
     // sgpr_solve state kept for sgpr_resolve: L of K_mm (+ridge) and the R factor of the last [K | Y]
     DevBuf<double> d_L, d_R1;
@@ -1428,7 +1429,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
         h->sc_ise.release();
     }
     for (auto &e : h->r1_cache) e.r1.release();
-    h->s2k.VT.release(); h->s2k.R1.release(); h->sc_s2W.release(); h->sc_s2flag.release();
+    h->s2k.VT.release(); h->s2k.R1.release(); h->sc_s2W.release(); h->sc_s2flag.release(); h->sc_potrf.release();
     for (auto &k : h->qr_keep) { k.clear_ops(); k.erows.release(); k.store.release(); k.Rc.release(); k.yt.release(); k.yraw.release(); k.ysnap.release(); k.vec.release(); }
     h->d_pack.release();
     h->t_covl.release();
@@ -3038,7 +3039,11 @@ extern "C" int sgpr_md_run(sgpr_model *h, int nevals, const double *noise, doubl
         // exchanges that took place: the ranks have enqueued different numbers of evaluations behind the halt, all of them
         // skipped on the device (peer_push_kernel): a covloss halt at evaluation k is seen by evaluation k + 1 (or by the
         // tail kernel when k is the last), an overflow by evaluation k itself — the same count on every rank
-        if (peer_on(h)) h->peer.epoch = epoch0 + (unsigned)(code == 2 ? k + 1 : std::min(nevals, k + 2));
+        if (peer_on(h)) {
+            h->peer.epoch = epoch0 + (unsigned)(code == 2 ? k + 1 : std::min(nevals, k + 2));
+            if (getenv("SGPR_PEER_TRACE"))
+                fprintf(stderr, "[sgpr peer] rank %d md_run halt: code %d k %d enq %d nevals %d -> epoch %u\n", h->peer.rank, code, k, enq, nevals, h->peer.epoch);
+        }
         m.t += k;                           // the state is configuration k, not evaluated (as far as the NEXT call goes)
         if (code == 2) { h->warm = false; }  // a capacity overflowed: the next call's checked pass grows it
     } else {

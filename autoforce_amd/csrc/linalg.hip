@@ -28,13 +28,25 @@ void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, 
 
 // One panel step at column k0.  Workgroup 0 factorises and stores the diagonal block;
 // workgroup b >= 1 computes rows [k0+nb+(b-1)*64, +64) of L21 = A21 L11^-T.
-__global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int ld, int k0, int *info)
+// EVERY workgroup factorises the diagonal block for itself from A.  Workgroup 0 therefore must not store L11 over A11
+// while another workgroup of the launch may still have to read A11: a workgroup that starts late — another process on
+// the same device, more workgroups than fit — would factorise the FACTOR.  (Round 5: two ranks sharing one GPU produced a
+// wrong L in one run of ten.)  With more than one workgroup L11 goes to `dsave` [2][64][64] (by panel parity) and is
+// copied into A by workgroup 0 of the NEXT launch, which nobody reads it before; the last panel has one workgroup.
+__global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int ld, int k0, int *info, double *dsave)
 {
     __shared__ double D[NB][NB + 1];
     __shared__ double P[NB][NB + 1];
     __shared__ int failed;
     const int tid = threadIdx.x;
     const int nb = min(NB, m - k0);
+    if (blockIdx.x == 0 && k0 > 0) {   // the previous panel's diagonal block, parked in dsave, goes home (also after a failure)
+        const double *src = dsave + (size_t)(((k0 / NB) - 1) & 1) * NB * NB;
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int i = e / NB, j = e % NB;
+            A[(size_t)(k0 - NB + i) * ld + k0 - NB + j] = src[e];
+        }
+    }
     if (*info != 0) return;
     if (tid == 0) failed = 0;
     for (int e = tid; e < NB * NB; e += 256) {
@@ -66,9 +78,17 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int 
         return;
     }
     if (blockIdx.x == 0) {
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int i = e / nb, j = e % nb;
-            A[(size_t)(k0 + i) * ld + k0 + j] = j <= i ? D[i][j] : 0.0;
+        if (gridDim.x == 1) {   // nobody else reads A11
+            for (int e = tid; e < nb * nb; e += 256) {
+                const int i = e / nb, j = e % nb;
+                A[(size_t)(k0 + i) * ld + k0 + j] = j <= i ? D[i][j] : 0.0;
+            }
+        } else {                // (a full 64 x 64 block: panels with workgroups below them are never the ragged last one)
+            double *dst = dsave + (size_t)((k0 / NB) & 1) * NB * NB;
+            for (int e = tid; e < NB * NB; e += 256) {
+                const int i = e / NB, j = e % NB;
+                dst[e] = (i < nb && j <= i) ? D[i][j] : 0.0;
+            }
         }
         // zero the strictly-upper part right of the diagonal block (rows k0..k0+nb)
         for (int i = 0; i < nb; i++)
@@ -97,14 +117,14 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int 
     }
 }
 
-int launch_cholesky_lower(int m, double *A, int ld, int *info, hipStream_t st)
+int launch_cholesky_lower(int m, double *A, int ld, int *info, hipStream_t st, double *dsave /*[2][64][64] scratch of the caller*/)
 {
     (void)hipMemsetAsync(info, 0, sizeof(int), st);
     for (int k0 = 0; k0 < m; k0 += NB) {
         const int nb = std::min(NB, m - k0);
         const int below = m - k0 - nb;
         const int nblk = 1 + (below + NB - 1) / NB;
-        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk), dim3(256), 0, st, m, A, ld, k0, info);
+        hipLaunchKernelGGL(potrf_panel_kernel, dim3(nblk), dim3(256), 0, st, m, A, ld, k0, info, dsave);
         if (below > 0) {
             // A22 -= L21 L21^T on the MFMA GEMM (lower tiles only)
             GemmParams g = {};

@@ -236,7 +236,8 @@ void launch_gemm_fused(const GemmParams &pk, const GemmParams &pw, const GemmPar
 // ---- dense solve side ---------------------------------------------------------------------
 // All on one stream, m x m row-major with leading dimension ld.
 int launch_cholesky_lower(int m, double *A /*in: M+ridge I, out: L (lower, upper zeroed)*/, int ld,
-                          int *info /*device: 0 ok else failing pivot+1*/, hipStream_t st);
+                          int *info /*device: 0 ok else failing pivot+1*/, hipStream_t st,
+                          double *dsave /*device scratch [2][64][64]: where diagonal blocks wait while others still read A*/);
 void launch_tril_inverse(int m, const double *L, int ld, double *Li, hipStream_t st);
 void launch_add_diag(int m, const double *A, int ld, double ridge, double *out, hipStream_t st);
 // Blocked Householder QR least squares on the TRANSPOSED matrix At[cols + 1][ldr] (column c of

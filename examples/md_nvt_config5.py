@@ -73,7 +73,14 @@ def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=
         for step, E, T, upd, wall in calc.run_md(at, steps, temperature, dt_fs=1.0, friction=friction, rng=rng, chunk=64, seed=1):
             yield step, E, T, wall, at.positions, upd
 
+    dbg = os.environ.get("C5_DEBUG")   # diagnostic: fingerprints of the model after every update, per rank
     for step, E, T, wall, p, updated in (device_loop() if device_md else host_loop()):
+        if dbg and updated:
+            eng = model.engine
+            eng._choli, eng._choli_on_device = None, True
+            ch = eng.choli
+            print(f"[c5dbg] rank {os.environ.get('RANK', '0')} step {step} m {eng.m} mu {float(np.sum(eng.mu)):.17g} "
+                  f"choli {float(np.abs(ch).sum()):.17g} M {float(np.abs(eng.M).sum()):.17g} E {E:.17g}", flush=True)
         rows.append(dict(step=step, E=E, T=T, wall=wall, size=calc.size, updated=updated, covloss=calc.covlog,
                          teacher_s=teacher.seconds, downsizes=stats["downsizes"], info=model.engine.solve_info()))
         if len(rows) > 1:
@@ -87,7 +94,7 @@ def run(steps=250, shape=(32, 32, 16), m_seed=1000, max_inducing=1024, friction=
         last = p
         if stop_after_downsizes and stats["downsizes"] >= stop_after_downsizes and step >= min_steps:
             break
-    if device_md:   # (the configuration the device holds now: the end of the last batch)
+    if device_md and getattr(model.engine, "_md", None) is not None:   # (the configuration the device holds now: the end of the last batch)
         last = model.engine.md_state()["positions"]
     return dict(calc=calc, teacher=teacher, system=(numbers, last, cell, pbc), rows=rows, stats=stats, setup_s=setup_s)
 

@@ -5,6 +5,7 @@
 #include "../autoforce_amd/csrc/tsqr.hip"
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 #include <random>
 void host_build_harm_coef(HarmCoef *) {}
 extern int g_bandqr_force;
@@ -71,7 +72,9 @@ int main(int argc, char **argv)
         for (int form = 0; form < 2; form++) {
             g_bandqr_force = form;
             float best = 1e30f;
-            for (int rep = 0; rep < 4; rep++) {
+            std::vector<double> xprev;
+            int nondet = 0;
+            for (int rep = 0; rep < 12; rep++) {
                 hipMemcpy(dA, A.data(), sizeof(double) * A.size(), hipMemcpyHostToDevice);
                 hipEvent_t e0, e1;
                 hipEventCreate(&e0); hipEventCreate(&e1);
@@ -83,7 +86,12 @@ int main(int argc, char **argv)
                 float ms_ = 0;
                 hipEventElapsedTime(&ms_, e0, e1);
                 best = std::min(best, ms_);
+                std::vector<double> xr(m);
+                hipMemcpy(xr.data(), dx, sizeof(double) * m, hipMemcpyDeviceToHost);
+                if (!xprev.empty() && memcmp(xprev.data(), xr.data(), sizeof(double) * m) != 0) nondet++;
+                xprev = xr;
             }
+            if (nondet) printf("m %d form %d: NOT REPRODUCIBLE in %d of 11 repeats\n", m, form, nondet);
             xs[form].resize(m);
             hipMemcpy(xs[form].data(), dx, sizeof(double) * m, hipMemcpyDeviceToHost);
             std::vector<double> Af(A.size());
