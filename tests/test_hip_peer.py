@@ -125,10 +125,13 @@ def _worker(rank, world, port, q, ediff):
         _lib.check(lib.sgpr_comm_allreduce(mdl.handle, buf.data_ptr(), buf.numel(), 0, None))
         _lib.check(lib.sgpr_sync_check(mdl.handle, None))
         s_sum = buf.cpu().numpy().copy()
-        buf = torch.arange(1000, dtype=torch.float64, device="cuda:0") * (rank + 1)
+        # (an odd number of words at an address that is not 16-byte aligned, with guard words either side)
+        big = torch.arange(-1, 1001, dtype=torch.float64, device="cuda:0") * (rank + 1)
+        buf = big[1:1000]
+        assert buf.data_ptr() % 16 == 8 and buf.numel() == 999
         _lib.check(lib.sgpr_comm_allreduce(mdl.handle, buf.data_ptr(), buf.numel(), 1, None))
         _lib.check(lib.sgpr_sync_check(mdl.handle, None))
-        s_max = buf.cpu().numpy().copy()
+        s_max = big.cpu().numpy().copy()
         x, v, sc, code = _md(mdl, system, STEPS, [3 + rank, 7, 100], ediff=0.0)   # (every rank cuts the run differently)
         xh, vh, sch, codeh = _md(mdl, system, STEPS, [100], ediff=ediff)
         q.put((rank, out["forces"], out["beta"], out["energy"], out["stress"], out2["forces"], s_sum, s_max, x, v, sc, xh, vh, sch,
@@ -187,7 +190,8 @@ def test_exchange_and_sharded_md_equal_the_single_process_bit_for_bit(world, sin
         np.testing.assert_allclose(F, single["gat"]["forces"], rtol=0, atol=1e-10 * fmax)
         # free-standing all-reduce
         np.testing.assert_array_equal(s_sum, np.arange(1000.0) * sum(range(1, world + 1)))
-        np.testing.assert_array_equal(s_max, np.arange(1000.0) * world)
+        np.testing.assert_array_equal(s_max[1:1000], np.arange(999.0) * world)
+        assert s_max[0] == -(rank + 1.0) and s_max[1000] == 999.0 * (rank + 1) and s_max[1001] == 1000.0 * (rank + 1)
         # the sharded MD loop: the single process's trajectory, whatever the batching
         assert len(sc) == STEPS
         np.testing.assert_array_equal(x, single["x"])

@@ -15,6 +15,14 @@ qt=$(ls gpurun_out/${tag}_pmc_sq/*/*kernel_trace.csv | head -1)
 python3 tools/pmc_json.py $f $w gpurun_out/${tag}_pmc_traffic_lips4096_m512.json "$note" $q $qt > /dev/null
 cp gpurun_out/${tag}_pmc_sq.txt gpurun_out/${tag}_pmc_sq_summary.txt; tail -n +2 gpurun_out/${tag}_pmc_lds.txt >> gpurun_out/${tag}_pmc_sq_summary.txt
 bash tools/pmc_mfma.sh ${tag}_pmc_mfma bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-big-wall > gpurun_out/${tag}_pmc_mfma_summary.txt 2>&1
+# the 16384-atom / 1024-inducing frame of bench.py's roofline_16384: FETCH_SIZE / WRITE_SIZE passes of tools/big_frame_steps.py
+for c in FETCH_SIZE WRITE_SIZE; do
+  mkdir -p gpurun_out/${tag}_pmc16k_$c
+  (cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${tag}_pmc16k_$c -- python3 tools/big_frame_steps.py 20 > gpurun_out/${tag}_pmc16k_$c/run.log 2>&1)
+done
+PMC_WORKLOAD="4-species oxide 16384 atoms / 1024 inducing, 1 GPU (tools/big_frame_steps.py)" python3 tools/pmc_json.py \
+  $(ls gpurun_out/${tag}_pmc16k_FETCH_SIZE/*/*counter_collection.csv | head -1) $(ls gpurun_out/${tag}_pmc16k_WRITE_SIZE/*/*counter_collection.csv | head -1) \
+  gpurun_out/${tag}_pmc_traffic_oxide16384_m1024.json "$note" > /dev/null
 cp $(ls gpurun_out/${tag}_final/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats_lips4096_m512.csv
 cat gpurun_out/${tag}_final_kstats.txt | tail -12
 cat gpurun_out/${tag}_pmc_mfma_summary.txt | tail -8

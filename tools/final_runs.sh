@@ -3,7 +3,7 @@
 tag=$1
 cd $GRAFT_REPO_ROOT
 bash tools/collect_profiles.sh $tag "builder run, round ${tag#r} (final build)" > gpurun_out/${tag}_collect.log 2>&1
-cp gpurun_out/${tag}_pmc_traffic_lips4096_m512.json profiles/   # (the bench line quotes the traffic of THIS build: same csrc sha)
+cp gpurun_out/${tag}_pmc_traffic_lips4096_m512.json gpurun_out/${tag}_pmc_traffic_oxide16384_m1024.json profiles/   # (the bench line quotes the traffic of THIS build: same csrc sha)
 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench_line.err
 python examples/md_nvt_config5.py --steps 300 > gpurun_out/${tag}_md_config5_16384.log 2>&1
 python examples/md_nvt_config5.py --steps 1000 > gpurun_out/${tag}_md_config5_16384_1000steps.log 2>&1

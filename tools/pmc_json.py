@@ -4,7 +4,7 @@ median per-launch bytes per kernel.  usage: pmc_json.py <fetch.csv> <write.csv> 
 With the SQ pass (SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_ANY, SQ_INSTS_VALU, ... of tools/collect_profiles.sh) and its kernel
 trace: per-kernel issue statistics, and `desc_valu_frac` = the share of the SIMDs' cycles in which the two descriptor
 kernels (list + forward, reverse) had a vector instruction executing."""
-import csv, json, statistics as st, sys
+import csv, json, os, statistics as st, sys
 from collections import defaultdict
 
 STAGE = [("nl_bin_kernel", "neighbor_bin"), ("nl_fwd_kernel", "list_forward"), ("desc_rev_kernel", "descriptor_rev"),
@@ -43,7 +43,7 @@ def csrc_sha():
 fetch, write = medians(sys.argv[1], "FETCH_SIZE"), medians(sys.argv[2], "WRITE_SIZE")
 out = {
     "csrc_sha": csrc_sha(),  # bench.py quotes this summary only while the kernel sources are the ones it was made on
-    "workload": "LiPS 4096 atoms / 512 inducing, 1 GPU",
+    "workload": os.environ.get("PMC_WORKLOAD", "LiPS 4096 atoms / 512 inducing, 1 GPU"),
     "source": sys.argv[4] if len(sys.argv) > 4 else "builder run",
     "unit": "bytes per launch",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc.sh), median over the "
