@@ -54,6 +54,7 @@ SIGNATURES = {
     "sgpr_data_get": (C.c_int, [_vp, _vp]),
     "sgpr_data_fit_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "sgpr_get_kmm_diag": (C.c_int, [_vp, _vp]),
+    "sgpr_get_kmm_rowsum": (C.c_int, [_vp, _vp]),
     "sgpr_data_solve": (C.c_int, [_vp, _vp, C.c_int, _dbl, _vp, _vp, _vp, _vp]),
     "sgpr_data_factor": (C.c_int, [_vp, _vp, C.c_int]),
     "sgpr_add_inducing": (C.c_int, [_vp, _i32, C.c_int, _vp, _vp]),

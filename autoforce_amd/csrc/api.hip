@@ -1813,6 +1813,57 @@ extern "C" int sgpr_get_kmm_diag(sgpr_model *h, double *diag)
     return SGPR_OK;
 }
 
+// Row sums of K_mm in the CALLER's order of inducing LCEs, each summed the way numpy sums a contiguous row (its pairwise
+// scheme: eight running sums over blocks of at most 128 elements, halves split at a multiple of eight), so that
+// `argsort(M.sum(axis=1))` of the downsizing rule (gppotential.py:815-842, lii) picks the same LCEs whether the matrix is
+// summed here or fetched and summed on the host.  One thread per row; inv[c] = sorted index of caller index c.
+__device__ static double numpy_pairwise(const double *row, const int *inv, int lo, int n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += row[inv[lo + i]];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = row[inv[lo + j]];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += row[inv[lo + i + j]];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += row[inv[lo + i]];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return numpy_pairwise(row, inv, lo, n2) + numpy_pairwise(row, inv, lo + n2, n - n2);
+}
+
+__global__ void kmm_rowsum_kernel(int m, const double *M, int ld, const int *inv, double *out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;   // caller index of the row
+    if (c >= m) return;
+    out[c] = numpy_pairwise(M + (size_t)inv[c] * ld, inv, 0, m);
+}
+
+extern "C" int sgpr_get_kmm_rowsum(sgpr_model *h, double *sums)
+{
+    if (!h || !sums) return fail(SGPR_E_INVALID, "sgpr_get_kmm_rowsum: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int m = h->m;
+    if (m <= 0) return SGPR_OK;
+    std::vector<int> inv(m);
+    for (int a = 0; a < m; a++) inv[h->ind_perm[a]] = a;
+    ScopedBuf<int> d_inv;
+    ScopedBuf<double> d_out;
+    if (d_inv.alloc(m) || d_out.alloc(m)) return fail(SGPR_E_NODEVICE, "hipMalloc failed");
+    HIPCHK(hipMemcpyAsync(d_inv.p, inv.data(), sizeof(int) * m, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(kmm_rowsum_kernel, dim3((m + 63) / 64), dim3(64), 0, h->stream, m, h->d_M.p, h->m_pad, d_inv.p, d_out.p);
+    HIPCHK(hipMemcpyAsync(sums, d_out.p, sizeof(double) * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return SGPR_OK;
+}
+
 extern "C" int sgpr_get_inducing_descriptors(sgpr_model *h, double *P)
 {
     if (!h || !P) return fail(SGPR_E_INVALID, "sgpr_get_inducing_descriptors: bad arguments");

@@ -269,6 +269,13 @@ class SGPRModel:
         return out
 
     @property
+    def M_rowsum(self):
+        """K_mm.sum(axis=1), caller order, summed on the device in numpy's own order (bit for bit `self.M.sum(axis=1)`)."""
+        out = np.zeros(self.m)
+        check(_lib.load().sgpr_get_kmm_rowsum(self._h, ptr(out)))
+        return out
+
+    @property
     def dims(self):
         out = np.zeros(8, np.int32)
         check(_lib.load().sgpr_get_dims(self._h, ptr(out)))

@@ -356,7 +356,7 @@ class PosteriorPotential:
             ch1 += 1
         ch2 = 0
         if lii and m < len(self.X):
-            order = np.argsort(self.M.sum(axis=1), kind="stable").tolist()
+            order = np.argsort(self.engine.M_rowsum, kind="stable").tolist()
             ch2 = order[:int(m)]
             self.select_inducing(ch2, remake=False)
         else:
@@ -444,20 +444,27 @@ class PosteriorPotential:
                 return [float(v) for v in self.engine.data_force_mae(np.asarray(mus), Yt)]
             return [float(np.abs(self._matvec(mu)[1] - f).mean()) for mu in mus]
 
+        solved = {}   # logit of the noise -> the weights of that second stage (what the mean offsets below start from)
+
         def objective(x):
             x = float(np.clip(x, -14.0, 14.0))
             if x not in cache:
-                mu = self.engine.resolve(noise=_sigmoid(x))
+                mu = solved[x] = self.engine.resolve(noise=_sigmoid(x))
                 cache[x] = float((maes([mu])[0] - noise_f) ** 2)
             return cache[x]
+
+        def scan(xs):
+            mus = self.engine.resolve_many([_sigmoid(x) for x in xs])
+            for x, mu, mae in zip(xs, mus, maes(mus)):
+                solved[x] = np.array(mu)
+                cache[x] = float((mae - noise_f) ** 2)
 
         x0 = float(self._noise["all"])
         grid = [x0 + d for d in (-6.0, -4.0, -3.0, -2.0, -1.0, -0.5, 0.5, 1.0, 2.0, 3.0, 4.0, 6.0)]
         if hasattr(self.engine, "resolve_many"):
             # the scan is a batch of independent second-stage problems: one set of launches for all of them
             xs = sorted({float(np.clip(x, -14.0, 14.0)) for x in grid + [x0]})
-            for x, mae in zip(xs, maes(self.engine.resolve_many([_sigmoid(x) for x in xs]))):
-                cache[x] = float((mae - noise_f) ** 2)
+            scan(xs)
         f0 = objective(x0)
         vals = [objective(x) for x in grid]
         k = int(np.argmin(vals))
@@ -476,8 +483,7 @@ class PosteriorPotential:
                 xs = [float(np.clip(lo + (hi - lo) * (j + 0.5) / 16.0, -14.0, 14.0)) for j in range(16)]
                 todo = [x for x in xs if x not in cache]
                 if todo and hasattr(self.engine, "resolve_many"):
-                    for x, mae in zip(todo, maes(self.engine.resolve_many([_sigmoid(x) for x in todo]))):
-                        cache[x] = float((mae - noise_f) ** 2)
+                    scan(todo)
                 cand = min(xs + [best], key=objective)
                 w = (hi - lo) / 16.0
                 best, lo, hi = cand, max(lo, cand - w), min(hi, cand + w)
@@ -485,7 +491,9 @@ class PosteriorPotential:
             if objective(xb) < f0 * (1.0 - 1e-3):
                 x0 = float(np.clip(xb, -14.0, 14.0))
         self._noise["all"] = x0
-        mu = self.engine.resolve(noise=_sigmoid(x0))
+        # (the scan has solved this very problem already: its weights are taken, not a second stage run once more — the
+        # fit with the energy rows that follows in make_munu is what the engine keeps)
+        mu = solved[x0] if x0 in solved else self.engine.resolve(noise=_sigmoid(x0))
         keys = sorted(self.mean.weights)
         nat = np.array([fr.natoms for fr in self.data], float)
         A = np.array([[fr.counts().get(z, 0) for z in keys] for fr in self.data], float) / nat[:, None]

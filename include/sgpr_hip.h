@@ -83,6 +83,10 @@ int sgpr_get_kmm(sgpr_model *h, double *M);
 int sgpr_get_inducing_descriptors(sgpr_model *h, double *P);
 /* diag(K_mm)[m], caller order. */
 int sgpr_get_kmm_diag(sgpr_model *h, double *diag);
+/* Row sums of K_mm [m], caller order — `self.M.sum(dim=1)` of the downsizing rule (regression/gppotential.py:815-842,
+ * lii=True) without the m x m matrix crossing the bus; summed in numpy's pairwise order over the caller's column order,
+ * so the values are the bits numpy gives for sgpr_get_kmm's matrix. */
+int sgpr_get_kmm_rowsum(sgpr_model *h, double *sums);
 
 /*
  * Set the regression state used by prediction.

@@ -92,6 +92,10 @@ class OracleModel:
     def M(self):
         return orc.kernel_matrix(self._ind_z, self._nnm, self._Pm, self._ind_z, self._nnm, self._Pm, self.exponent)
 
+    @property
+    def M_rowsum(self):
+        return self.M.sum(axis=1)
+
     def kernel_local(self, loc):
         P, nn = orc.inducing_descriptors(self.lmax, self.nmax, self.cutoff, self.species, *self._csr([loc]),
                                          radii=self.radii)

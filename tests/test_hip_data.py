@@ -457,6 +457,7 @@ def test_fit_statistics_on_the_device():
     want = [d.sum(), np.abs(d).sum(), (d * d).sum(), y.sum(), (y * y).sum(), np.abs(y).max(), len(d)]
     np.testing.assert_allclose(st, want, rtol=1e-12, atol=1e-10)
     np.testing.assert_array_equal(mdl.M_diag, np.diag(mdl.M))
+    np.testing.assert_array_equal(mdl.M_rowsum, mdl.M.sum(axis=1))   # (numpy's summation order, on the device)
     # the objective of the noise search: force rows only (energy and virial rows out), a batch of weight vectors
     is_f = np.zeros(len(K), bool)
     a = 0
