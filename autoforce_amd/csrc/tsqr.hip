@@ -723,6 +723,7 @@ size_t lstsq_qr_blocked_work_doubles(int rows, int cols)
     tsqr_levels(std::max(rows, 1), ch);
     size_t total = 0;
     for (int c : ch) total += (size_t)c * (2 * TNB * TCH + TNB * TNB);  // V, stacked R of the level above, T
+    for (int c : ch) total += (size_t)c * (TNB * TCH + TNB * TNB);      // a second V | T set (look-ahead: tsqr_panel)
     total = std::max(total, (size_t)2 * (32 * 1088 + 32 * 32));          // (the flat-panel form of banded problems: bandqr.inc)
     return total + (size_t)cols * cols + cols + 64;
 }
@@ -764,18 +765,35 @@ static void tsqr_attrs()
 // panel_cols[c * ld + r], r a physical row) over rows [k0, row_end), level by level, and update `ntrail` trailing
 // columns (trail[c * ld + r]) after every level.  V / T of every level go to `keep` (consecutive) when given — the
 // panel can then be applied again later (tsqr_apply_panels) — else to the per-level scratch in `work`.
+struct TsqrLookahead {
+    // the trailing update in two parts (launch_lstsq_qr_blocked): `near` columns right behind the panel on the panel's own
+    // stream, the rest on `far_stream` once `leaf_done` is reached; null far_stream: everything on the panel's stream
+    int near = 0;
+    hipStream_t far_stream = nullptr;
+    hipEvent_t leaf_done = nullptr, far_wait = nullptr, far_done = nullptr;
+    double *set2 = nullptr;   // V | T scratch of the odd panels (the far update of the panel before still reads the even set); null: even
+};
+
 static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, double *trail, int ntrail, double *work,
-                       double *keep, TsqrPanel *rec, hipStream_t st, int batch = 1, size_t bs_mat = 0, size_t bs_work = 0)
+                       double *keep, TsqrPanel *rec, hipStream_t st, int batch = 1, size_t bs_mat = 0, size_t bs_work = 0,
+                       const TsqrLookahead *la = nullptr)
 {
     std::vector<int> ch;
     tsqr_levels(std::max(row_end - k0, 1), ch);
-    // scratch layout of this panel: per level V | S (input of the level) | T
+    // scratch layout of this panel: per level V | S (input of the level) | T; a second V | T set behind (look-ahead)
     std::vector<double *> Vl(ch.size()), Tl(ch.size()), Sl(ch.size());
     double *w = work;
     for (size_t l = 0; l < ch.size(); l++) {
         Vl[l] = w; w += (size_t)ch[l] * TNB * TCH;
         Sl[l] = w; w += (size_t)ch[l] * TNB * TCH;
         Tl[l] = w; w += (size_t)ch[l] * TNB * TNB;
+    }
+    if (la && la->set2 && !keep) {
+        w = la->set2;
+        for (size_t l = 0; l < ch.size(); l++) {
+            Vl[l] = w; w += (size_t)ch[l] * TNB * TCH;
+            Tl[l] = w; w += (size_t)ch[l] * TNB * TNB;
+        }
     }
     if (keep) {
         double *kp = keep;
@@ -785,6 +803,27 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
         }
     }
     if (rec) { rec->k0 = k0; rec->nb = nb; rec->row_end = row_end; rec->nlev = 0; }
+    struct Lev { int n, chunks, stride; };
+    std::vector<Lev> levs;
+    // the update of a run of trailing columns by every level in turn (a level's leaf does not read the trailing columns: the
+    // leaves of all levels may run before any update, and the updates of different column ranges beside one another)
+    auto apply = [&](double *cols0, int ncols, hipStream_t s_, size_t l_first, size_t l_end) {
+        if (ncols <= 0) return;
+        for (size_t l = l_first; l < l_end; l++) {
+            TsqrApply ap = {};
+            ap.A = cols0;
+            ap.ldr = ld; ap.ntrail = ncols;
+            ap.row0 = k0; ap.row_end = row_end;
+            ap.n = levs[l].n; ap.stride = levs[l].stride;
+            ap.V = Vl[l]; ap.T = Tl[l];
+            // enough workgroups to fill the chip several times over, else as many tiles per workgroup as possible
+            const int ntiles = (ncols + TNB - 1) / TNB;
+            ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * levs[l].chunks * batch / 1024)));
+            ap.bs_mat = bs_mat; ap.bs_work = bs_work;
+            hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, levs[l].chunks, batch), dim3(TCH), lds_apply_bytes(), s_, ap);
+        }
+    };
+    const bool split = la && la->far_stream;
     int n = row_end - k0, stride = TNB;
     for (int l = 0;; l++) {
         const int chunks = (n + TCH - 1) / TCH;
@@ -820,23 +859,46 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
             TsqrLevel &lv = rec->lv[rec->nlev++];
             lv.V = Vl[l]; lv.T = Tl[l]; lv.n = n; lv.chunks = chunks; lv.stride = stride;
         }
-        if (ntrail > 0) {
-            TsqrApply ap = {};
-            ap.A = trail;
-            ap.ldr = ld; ap.ntrail = ntrail;
-            ap.row0 = k0; ap.row_end = row_end;
-            ap.n = n; ap.stride = stride;
-            ap.V = Vl[l]; ap.T = Tl[l];
-            // enough workgroups to fill the chip several times over, else as many tiles per workgroup as possible
-            const int ntiles = (ntrail + TNB - 1) / TNB;
-            ap.tpw = std::max(1, std::min(8, (int)((size_t)ntiles * chunks * batch / 1024)));
-            ap.bs_mat = bs_mat; ap.bs_work = bs_work;
-            hipLaunchKernelGGL(tsqr_apply_kernel, dim3((ntiles + ap.tpw - 1) / ap.tpw, chunks, batch), dim3(TCH), lds_apply_bytes(), st, ap);
-        }
+        levs.push_back({n, chunks, stride});
+        if (!split) apply(trail, ntrail, st, (size_t)l, (size_t)l + 1);   // (one stream: level by level, as the tree goes up)
         if (top) break;
         n = chunks * TNB;
         stride = l == 0 ? TCH : stride * TSB;
     }
+    if (split) {
+        const int near = std::min(la->near, ntrail);
+        (void)hipEventRecord(la->leaf_done, st);
+        // the far columns: beside whatever this stream does next (the near columns, then the next panel's leaves)
+        if (ntrail - near > 0) {
+            (void)hipStreamWaitEvent(la->far_stream, la->leaf_done, 0);
+            apply(trail + (size_t)near * ld, ntrail - near, la->far_stream, 0, levs.size());
+        }
+        (void)hipEventRecord(la->far_done, la->far_stream);
+        // the near columns were last written by the far update of the panel before
+        if (la->far_wait) (void)hipStreamWaitEvent(st, la->far_wait, 0);
+        apply(trail, near, st, 0, levs.size());
+    }
+}
+
+// the second stream and the events of the look-ahead: one set per host thread and device
+struct LookaheadRes {
+    hipStream_t side = nullptr;
+    hipEvent_t leaf[2] = {nullptr, nullptr}, far[2] = {nullptr, nullptr};
+};
+static LookaheadRes *lookahead_res()
+{
+    thread_local LookaheadRes res[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    LookaheadRes &r = res[dev];
+    if (!r.side) {
+        if (hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) != hipSuccess) { r.side = nullptr; return nullptr; }
+        for (int i = 0; i < 2; i++)
+            if (hipEventCreateWithFlags(&r.leaf[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&r.far[i], hipEventDisableTiming) != hipSuccess)
+                return nullptr;
+    }
+    return &r;
 }
 
 int g_bandqr_force = -1;   // tools/bandqr_test.hip: 0 / 1 overrides the environment
@@ -856,24 +918,45 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
         launch_band_qr(rows, cols, At, ldr, x, work, st, band, band_off, extra, 1, 0, 0) == 0)
         return 0;
     tsqr_attrs();
-    size_t scratch = 0;
+    size_t scratch = 0, set1 = 0;
     {
         std::vector<int> ch;
         tsqr_levels(rows, ch);
-        for (int c : ch) scratch += (size_t)c * (2 * TNB * TCH + TNB * TNB);
+        for (int c : ch) set1 += (size_t)c * (2 * TNB * TCH + TNB * TNB);
+        for (int c : ch) scratch += (size_t)c * (3 * TNB * TCH + 2 * TNB * TNB);
     }
     double *Rc = work + scratch, *z = Rc + (size_t)cols * cols;
     if (panels) panels->clear();
-    for (int k0 = 0; k0 < cols; k0 += TNB) {
+    // Look-ahead (tall dense problems): a panel's leaves occupy one wave per 256-row chunk — a fifth of the chip at 50 000
+    // rows — and its trailing update is bound by HBM, so the update of the columns BEHIND the next panel runs on a second
+    // stream beside the next panel's leaves; only the next panel's own 32 columns are updated in line.  Same kernels, same
+    // operands, same order for every column: the factorisation is bit for bit the one-stream one (SGPR_QR_LOOKAHEAD=0).
+    // Measured at 16384-atom frames, m = 1024: the rows of a frame appended to a kept factor (50 183 x 1024) 14.7 -> 13.3 ms
+    // — the chain leaves -> next panel's own columns -> leaves (330 us per panel, eight small launches) is what remains;
+    // a factorisation that KEEPS its reflectors (98 318 rows and more) gained nothing and stays on one stream.
+    static const bool la_on = !(getenv("SGPR_QR_LOOKAHEAD") && atoi(getenv("SGPR_QR_LOOKAHEAD")) == 0);
+    LookaheadRes *res = (la_on && band <= 0 && !keep && rows >= 8192 && cols > TNB) ? lookahead_res() : nullptr;
+    int npanel = 0;
+    for (int k0 = 0; k0 < cols; k0 += TNB, npanel++) {
         const int nb = std::min(TNB, cols - k0);
         const int row_end = band > 0 ? std::min(rows, band * (k0 + nb) + band_off) : rows;
         const int ntrail = cols + 1 + extra - (k0 + nb);  // the other columns, the targets, `extra` columns that follow Q^T
         TsqrPanel rec;
+        TsqrLookahead la;
+        if (res) {
+            la.near = std::min(TNB, cols - (k0 + nb));   // the next panel's columns (none behind the last panel)
+            la.far_stream = res->side;
+            la.leaf_done = res->leaf[npanel & 1];
+            la.far_done = res->far[npanel & 1];
+            la.far_wait = npanel > 0 ? res->far[(npanel - 1) & 1] : nullptr;
+            la.set2 = (npanel & 1) ? work + set1 : nullptr;
+        }
         tsqr_panel(At + (size_t)k0 * ldr, ldr, k0, nb, row_end, At + (size_t)(k0 + nb) * ldr, ntrail, work, keep,
-                   panels ? &rec : nullptr, st);
+                   panels ? &rec : nullptr, st, 1, 0, 0, res ? &la : nullptr);
         if (keep) keep += tsqr_panel_doubles(row_end - k0);
         if (panels) panels->push_back(rec);
     }
+    if (res && npanel > 0) (void)hipStreamWaitEvent(st, res->far[(npanel - 1) & 1], 0);   // the caller's stream sees the whole result
     if (x) {
         (void)Rc; (void)z;
         hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, At, ldr, At + (size_t)cols * ldr, x);
