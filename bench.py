@@ -9,12 +9,14 @@ A "step" = one pass of the hot path over one frame: device neighbour list -> SeS
 with positions already resident in HBM.  Workload at N=1: BASELINE configs[2] — 4096-atom
 "LiPS" (3 species), 512 inducing points, lmax=nmax=3, eta=4, rc=6 A, fp64.
 N > 1: atoms are dealt to ranks (per-species round robin, the reference's Distributer); every
-rank evaluates its share and ONE RCCL all-reduce of the packed [F | beta | E | virial] buffer
-combines them (the reference's four MPI all-reduces, calculator/active.py:562,601,602,777).  The
-all-reduce is issued by libsgpr_hip itself on the step's stream (sgpr_comm_init): no PyTorch op on
-the step.  torch.distributed (gloo, CPU) only carries the 128-byte communicator id at start-up and
-the barrier / max-over-ranks around the timed region.  The frame is the same for every N, so scaling
-is "strong".
+rank evaluates its share and ONE exchange of the packed [F | beta | E | virial] buffer combines them
+(the reference's four MPI all-reduces, calculator/active.py:562,601,602,777).  The exchange is issued
+by libsgpr_hip itself on the step's stream: by default its own all-gather over hipIpc-mapped buffers
+(sgpr_peer_attach: one hop on the xGMI mesh, summed in rank order — the same bits for every N; it also
+runs with several ranks on ONE GPU), else one RCCL all-reduce (sgpr_comm_init; --collective native).
+No PyTorch op on the step.  torch.distributed (gloo, CPU) only carries the handles / the 128-byte
+communicator id at start-up and the barrier / max-over-ranks around the timed region.  The frame is the
+same for every N, so scaling is "strong".
 
 torch is used for device memory and that bootstrap only; the numerics are libsgpr_hip.so
 (hand-written HIP) called through its C ABI.
