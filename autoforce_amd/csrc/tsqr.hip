@@ -772,6 +772,9 @@ struct TsqrLookahead {
     hipStream_t far_stream = nullptr;
     hipEvent_t leaf_done = nullptr, far_wait = nullptr, far_done = nullptr;
     double *set2 = nullptr;   // V | T scratch of the odd panels (the far update of the panel before still reads the even set); null: even
+    int layout_rows = 0;      // the scratch layout is that of a panel over this many rows, the SAME for every panel of the call: a
+                              // layout that followed each panel's own row count would shift when a 256-row chunk drops out, and
+                              // the next panel's stacked R would land on the V | T the far update is still reading
 };
 
 static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, double *trail, int ntrail, double *work,
@@ -779,7 +782,7 @@ static void tsqr_panel(double *panel_cols, int ld, int k0, int nb, int row_end, 
                        const TsqrLookahead *la = nullptr)
 {
     std::vector<int> ch;
-    tsqr_levels(std::max(row_end - k0, 1), ch);
+    tsqr_levels(std::max(la && la->layout_rows > 0 && !keep ? la->layout_rows : row_end - k0, 1), ch);
     // scratch layout of this panel: per level V | S (input of the level) | T; a second V | T set behind (look-ahead)
     std::vector<double *> Vl(ch.size()), Tl(ch.size()), Sl(ch.size());
     double *w = work;
@@ -950,6 +953,7 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
             la.far_done = res->far[npanel & 1];
             la.far_wait = npanel > 0 ? res->far[(npanel - 1) & 1] : nullptr;
             la.set2 = (npanel & 1) ? work + set1 : nullptr;
+            la.layout_rows = rows;
         }
         tsqr_panel(At + (size_t)k0 * ldr, ldr, k0, nb, row_end, At + (size_t)(k0 + nb) * ldr, ntrail, work, keep,
                    panels ? &rec : nullptr, st, 1, 0, 0, res ? &la : nullptr);

@@ -544,3 +544,43 @@ def test_downsize_follows_incrementally():
         check(route="columns appended / popped through the kept reflectors")
     assert nblocks >= 2
     mdl.close()
+
+
+_LOOKAHEAD_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+from autoforce_amd import SGPRModel
+from autoforce_amd.workloads import inducing_from_frame, lips
+mdl = SGPRModel(3, 3, 4, 6.0, species=[3, 15, 16])
+mdl.set_inducing(inducing_from_frame(mdl, *lips(16, seed=0), 1024, seed=1))
+rng = np.random.default_rng(0)
+# a tall dense problem of the size of a 16384-atom frame's rows (no reflectors kept: the two-stream schedule); 1024
+# columns: the 256-row chunk count of the panels drops four times on the way
+K = rng.normal(size=(50183, 1024)); Y = rng.normal(size=50183)
+out = []
+for rep in range(4):
+    mu = mdl.solve(K, Y)
+    out.append(hashlib.sha256(np.ascontiguousarray(mu).tobytes()).hexdigest())
+assert len(set(out)) == 1, out
+print("MU", out[0])
+"""
+
+
+@pytest.mark.gpu
+def test_tall_factorisation_with_lookahead_is_the_one_stream_one():
+    """A tall factorisation that keeps no reflectors — the rows of a pushed frame appended to a kept factor — runs the far
+    trailing update on a second stream beside the next panel's leaves (tsqr.hip): the weights are those of the one-stream
+    schedule bit for bit, call after call.  (The scratch the two streams share is laid out once per call: a layout that
+    followed the panels let a stacked R land on reflectors still being read, and an on-the-fly run took another
+    trajectory now and then.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for la in ("1", "0", "1"):
+        env = dict(os.environ, SGPR_QR_LOOKAHEAD=la, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _LOOKAHEAD_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.setdefault(la, []).append([ln for ln in r.stdout.splitlines() if ln.startswith("MU")][-1])
+    assert len(set(got["1"])) == 1 and got["1"][0] == got["0"][0], got
