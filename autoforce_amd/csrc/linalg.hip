@@ -13,6 +13,12 @@
 #include <vector>
 
 #define NB 64
+#ifdef POTRF_STAMPS   // tools/potrf_test.hip: where a panel launch spends its time (workgroup 1, thread 0)
+__device__ long long potrf_stamps[8];
+#define PSTAMP(i) if (blockIdx.x == 1 && threadIdx.x == 0) potrf_stamps[i] = wall_clock64();
+#else
+#define PSTAMP(i)
+#endif
 
 __global__ void add_diag_kernel(int m, const double *A, int ld, double ridge, double *out)
 {
@@ -40,6 +46,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int 
     __shared__ int failed;
     const int tid = threadIdx.x;
     const int nb = min(NB, m - k0);
+    PSTAMP(0)
     if (blockIdx.x == 0 && k0 > 0) {   // the previous panel's diagonal block, parked in dsave, goes home (also after a failure)
         const double *src = dsave + (size_t)(((k0 / NB) - 1) & 1) * NB * NB;
         for (int e = tid; e < NB * NB; e += 256) {
@@ -49,30 +56,71 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int 
     }
     if (*info != 0) return;
     if (tid == 0) failed = 0;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        D[i][j] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
+    // The 64 x 64 diagonal block in REGISTERS: thread (ty, tx) of a 16 x 16 grid holds the 4 x 4 tile of rows 4 ty .., columns
+    // 4 tx ..; a column step publishes the scaled column j through LDS and every thread takes it out of its tile — two
+    // barriers and 16 multiply-adds per step (the LDS form walked (nb - j)^2 elements with a division each: 100 us a block).
+    // Same operations on every element in the same order as before: the factor is the same bits.
+    const int ty = tid >> 4, tx = tid & 15;
+    double t[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = 4 * ty + a, j = 4 * tx + b;
+            t[a][b] = (i < nb && j <= i) ? A[(size_t)(k0 + i) * ld + k0 + j] : 0.0;
+        }
+    __shared__ double colj[NB];
+    __shared__ double s_d;
+    __syncthreads();
+    PSTAMP(1)
+    // (the column loop in groups of four with the position inside the tile a compile-time constant: no selects)
+    for (int jb = 0; jb < (nb + 3) / 4 && !failed; jb++) {
+#pragma unroll
+        for (int jr = 0; jr < 4; jr++) {
+            const int j = 4 * jb + jr;
+            if (j >= nb) break;
+            if (ty == jb && tx == jb) {          // the owner of (j, j)
+                const double d = t[jr][jr];
+                if (!(d > 0.0)) failed = j + 1;  // LAPACK potrf: leading minor not positive definite
+                s_d = sqrt(d);
+            }
+            __syncthreads();
+            if (failed) break;
+            const double djj = s_d;
+            if (tx == jb) {                      // the owners of column j: scale and publish
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const int i = 4 * ty + a;
+                    if (i == j) t[a][jr] = djj;
+                    else if (i > j) t[a][jr] /= djj;
+                    colj[i] = t[a][jr];
+                }
+            }
+            __syncthreads();
+            // trailing update of the lower triangle: D[i][k] -= D[i][j] D[k][j], j < k <= i
+            if (ty >= tx && tx >= jb) {
+                double ci[4], ck[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) { ci[a] = colj[4 * ty + a]; ck[a] = colj[4 * tx + a]; }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int i = 4 * ty + a, k = 4 * tx + b;
+                        if (k > j && k <= i && i < nb) t[a][b] -= ci[a] * ck[b];
+                    }
+            }
+        }
     }
     __syncthreads();
-    for (int j = 0; j < nb; j++) {
-        if (tid == 0) {
-            const double d = D[j][j];
-            if (!(d > 0.0)) failed = j + 1;  // LAPACK potrf: leading minor not positive definite
-            D[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        if (failed) break;
-        const double djj = D[j][j];
-        for (int i = j + 1 + tid; i < nb; i += 256) D[i][j] /= djj;
-        __syncthreads();
-        // trailing update of the lower triangle: D[i][k] -= D[i][j] D[k][j], j < k <= i
-        const int t = nb - j - 1;
-        for (int e = tid; e < t * t; e += 256) {
-            const int i = j + 1 + e / t, k = j + 1 + e % t;
-            if (k <= i) D[i][k] -= D[i][j] * D[k][j];
-        }
-        __syncthreads();
+    if (!failed) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) D[4 * ty + a][4 * tx + b] = (4 * tx + b <= 4 * ty + a) ? t[a][b] : 0.0;
     }
+    __syncthreads();
+    PSTAMP(2)
     if (failed) {
         if (tid == 0 && blockIdx.x == 0) atomicCAS(info, 0, k0 + failed);
         return;
@@ -98,23 +146,55 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(int m, double *A, int 
     const int r0 = k0 + nb + (blockIdx.x - 1) * NB;
     const int nr = min(NB, m - r0);
     if (nr <= 0) return;
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int i = e / NB, j = e % NB;
-        P[i][j] = (i < nr && j < nb) ? A[(size_t)(r0 + i) * ld + k0 + j] : 0.0;
-    }
-    __syncthreads();
-    if (tid < nr) {
-        for (int j = 0; j < nb; j++) {
-            double v = P[tid][j];
-            for (int k = 0; k < j; k++) v -= P[tid][k] * D[j][k];
-            P[tid][j] = v / D[j][j];
+    // L21 = A21 L11^-T, the 64 x 64 row block in register tiles as above, column by column: the owners of column k divide it
+    // by D[k][k] and publish it, everybody takes P[:, k] D[j][k] out of the columns j > k — per element the terms k = 0 .. j - 1
+    // in order, then the division: the bits of the row-by-row substitution it replaces (one thread per row, 2016 dependent
+    // multiply-adds through LDS: half of the launch).
+    double p[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = 4 * ty + a, j = 4 * tx + b;
+            p[a][b] = (i < nr && j < nb) ? A[(size_t)(r0 + i) * ld + k0 + j] : 0.0;
+        }
+    PSTAMP(3)
+    double (*pc)[NB] = (double (*)[NB])&P[0][0];   // [2][64]: column k of P, by parity of k (P itself is not needed any more)
+    for (int kb = 0; kb < (nb + 3) / 4; kb++) {
+#pragma unroll
+        for (int kr = 0; kr < 4; kr++) {
+            const int k = 4 * kb + kr;
+            if (k >= nb) break;
+            if (tx == kb) {
+                const double dkk = D[k][k];
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    p[a][kr] /= dkk;
+                    pc[k & 1][4 * ty + a] = p[a][kr];
+                }
+            }
+            __syncthreads();
+            if (tx >= kb) {
+                double ci[4], dj[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) { ci[a] = pc[k & 1][4 * ty + a]; dj[a] = D[4 * tx + a][k]; }
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (4 * tx + b > k) p[a][b] -= ci[a] * dj[b];
+            }
         }
     }
-    __syncthreads();
-    for (int e = tid; e < nr * nb; e += 256) {
-        const int i = e / nb, j = e % nb;
-        A[(size_t)(r0 + i) * ld + k0 + j] = P[i][j];
-    }
+    PSTAMP(4)
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = 4 * ty + a, j = 4 * tx + b;
+            if (i < nr && j < nb) A[(size_t)(r0 + i) * ld + k0 + j] = p[a][b];
+        }
+    PSTAMP(5)
 }
 
 int launch_cholesky_lower(int m, double *A, int ld, int *info, hipStream_t st, double *dsave /*[2][64][64] scratch of the caller*/)
