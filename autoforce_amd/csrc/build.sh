@@ -8,7 +8,12 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno
 mkdir -p build
 pids=()
 for f in api descriptor neighbor gemm linalg tsqr; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ sgpr_internal.h -nt build/$f.o ] || [ ../../include/sgpr_hip.h -nt build/$f.o ] || [ solve.inc -nt build/$f.o ] || [ data.inc -nt build/$f.o ] || [ gemm_tile.inc -nt build/$f.o ] || [ rows16.inc -nt build/$f.o ]; then
+  stale=0
+  [ -f build/$f.o ] || stale=1
+  for dep in $f.hip *.inc *.h ../../include/sgpr_hip.h; do [ $dep -nt build/$f.o ] && stale=1; done   # (every include: peer.inc, bandqr.inc, ...)
+  [ "${EXTRA_FLAGS}" != "$(cat build/$f.flags 2>/dev/null)" ] && stale=1
+  if [ $stale = 1 ]; then
+    echo "${EXTRA_FLAGS}" > build/$f.flags
     # gemm, tsqr: MFMA accumulators stay in VGPRs (the AGPR form copies them in and out around every trip of a loop)
     X=""; [ $f = gemm -o $f = tsqr ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"
     $HIPCC $FLAGS $X ${EXTRA_FLAGS} -c $f.hip -o build/$f.o &

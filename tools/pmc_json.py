@@ -14,6 +14,8 @@ STAGE = [("nl_bin_kernel", "neighbor_bin"), ("nl_fwd_kernel", "list_forward"), (
          ("nl_build_kernel", "neighbor_build"), ("desc_fwd_kernel", "descriptor_fwd"),
          ("gemm_nt_kernel<1", "gemm_knm"), ("gemm_nt_kernel<(GemmEpilogue)1", "gemm_knm"),
          ("gemm_nt_kernel<4", "gemm_w_covloss"), ("gemm_nt_kernel<(GemmEpilogue)4", "gemm_w_covloss"),
+         ("gemm_nt_kernel8r64<4", "gemm_w_covloss"), ("gemm_nt_kernel8r64<(GemmEpilogue)4", "gemm_w_covloss"),
+         ("gemm_nt_kernel8<4", "gemm_w_covloss"), ("gemm_nt_kernel8<(GemmEpilogue)4", "gemm_w_covloss"),
          ("desc_dc_kernel", "descriptor_dc"), ("desc_pair_kernel", "descriptor_pair"), ("finalize_kernel", "finalize")]
 
 
