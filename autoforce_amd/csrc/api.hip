@@ -393,6 +393,8 @@ struct sgpr_model {
     bool gemm_64_forced = false;              //   (decide_tile_heights) unless SGPR_GEMM_64="k,w" says so
     int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
     bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
+    int tile_chain = 1;                  // SGPR_TILE_CHAIN=0: every W + covloss tile its own workgroup, longest first (build_tiles)
+    int wcov_grid = 0;                   // workgroups of the grouped W + covloss launch (<= t_wcov.n: the rest are chained)
     bool xcd_quads = true;               // SGPR_XCD_QUADS=0: workgroup b of the descriptor kernels works on atoms 4b .. 4b+3
     std::vector<int4> h_t_w, h_t_cov, h_t_knm, h_t_both;
     // the three products of a step as ONE launch (gemm.hip::launch_gemm_fused): K_nm tiles first, then their consumers
@@ -1300,6 +1302,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
         if (sscanf(e, "%d,%d", &k, &w) == 2) { h->gemm_k64 = k != 0; h->gemm_w64 = w != 0; h->gemm_64_forced = true; }
     }
     if (const char *e = getenv("SGPR_TILE_BALANCE")) h->tile_balance = atoi(e) != 0;
+    if (const char *e = getenv("SGPR_TILE_CHAIN")) h->tile_chain = atoi(e);
     if (const char *e = getenv("SGPR_XCD_QUADS")) h->xcd_quads = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ROWS16")) h->rows16 = atoi(e) != 0;
     if (const char *e = getenv("SGPR_ROWS16_MB")) h->rows16_mb = std::max(1, atoi(e));
@@ -1462,20 +1465,31 @@ extern "C" void sgpr_destroy(sgpr_model *h)
 // 23.6.  Here every round of 32 goes to the CUs in the order of their load so far, the shortest tile of the round to the
 // most loaded CU (22 - 24 stages per CU).  Only the rounds that fill the free slots of an empty chip are placed; the rest
 // (and a last partial round) stay longest-first and run wherever a slot frees up.
-static void balance_xcd_share(std::vector<int4> &b, int ncu, int slots)
+// `extra` / `cov_first` (the grouped W + covloss table, build_tiles): an entry may carry a SUCCESSOR (index + 1 into `extra` in
+// the high half of .y; its reduction counts with the entry's), and of two entries of one length the covloss one (bit 16 of
+// .x: the longer epilogue) is dispatched first.
+static void balance_xcd_share(std::vector<int4> &b, int ncu, int slots, const std::vector<int4> *extra = nullptr, bool cov_first = false)
 {
-    std::stable_sort(b.begin(), b.end(), [](const int4 &p, const int4 &q) { return p.w - p.z > q.w - q.z; });
+    auto len = [&](const int4 &t) {
+        int l = t.w - t.z;
+        const unsigned sidx = (unsigned)t.y >> 16;
+        if (extra && sidx) l += (*extra)[sidx - 1].w - (*extra)[sidx - 1].z;
+        return l;
+    };
+    auto cov = [&](const int4 &t) { return cov_first && ((t.x >> 16) & 1); };
+    std::stable_sort(b.begin(), b.end(), [&](const int4 &p, const int4 &q) { return len(p) != len(q) ? len(p) > len(q) : cov(p) > cov(q); });
     if (ncu <= 1) return;
     std::vector<long long> load(ncu, 0);
     std::vector<int> order(ncu);
     for (int r = 0; r < slots && (size_t)(r + 1) * ncu <= b.size(); r++) {
         for (int c = 0; c < ncu; c++) order[c] = c;
         std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return load[p] > load[q]; });
-        std::vector<int4> round(b.begin() + (size_t)r * ncu, b.begin() + (size_t)(r + 1) * ncu);  // descending
+        std::vector<int4> round(b.begin() + (size_t)r * ncu, b.begin() + (size_t)(r + 1) * ncu);
+        std::stable_sort(round.begin(), round.end(), [&](const int4 &p, const int4 &q) { return len(p) > len(q); });  // descending
         for (int k = 0; k < ncu; k++) {
             const int4 t = round[ncu - 1 - k];  // ascending: the shortest to the most loaded
             b[(size_t)r * ncu + order[k]] = t;
-            load[order[k]] += t.w - t.z;
+            load[order[k]] += len(t);
         }
     }
 }
@@ -1609,8 +1623,42 @@ static int build_tiles(sgpr_model *h, int kind)
         for (const int4 &t : h->h_t_cov)
             if (t.w > t.z) bk[t.x % 8].push_back(make_int4(t.x | (1 << 16), t.y, t.z, t.w));
         // longest reductions first (LPT): row tiles come in species order and the species with the most
-        // inducing points — the deepest reductions — would otherwise form the tail of the launch
-        for (auto &b : bk) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? 2 : 4);
+        // inducing points — the deepest reductions — would otherwise form the tail of the launch.
+        // What the per-tile stamps of the 32-row form showed (tools/stamps_wcov.py, round 5): the four tiles of a CU share
+        // the matrix pipe OLDEST WAVE FIRST, so they finish in the order they were dispatched whatever their length (the
+        // longest, first in the table, at 28k cycles; the shortest, starved until then, at 33-34k); a CU's finish time goes
+        // with its stage count (1450 cycles per 32-deep stage) as long as nothing runs alone at the end; and a tile beyond
+        // the slots x CUs that start with the launch (1056 tiles for 1024 slots at 4096 / 512) waits for a slot until 34k
+        // and then runs its entry, first loads and epilogue alone: those 32 CUs ended at 42-43k, the others at 34-37k, and
+        // the launch lasts as long as they do.  So no tile waits for a slot: each overflow tile (the shortest of the XCD's
+        // share) is run by the OLDEST workgroup of one of the least loaded CUs AHEAD of that workgroup's own tile — at full
+        // priority, out of the way after 5k cycles; the entry's .y carries the position of its successor + 1 in the high
+        // half and the launch has `wcov_grid` workgroups.  (Behind the first tile to finish, the overflow tile ran from 30k
+        // to 39k; paired with another short tile in a young workgroup, from 32k to 41k.)  SGPR_TILE_CHAIN=0: one workgroup
+        // per tile.
+        const bool chain = h->tile_chain && h->tile_balance && !h->gemm_w64;
+        std::vector<std::vector<int4>> extra(8);
+        for (int x = 0; x < 8; x++) {
+            auto &b = bk[x];
+            balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? 2 : 4, nullptr, chain);
+            const size_t ncu_x = (size_t)h->cus_per_xcd, cap = 4 * ncu_x;
+            if (!chain || b.size() <= cap || b.size() - cap > ncu_x) continue;
+            std::vector<long long> load(ncu_x, 0);
+            for (size_t r = 0; r < 4; r++)
+                for (size_t c = 0; c < ncu_x; c++) load[c] += b[r * ncu_x + c].w - b[r * ncu_x + c].z;
+            std::vector<bool> taken(ncu_x, false);
+            for (size_t j = cap; j < b.size(); j++) {
+                size_t c = ncu_x;
+                for (size_t k = 0; k < ncu_x; k++)
+                    if (!taken[k] && (c == ncu_x || load[k] < load[c])) c = k;
+                taken[c] = true;
+                extra[x].push_back(b[c]);                              // round 0 of CU c: its oldest (longest) tile, now the successor
+                b[c] = b[j];
+                b[c].y |= (int)(extra[x].size() << 16);
+                load[c] += b[j].w - b[j].z;
+            }
+            b.resize(cap);
+        }
         size_t dp = 0;
         for (auto &b : bk) dp = std::max(dp, b.size());
         std::vector<int4> both(dp * 8, make_int4(0, 0, 0, 0));
@@ -1632,12 +1680,26 @@ static int build_tiles(sgpr_model *h, int kind)
                 if (hipMemcpy(h->t_covl.p, only.data(), sizeof(int4) * only.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
             }
         }
+        h->wcov_grid = (int)both.size();
+        {
+            // the successors behind the dispatched part; links become table positions
+            size_t base[8];
+            for (int x = 0; x < 8; x++) { base[x] = both.size(); both.insert(both.end(), extra[x].begin(), extra[x].end()); }
+            if (both.size() >= 65535) {   // (positions must fit the half word: cannot happen below ~2 M atoms per rank)
+                return -1;
+            }
+            for (size_t ppos = 0; ppos < (size_t)h->wcov_grid; ppos++) {
+                const unsigned sidx = (unsigned)both[ppos].y >> 16;
+                if (sidx) both[ppos].y = (both[ppos].y & 0xffff) | (int)((base[ppos % 8] + sidx) << 16);
+            }
+            h->h_t_both = both;
+            for (auto &t : h->h_t_both) t.y &= 0xffff;   // (the fused table has one workgroup per entry)
+        }
         h->t_wcov.release();
         if (!both.empty()) {
             if (h->t_wcov.alloc(both.size(), false)) return -1;
             if (hipMemcpy(h->t_wcov.p, both.data(), sizeof(int4) * both.size(), hipMemcpyHostToDevice) != hipSuccess) return -1;
         }
-        h->h_t_both = both;
         if (build_fused_tiles(h)) return -1;
     }
     dst.release();
@@ -2330,7 +2392,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
         stamp(h, "gemm_w", st);
         cov_rides = true;
     } else if (predict && beta) {
-        launch_gemm_wcov(gw, gc, h->t_wcov.p, (int)h->t_wcov.n, st);
+        launch_gemm_wcov(gw, gc, h->t_wcov.p, (int)h->t_wcov.n, st, h->wcov_grid);
         stamp(h, "gemm_w_covloss", st);
     } else if (predict) {
         launch_gemm_nt(gw, EPI_STORE, st);

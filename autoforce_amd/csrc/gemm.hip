@@ -33,7 +33,19 @@ __global__ __launch_bounds__(256, KD == 16 ? 4 : 2) void gemm_nt_kernel(GemmArgs
     using L = GemmLds<EPI, TM, KD>;
     __shared__ double As[L::NBUF * L::ASZ];
     __shared__ double Bs[L::NBUF * L::BSZ];
-    gemm_tile_body<EPI, TM, KD>(g, (int)blockIdx.x, As, Bs);
+    if constexpr (EPI == EPI_WCOV && TM == 1 && KD == 16) {
+        // (a tile table entry may name a successor — position + 1 in the high half of .y —: the tiles that would otherwise
+        // wait for a free slot run behind the first tile to finish on the least loaded CUs, api.hip::build_tiles)
+        for (int bid = (int)blockIdx.x;;) {
+            gemm_tile_body<EPI, TM, KD>(g, bid, As, Bs);
+            const int nxt = (int)((unsigned)g.p.tiles[bid].y >> 16) - 1;
+            if (nxt < 0) break;
+            __syncthreads();
+            bid = nxt;
+        }
+    } else {
+        gemm_tile_body<EPI, TM, KD>(g, (int)blockIdx.x, As, Bs);
+    }
 }
 
 template <int EPI>
@@ -53,9 +65,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel8r64(GemmArgs g)
     gemm_tile_body8r64<EPI>(g, (int)blockIdx.x, As, Bs);
 }
 
-void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st)
+void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st, int grid)
 {
     if (ntiles <= 0) return;
+    const bool chained = grid > 0 && grid < ntiles;
     GemmArgs g = {};
     g.p = pw;
     g.p2 = pc;
@@ -64,7 +77,7 @@ void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *ti
     g.ieta = -1;
     g.stamps = pw.stamps;
     if (pw.bm == 64 && pw.waves == 8) hipLaunchKernelGGL(gemm_nt_kernel8r64<EPI_WCOV>, dim3(ntiles), dim3(512), 0, st, g);
-    else if (pw.bm == 32 && pw.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 1, 16>), dim3(ntiles), dim3(256), 0, st, g);
+    else if (pw.bm == 32 && pw.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 1, 16>), dim3(chained ? grid : ntiles), dim3(256), 0, st, g);
     else if (pw.bm == 32) hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 1>), dim3(ntiles), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 2>), dim3(ntiles), dim3(256), 0, st, g);
 }

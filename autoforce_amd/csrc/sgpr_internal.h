@@ -226,7 +226,8 @@ struct GemmParams {
 void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st);
 // one launch for two products sharing the row dimension: pw with EPI_STORE, pc with EPI_ROWSQ;
 // tiles[].x carries the row tile in its low 16 bits and the problem (0 = pw, 1 = pc) in bit 16
-void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st);
+void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *tiles, int ntiles, hipStream_t st,
+                      int grid = 0 /*workgroups, when entries beyond them are chained to earlier ones (32-row four-wave form); 0: ntiles*/);
 // ONE launch for the three products of a step: K_nm (pk, EPI_KERNEL epilogue) and, behind per-row-panel counters, its
 // consumers W (pw) and covloss (pc).  tiles[].x: row tile | kind << 16 (0 W, 1 covloss, 2 K_nm) | K tiles of the row
 // panel << 20; K_nm entries first.  panel_cnt: [row tiles] ints, zero when `epoch` starts at 1; err: one int, zero.
