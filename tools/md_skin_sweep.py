@@ -14,9 +14,9 @@ fit_to_teacher(mdl, numbers, pos, cell, pbc)
 mass = np.array([MASS[int(z)] for z in numbers])
 v0 = np.random.default_rng(0).normal(size=(N, 3)) * np.sqrt(kB * 600.0 / mass[:, None])
 lib = _lib.load()
-for skin in (500, 650, 800, 1000, 1250):
+for skin in (400, 500, 600, 700, 800, 1000):
     _lib.check(lib.sgpr_set_option(mdl.handle, b"skin_milliangstrom", skin))
-    mdl.md_begin(numbers, pos, cell, pbc, mass, v0, dt=FS, friction=0.02, kT=kB * 600.0, seed=5)
+    mdl.md_begin(numbers, pos, cell, pbc, mass, v0, dt=FS, friction=float(os.environ.get("SWEEP_FRICTION", "0.02")), kT=kB * 600.0, seed=5)
     mdl.md_run(300, None)
     best = None
     for rep in range(3):
