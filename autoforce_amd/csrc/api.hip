@@ -1685,9 +1685,8 @@ static int build_tiles(sgpr_model *h, int kind)
             // the successors behind the dispatched part; links become table positions
             size_t base[8];
             for (int x = 0; x < 8; x++) { base[x] = both.size(); both.insert(both.end(), extra[x].begin(), extra[x].end()); }
-            if (both.size() >= 65535) {   // (positions must fit the half word: cannot happen below ~2 M atoms per rank)
-                return -1;
-            }
+            // (successors exist only in tables of little more than slots x CUs entries: positions fit the half word by far;
+            // a table without successors — every larger frame — carries no links and may have any size)
             for (size_t ppos = 0; ppos < (size_t)h->wcov_grid; ppos++) {
                 const unsigned sidx = (unsigned)both[ppos].y >> 16;
                 if (sidx) both[ppos].y = (both[ppos].y & 0xffff) | (int)((base[ppos % 8] + sidx) << 16);
