@@ -217,11 +217,7 @@ class ActiveCalculator(Calculator):
             except Exception as exc:  # noqa: BLE001
                 ok = 0
                 self._comm_note = f"native communicator not built ({exc}): host-side all-reduce instead"
-        flag = torch.tensor([ok])
-        if dist.get_backend(self.process_group) == "nccl":
-            flag = flag.cuda()
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
-        if int(flag.item()) == 0:
+        if self._min_over_ranks(ok) == 0:
             if getattr(eng, "comm_world", 1) > 1:
                 eng.comm_destroy()
             if not self._comm_note:
@@ -252,15 +248,9 @@ class ActiveCalculator(Calculator):
         else:
             ok = 0
         # every rank tries the exchange once before anybody relies on it (collective: all ranks that attached take part)
-        att = torch.tensor([ok])
-        dist.all_reduce(att, op=dist.ReduceOp.MIN, group=self.process_group)
-        if int(att.item()) == 1 and not eng.peer_selftest(rank, world):
+        if self._min_over_ranks(ok) == 1 and not eng.peer_selftest(rank, world):
             ok, why = 0, "the self-test exchange did not return the expected sum"
-        flag = torch.tensor([ok])
-        if dist.get_backend(self.process_group) == "nccl":
-            flag = flag.cuda()
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.process_group)
-        if int(flag.item()) == 0:
+        if self._min_over_ranks(ok) == 0:
             if blob is not None:
                 eng.peer_destroy()
             self._comm_note = f"the library's own exchange was not built ({why or 'another rank failed'})"
@@ -269,6 +259,16 @@ class ActiveCalculator(Calculator):
             return False
         self._peer_atoms = int(atoms_cap)
         return True
+
+    def _min_over_ranks(self, value):
+        """MIN of an integer over the process group (an NCCL / RCCL group reduces device tensors only)."""
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([int(value)])
+        if dist.get_backend(self.process_group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.process_group)
+        return int(t.item())
 
     def _peer_fit(self, engine, N):
         """A frame larger than the buffers of the library's own exchange hold: export and attach again (collective: every

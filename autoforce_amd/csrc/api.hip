@@ -140,7 +140,11 @@ struct PeerXchg {
     bool opened[SGPR_PEER_MAX] = {};       // mapped through hipIpcOpenMemHandle (to be closed)
     unsigned epoch = 0;                    // exchanges so far (the same on every rank: exchanges are collective)
     DevBuf<int> ctl;                       // [SGPR_PEER_MAX + 2] lines of 32 ints: push counters per peer | error word | dead word
-    long long timeout_ticks = 200000000LL; // bounded spin of the wait kernel (100 MHz ticks; SGPR_PEER_TIMEOUT_MS)
+    long long timeout_ticks = 3000000000LL; // bounded spin of the wait kernel: 30 s of 100 MHz ticks (SGPR_PEER_TIMEOUT_MS) — a rank's first
+                                           // sharded step may grow capacities and load code objects while its peers already wait
+    hipStream_t last_st = nullptr;         // the stream of the last exchange; an exchange on ANOTHER stream is ordered behind it (ev):
+    bool any_st = false;                   // the parity scheme and the push counters assume this handle's exchanges run one after the other
+    hipEvent_t ev = nullptr;
     const double *slice(int parity, int r) const { return (const double *)base + ((size_t)parity * world + r) * cap; }
 };
 
@@ -375,6 +379,7 @@ struct sgpr_model {
     double *pin = nullptr;     // page-locked staging of sgpr_compute: [3N + 9] in | [4N + 11] out
     size_t pin_doubles = 0;
     int pin_flip = 0;          // which of the two output halves of `pin` the last sgpr_compute wrote
+    double *pin_old = nullptr; // the buffer `pin` replaced when a larger frame came: views of the call before stay readable until the next growth
     DevBuf<int> d_shear;
     int epart_len = 0, virpart_len = 0;
     DevBuf<long long> d_stamps;  // SGPR_STAMPS=1 diagnostic
@@ -1402,6 +1407,7 @@ extern "C" void sgpr_destroy(sgpr_model *h)
     h->d_rows_cols.release();
     h->d_rows_rowof.release(); h->d_rows_qoff.release(); h->d_rows_vpart.release();
     if (h->pin) (void)hipHostFree(h->pin);
+    if (h->pin_old) (void)hipHostFree(h->pin_old);
     if (h->md.halt_host) (void)hipHostFree(h->md.halt_host);
     if (h->md.mark) (void)hipHostFree(h->md.mark);
     if (h->md.scal_pin) (void)hipHostFree(h->md.scal_pin);
@@ -2434,9 +2440,12 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     if (shard_next) {
         stamp(h, "finalize", st);
         ShardSrc src;
-        src.base = h->d_xpacked.p; src.n = 1; src.stride = 0;
+        src.base = h->d_xpacked.p; src.n = 1; src.stride = 0; src.ctl = nullptr;
         if (px) {
             int parity = 0;
+            if (h->peer.world != h->world || h->peer.rank != h->rank)
+                return fail(SGPR_E_INVALID, "the bound sharding (rank %d of %d) differs from the exchange's (rank %d of %d)",
+                            h->rank, h->world, h->peer.rank, h->peer.world);
             const int *halt = nx->mode == 2 ? nx->md.halt : nullptr;
             const int re = peer_exchange(h, h->d_xpacked.p, xlen, st, &parity, halt, (int)step);
             if (re) return re;
@@ -2539,7 +2548,7 @@ static int reduce_packed(sgpr_model *h, double *packed_dev, hipStream_t st)
         const int re = peer_exchange(h, h->d_xpacked.p, peer_xlen(h->N), st, &parity);
         if (re) return re;
         hipLaunchKernelGGL(peer_sum_xp_kernel, dim3(std::min(256, (4 * std::max(h->N, 1) + 11 + 255) / 256)), dim3(256), 0, st,
-                           peer_src(h->peer, parity), h->N, packed_dev);
+                           peer_src(h->peer, parity), h->N, packed_dev, (const int *)h->peer.ctl.p);
         return SGPR_OK;
     }
     if (!h->comm) return SGPR_OK;  // no communicator attached: the caller combines the partial sums
@@ -2610,7 +2619,7 @@ extern "C" int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count
         const int re = peer_exchange(h, buf_dev, (size_t)count, st, &parity);
         if (re) return re;
         hipLaunchKernelGGL(peer_sum_kernel, dim3((unsigned)std::min<int64_t>(256, (count + 255) / 256)), dim3(256), 0, st,
-                           peer_src(h->peer, parity), (size_t)count, op_max, buf_dev);
+                           peer_src(h->peer, parity), (size_t)count, op_max, buf_dev, (const int *)h->peer.ctl.p);
         return SGPR_OK;
     }
     const ncclResult_t r = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, ncclDouble, op_max ? ncclMax : ncclSum, h->comm, st);
@@ -2676,7 +2685,10 @@ static int compute_core(sgpr_model *h, int N, const int32_t *numbers, const doub
     // held — if not, or on the first call, the checked path below re-sizes and repeats
     const size_t n_in = (size_t)3 * N + 9, n_out = (size_t)4 * N + 11 + 6;
     if (h->pin_doubles < n_in + 2 * n_out) {
-        if (h->pin) (void)hipHostFree(h->pin);
+        // (the stream is idle here: every call ends synchronised.  The outgoing buffer is kept for one more generation: a view
+        // handed out by the previous call stays valid "until the call after next" also across a growth)
+        if (h->pin_old) (void)hipHostFree(h->pin_old);
+        h->pin_old = h->pin;
         h->pin = nullptr; h->pin_doubles = 0;
         if (hipHostMalloc((void **)&h->pin, sizeof(double) * (n_in + 2 * n_out + 64), hipHostMallocMapped) == hipSuccess) {
             h->pin_doubles = n_in + 2 * n_out + 64;
@@ -2743,6 +2755,14 @@ static int compute_core(sgpr_model *h, int N, const int32_t *numbers, const doub
         }
         h->warm = false;  // a capacity overflowed (or the cell is degenerate): the checked path sorts it out
         h->lists_valid = false;
+        // ... unless the word is the poison value: a wait of this rank's exchange gave up (the consumer kernel has seen the dead
+        // word: peer.inc) or another rank failed the step outright — then the call fails here, like its peers', with the ONE
+        // exchange every rank has issued for it
+        if (po[4 * (size_t)N + 10] >= 0.5 * SGPR_PEER_POISON) {
+            if (const int pc = peer_check(h)) return pc;
+            return fail(SGPR_E_OVERFLOW, "sgpr_compute: another rank of the communicator failed this step (its own error "
+                        "message says why); the call fails on every rank");
+        }
     }
     HIPCHK(hipMemcpyAsync(h->d_pos_in.p, positions, sizeof(double) * 3 * N, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_cell_in.p, cell, sizeof(double) * 9, hipMemcpyHostToDevice, h->stream));

@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MIN_TIMED_MS = 50.0       # the --steps batch is repeated until this much has been timed; the median batch is reported
 FP64_MFMA_PEAK_TF = 78.6  # BASELINE.md §4 (MI355X FP64 matrix peak)
 
 
@@ -416,22 +417,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    fence()
-    rb0 = C.c_int64(0)
-    _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb0)))
-    with Watchdog("timed steps", seconds=max(600, int(0.05 * args.steps)), rank=rank):
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def batches_of(first_dt):
+        """A batch = exactly --steps steps between two fences (the contract's timed region).  One batch of 20 steps is
+        under 2 ms: the batch is REPEATED until >= MIN_TIMED_MS of steps have been timed and the MEDIAN batch is reported
+        (min / max beside it).  The count follows from the first batch's max-over-ranks time: the same on every rank."""
+        return int(min(400, max(1, np.ceil(MIN_TIMED_MS * 1e-3 / max(first_dt, 1e-9)))))
+
+    def resident_batch():
+        fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
-        dt = time.perf_counter() - t0
+        return max_over_ranks(time.perf_counter() - t0)
+
+    rb0 = C.c_int64(0)
+    _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb0)))
+    with Watchdog("timed steps", seconds=max(600, int(0.05 * args.steps)), rank=rank):
+        res_dts = [resident_batch()]
+        for _ in range(batches_of(res_dts[0]) - 1):
+            res_dts.append(resident_batch())
     rb1 = C.c_int64(0)
     _lib.check(lib.sgpr_get_list_rebuilds(h, C.addressof(rb1)))
     _lib.check(lib.sgpr_sync_check(h, sp))
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = float(np.median(res_dts))
     ms_per_step = dt / args.steps * 1e3
     value = N * args.steps / dt
     out_host = packed.cpu().numpy()  # the reduced result of the last timed step
@@ -552,18 +568,26 @@ def main():
                 resizes += code == 2   # a neighbour capacity outgrown on the way: the next call re-sizes and goes on
             return time.perf_counter() - tm, np.concatenate(rows), resizes
 
-        # THE HEADLINE: exactly --steps dependent MD steps between two fences, max over the ranks
-        fence()
-        th = time.perf_counter()
-        _, sc_h, rz_h = md_timed(None, args.steps)
-        fence()
-        dt_md = time.perf_counter() - th
-        if world > 1:
-            t = torch.tensor([dt_md], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_md = float(t.item())
-        if len(sc_h) == args.steps:
-            md_head = {"ms_per_step": dt_md / args.steps * 1e3, "value": N * args.steps / dt_md, "capacity_resizes": int(rz_h)}
+        # THE HEADLINE: exactly --steps dependent MD steps between two fences, max over the ranks — one BATCH; batches are
+        # repeated (each continues the run where the one before stopped) until >= MIN_TIMED_MS have been timed, and the
+        # median batch is what `value` / `ms_per_step` quote
+        def md_batch():
+            fence()
+            th = time.perf_counter()
+            _, sc_b, rz_b = md_timed(None, args.steps)
+            fence()
+            return max_over_ranks(time.perf_counter() - th), len(sc_b) == args.steps and rz_b == 0
+
+        md_dts = []
+        d0, ok0 = md_batch()
+        for _ in range(batches_of(d0) - 1 if ok0 else 0):
+            md_dts.append(md_batch())
+        md_dts = [d0] * bool(ok0) + [d for d, ok in md_dts if ok]   # (a batch that outgrew a capacity is not a sample)
+        if md_dts:
+            dt_md = float(np.median(md_dts))
+            md_head = {"ms_per_step": dt_md / args.steps * 1e3, "value": N * args.steps / dt_md, "batches": len(md_dts),
+                       "ms_per_step_min": min(md_dts) / args.steps * 1e3, "ms_per_step_max": max(md_dts) / args.steps * 1e3,
+                       "ms_per_step_first_batch": d0 / args.steps * 1e3}
         rbm0 = mdl.list_rebuilds()
         tmd, sc, resizes = md_timed(None)                       # deviates drawn on the device
         rbm1 = mdl.list_rebuilds()
@@ -616,8 +640,16 @@ def main():
                                   f"(csrc sha {tj.get('csrc_sha')} then, {sha} now)")
         af = algorithmic_flops(numbers, [x.number for x in mdl.X], dims["Dpad"], world)
         if dom in af:  # a GEMM leads: price it against the dense fp64 MFMA peak
+            Dd = dims["D"] * dims["S"] ** 2
+            dense = {"gemm_knm": 2.0 * cnt * m * Dd, "gemm_w": 2.0 * cnt * m * Dd, "gemm_w_covloss": 2.0 * cnt * m * Dd + float(m) * m * cnt}
             head = {"bound": "mfma", "achieved": af[dom] / dom_s / 1e12, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": af[dom] / dom_s / 1e12 / FP64_MFMA_PEAK_TF, "algorithmic_flops": af[dom]}
+                    "frac": af[dom] / dom_s / 1e12 / FP64_MFMA_PEAK_TF, "algorithmic_flops": af[dom],
+                    "dense_equiv_flops": dense.get(dom),
+                    "flops_note": "algorithmic_flops counts what the block-diagonal formulation needs: K_nm, W and L^-1 are zero "
+                                  "outside a species block (atoms and inducing points are species-sorted) and rows are packed "
+                                  f"{Dd} -> {dims['Dpad']} doubles (p[u,v,l] is symmetric in u,v); dense_equiv_flops is SURVEY 8(d)'s "
+                                  "formula for the same product on dense unpacked operands (2NmD + m^2 N): pricing the launch with "
+                                  "it would exceed the fp64 MFMA peak, so frac uses the block count"}
         else:
             head = {"bound": "hbm", "achieved": ab[dom] / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ab[dom] / dom_s / 1e9 / HBM_PEAK_GBS}
@@ -667,6 +699,12 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": md_head["ms_per_step"] if md_head else ms_per_step,
             "value_is": "md_loop (dependent steps)" if md_head else "resident frames",
+            "timed": {"batch_steps": args.steps, "min_timed_ms": MIN_TIMED_MS,
+                      "what": "a batch = exactly --steps steps between two fences (barrier + synchronize), max over ranks; repeated "
+                              "until min_timed_ms have been timed; value / ms_per_step = the MEDIAN batch",
+                      "md_loop": md_head, "resident_frames": {"batches": len(res_dts), "ms_per_step_min": min(res_dts) / args.steps * 1e3,
+                                                              "ms_per_step_max": max(res_dts) / args.steps * 1e3,
+                                                              "ms_per_step_first_batch": res_dts[0] / args.steps * 1e3}},
             "value_resident_frames": value,
             "ms_per_step_resident_frames": ms_per_step,
             "collective": backend if world > 1 else None,

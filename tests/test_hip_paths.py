@@ -386,3 +386,12 @@ def test_bench_line_keeps_its_contract():
     assert d["value_is"].startswith("md_loop") and d["value_resident_frames"] > 0 and d["ms_per_step_resident_frames"] > 0
     assert abs(d["value_resident_frames"] - atoms / (d["ms_per_step_resident_frames"] * 1e-3)) <= 1e-6 * d["value_resident_frames"]
     assert d["value"] <= 1.05 * d["value_resident_frames"]
+    # the timed region: --steps is the BATCH, repeated until >= 50 ms have been timed; the median batch is the headline
+    t = d["timed"]
+    assert t["batch_steps"] == 20 and t["min_timed_ms"] >= 50.0
+    for leg, ms in ((t["md_loop"], d["ms_per_step"]), (t["resident_frames"], d["ms_per_step_resident_frames"])):
+        assert leg["batches"] >= 3 and leg["batches"] * 20 * ms >= 0.5 * t["min_timed_ms"]
+        assert leg["ms_per_step_min"] <= ms <= leg["ms_per_step_max"]
+    # the flop count behind frac is the block-diagonal one; the dense formula of SURVEY 8(d) is quoted beside it
+    if r["bound"] == "mfma":
+        assert r["dense_equiv_flops"] > r["algorithmic_flops"] > 0

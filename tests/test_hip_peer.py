@@ -275,3 +275,75 @@ def test_on_the_fly_learning_with_the_md_state_on_two_ranks(tmp_path, tdamp):
         np.testing.assert_allclose(v, ref[3], rtol=0, atol=1e-7)
     np.testing.assert_array_equal(res[2][0][2], res[2][1][2])            # both ranks end in the same bits
     np.testing.assert_array_equal(res[2][0][3], res[2][1][3])
+
+
+def _timeout_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests")]
+    import torch.distributed as dist
+    from autoforce_amd import _lib
+    from autoforce_amd.watchdog import Watchdog
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SGPR_PEER_TIMEOUT_MS"] = "20000"
+    with Watchdog(f"peer time-out, rank {rank} of {world}", seconds=240, rank=rank):
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        mdl, (numbers, pos, cell, pbc) = _build()
+        N = len(numbers)
+
+        def attach():
+            blobs = [None] * world
+            dist.all_gather_object(blobs, mdl.peer_export(rank, world, 7 * N + 11))
+            mdl.peer_attach(blobs)
+            dist.barrier()
+        attach()
+        ok = mdl.predict(numbers, pos, cell, pbc, rank=rank, world=world)          # the checked path
+        ok2 = mdl.predict_view(numbers, pos, cell, pbc, rank=rank, world=world)    # the warm path
+        same = np.array_equal(ok["forces"], ok2["forces"])
+        dist.barrier()
+        # rank 1 leaves the step; rank 0's WARM call must fail (not return the sums of the exchange before)
+        msgs = []
+        os.environ["SGPR_PEER_TIMEOUT_MS"] = "1000" if rank == 0 else "20000"
+        attach()                                          # (the time-out is read at export: rank 0 now gives up after 1 s)
+        mdl.predict(numbers, pos, cell, pbc, rank=rank, world=world)
+        mdl.predict_view(numbers, pos, cell, pbc, rank=rank, world=world)
+        dist.barrier()
+        if rank == 0:
+            for call in (mdl.predict_view, mdl.predict, mdl.predict_view):
+                try:
+                    out = call(numbers, pos + 0.01, cell, pbc, rank=rank, world=world)
+                    msgs.append("returned")
+                except _lib.SgprError as exc:
+                    msgs.append(str(exc))
+        dist.barrier()
+        # a time-out is permanent until the exchange is built again: export + attach on every rank, then steps work
+        attach()
+        again = mdl.predict(numbers, pos, cell, pbc, rank=rank, world=world)
+        again2 = mdl.predict_view(numbers, pos, cell, pbc, rank=rank, world=world)
+        q.put((rank, same, msgs, np.array_equal(again["forces"], ok["forces"]), np.array_equal(again2["forces"], ok["forces"])))
+        dist.barrier()
+        mdl.peer_destroy()
+        dist.destroy_process_group()
+
+
+def test_a_rank_that_leaves_the_step_fails_the_warm_call_of_its_peer():
+    """A peer that never pushes: the waiting rank's bounded wait gives up, and the call — the WARM path of sgpr_compute /
+    sgpr_compute_view included, which reads only the step's own overflow word — fails with the time-out instead of returning
+    the sums of the previous exchange of the same parity; so does every later call, until the exchange is exported and
+    attached again (then steps are the old bits)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, msgs, again, again2 in got:
+        assert same and again and again2
+    msgs = got[0][2]
+    assert len(msgs) == 3 and all("timed out" in m for m in msgs), msgs
