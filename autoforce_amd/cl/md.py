@@ -4,8 +4,10 @@
 
 Langevin dynamics (the reference's `dynamics = 'Langevin'`, cl/md.py:117-128) and the reference's DEFAULT — `dynamics =
 'NPT'` without a bulk modulus: Nose-Hoover NVT, ase.md.npt.NPT(pfactor=None, ttime=tdamp fs), cl/md.py:17, :131-166 — run with
-positions and velocities in device memory (ActiveCalculator.run_md); NPT with a bulk modulus (a cell that moves) is
-ase.md.npt.NPT around the calculator and needs ASE.  Structures are read and written as extended XYZ (ASE's own format; without ASE no other reader exists
+positions and velocities in device memory (ActiveCalculator.run_md); NPT with a bulk modulus (a cell that moves, cl/md.py:147-166)
+is the same ASE integrator restated in `autoforce_amd/npt.py` (Melchionna's combined Nose-Hoover / Parrinello-Rahman scheme,
+`mask`, `iso`, `stress`, `pdamp`, the `ml_filter` wrapper) driving calculate() once per step, as ASE's object does in the
+reference.  Structures are read and written as extended XYZ (ASE's own format; without ASE no other reader exists
 here), the trajectory likewise (`trajectory = 'md.xyz'`)."""
 import argparse
 
@@ -60,18 +62,60 @@ def init_velocities(numbers, masses, temperature, rng, cm0=True):
     return p / masses[:, None]
 
 
-def manual_steps(atoms, calc, eps, rng):
-    """cl/md.py:176-199 for constant-cell runs: a rattled copy is shown to an active calculator before the run."""
+def _scale_cell(atoms, cell, factor):
+    """atoms.set_cell(factor * cell, scale_atoms=True): the atoms keep their fractional coordinates."""
+    old = np.array(getattr(atoms.cell, "array", atoms.cell), float)
+    frac = np.linalg.solve(old.T, np.asarray(atoms.positions, float).T).T
+    atoms.cell = factor * np.asarray(cell, float)
+    atoms.positions = frac @ (factor * np.asarray(cell, float))
+
+
+def manual_steps(atoms, calc, eps, rng, eps2=0.0, npt=False):
+    """cl/md.py:175-196: a rattled copy — and, before a run whose cell moves, an expanded and a shrunk copy — is shown to an
+    active calculator before the run."""
     calc._logpref = "#"
     calc.log("manual steps:")
     calc.log(f"rattle: {eps}")
+    saved = atoms.positions.copy()
+    atoms.calc = calc
     if eps > 0.0:
-        saved = atoms.positions.copy()
         atoms.positions = saved + rng.normal(scale=eps, size=saved.shape)
-        atoms.calc = calc
         atoms.get_potential_energy()
-        atoms.positions = saved
+    if npt and eps2 > 0.0:
+        cell = np.array(getattr(atoms.cell, "array", atoms.cell), float)
+        calc.log(f"expand: {(1. + eps2)}*cell")
+        _scale_cell(atoms, cell, 1.0 + eps2)
+        atoms.get_potential_energy()
+        calc.log(f"shrink: {(1. - eps2)}*cell")
+        _scale_cell(atoms, cell, 1.0 - eps2)
+        atoms.get_potential_energy()
+        _scale_cell(atoms, cell, 1.0)
+    atoms.positions = saved
     calc._logpref = ""
+
+
+def npt_dynamics(atoms, calc, dt, tem, bulk_modulus, stress, mask, iso, tdamp, pdamp, ml_filter):
+    """cl/md.py:131-166 with a bulk modulus: ase.md.npt.NPT(atoms, dt fs, temperature_K, externalstress = stress GPa, ttime =
+    tdamp fs, pfactor = (pdamp fs)^2 * bulk_modulus GPa, mask) on the upper-triangular cell (`configure_cell`, :169-172;
+    an all-zero cell would need ASE's `center(vacuum=6)`: a periodic cell is asked for here), `iso` = no traceless strain."""
+    from ..npt import GPA, NPT, FilterDeltas, make_cell_upper_triangular
+    from ..workloads import FS
+    cell = np.array(getattr(atoms.cell, "array", atoms.cell), float)
+    if np.allclose(cell, 0.0):
+        raise ValueError("NPT needs a cell (the reference puts a cluster into a box with 6 A of vacuum: give the box)")
+    v = atoms.get_velocities()
+    pos, cell_ut, R = make_cell_upper_triangular(atoms.positions, cell)
+    if not np.array_equal(cell_ut, cell):
+        atoms.cell = cell_ut
+        atoms.positions = pos
+        if v is not None:
+            atoms.set_velocities(np.asarray(v) @ R)
+    md_atoms = FilterDeltas(atoms, shrink=ml_filter) if ml_filter else atoms
+    dyn = NPT(md_atoms, dt * FS, tem, externalstress=stress * GPA, ttime=tdamp * FS, pfactor=(pdamp * FS) ** 2 * bulk_modulus * GPA,
+              mask=mask)
+    if iso:
+        dyn.set_fraction_traceless(0.0)
+    return dyn
 
 
 def md(atoms, calc=None, dynamics="NPT", dt=None, tem=300.0, picos=100, trajectory="md.xyz", loginterval=1, append=False,
@@ -85,7 +129,7 @@ def md(atoms, calc=None, dynamics="NPT", dt=None, tem=300.0, picos=100, trajecto
     calc = gen_active_calc(species=sorted(set(int(z) for z in numbers))) if calc is None else calc
     atoms.calc = calc
     if calc.active:
-        manual_steps(atoms, calc, eps_pos, rng)
+        manual_steps(atoms, calc, eps_pos, rng, eps_cell, npt=bool(bulk_modulus))
     if rattle:
         atoms.positions = atoms.positions + rng.normal(scale=rattle, size=atoms.positions.shape)
     temperatures = list(tem) if hasattr(tem, "__iter__") else [tem]
@@ -101,14 +145,19 @@ def md(atoms, calc=None, dynamics="NPT", dt=None, tem=300.0, picos=100, trajecto
         dt = 0.25 if (numbers == 1).any() else 1.0          # cl/md.py:70-74
     if dynamics.upper() not in ("LANGEVIN", "NPT"):
         raise ValueError(f"dynamics = {dynamics!r}: 'NPT' or 'Langevin' (cl/md.py:84-101)")
-    if dynamics.upper() == "NPT" and bulk_modulus:
-        raise NotImplementedError("NPT with a bulk modulus (a cell that moves) is ase.md.npt.NPT around this calculator "
-                                  "(cl/md.py:131-166): install ASE and use the reference's driver with "
-                                  "autoforce_amd.calculator.ActiveCalculator; here: bulk_modulus = None (Nose-Hoover NVT) or 'Langevin'")
+    moving_cell = dynamics.upper() == "NPT" and bool(bulk_modulus)
     tdamp_fs = float(tdamp) if dynamics.upper() == "NPT" else None
     out = open(trajectory, "a" if append else "w") if (trajectory and calc.rank == 0) else None
     for T in temperatures:
         steps = int(picos * 1000 / dt) if picos > 0 else int(-picos)
+        if moving_cell:
+            # the barostat's integrator around calculate(), one call per step (the log line, the covloss gate and the model
+            # updates are calculate()'s own, as in the reference)
+            dyn = npt_dynamics(atoms, calc, dt, T, bulk_modulus, stress, mask, iso, tdamp, pdamp, ml_filter)
+            for step, energy, temperature, wall in dyn.run(steps):
+                if out is not None and loginterval and step % loginterval == 0:
+                    out.writelines(format_extxyz(Frame(numbers, atoms.positions, atoms.cell, atoms.pbc, energy, None, None)))
+            continue
         for step, energy, temperature, updated, wall in calc.run_md(atoms, steps, T, dt_fs=dt, friction=friction, rng=None,
                                                                     seed=int(rng.integers(1, 2 ** 62)), sync_every=loginterval or None,
                                                                     tdamp_fs=tdamp_fs):

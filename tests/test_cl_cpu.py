@@ -70,12 +70,10 @@ def test_md_driver_on_the_cpu_engine(tmp_path, monkeypatch):
     assert frames == 2 * 3      # steps 0, 2, 4 of each temperature
     assert read_structure("md.xyz").natoms == len(numbers)
     # the reference's default dynamics: 'NPT' without a bulk modulus = Nose-Hoover NVT (cl/md.py:17, :131-166) — on this
-    # engine through the host loop (workloads.nose_hoover_nvt); with a bulk modulus the cell moves: ASE's NPT, said so
+    # engine through the host loop (workloads.nose_hoover_nvt); with a bulk modulus the cell moves: tests/test_npt_cpu.py
     step0 = calc.step
     md(atoms, calc=calc, picos=-4, tem=300.0, tdamp=25, trajectory=None, seed=3)
     assert calc.step >= step0 + 5
-    with pytest.raises(NotImplementedError, match="bulk modulus"):
-        md(atoms, calc=calc, dynamics="NPT", bulk_modulus=30.0, picos=-1)
     # atoms that carry ASE constraints are not for this loop (neither integrator knows them): said so, not ignored
     atoms.constraints = [object()]
     with pytest.raises(NotImplementedError, match="constraints"):
