@@ -623,3 +623,40 @@ def test_one_off_entry_points_give_their_device_memory_back():
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < (4 << 20)
     mdl.close()
+
+
+def test_npt_with_a_moving_cell_around_the_device_calculator():
+    """cl/md.py:131-166 with a bulk modulus: the barostat's integrator (autoforce_amd/npt.py, ASE's NPT restated) around the
+    device predict path — forces AND stress of every step feed the next cell.  The cell changes every step; the candidate
+    lists are kept while the strain since their build allows it (neighbor.hip's affine rule): against a handle that rebuilds
+    its lists at every step the trajectory — positions, cell, strain rate — is the same bits, with a handful of rebuilds
+    instead of one per step; the extended system's conserved quantity holds."""
+    from autoforce_amd import _lib
+    from autoforce_amd.ase_shim import Atoms, kB
+    from autoforce_amd.npt import GPA, NPT
+    from autoforce_amd.workloads import FS, MASS
+    steps = 60
+    out = {}
+    for skin0 in (False, True):
+        mdl, (numbers, pos, cell, pbc) = _model()
+        if skin0:
+            _lib.check(_lib.load().sgpr_set_option(mdl.handle, b"skin_milliangstrom", 0))
+        mass = np.array([MASS[int(z)] for z in numbers])
+        cell0 = cell.copy()
+        rng = np.random.default_rng(3)
+        v = rng.normal(size=pos.shape) * np.sqrt(kB * 600.0 / mass)[:, None]
+        at = Atoms(numbers, pos, cell, pbc, velocities=v, masses=mass)
+        at.calc = _PredictCalc(mdl)
+        dyn = NPT(at, 1.0 * FS, 600.0, externalstress=1.0 * GPA, ttime=25.0 * FS, pfactor=(100.0 * FS) ** 2 * 30.0 * GPA)
+        r0 = mdl.list_rebuilds()
+        G = [dyn.get_gibbs_free_energy() for _ in dyn.run(steps)]
+        out[skin0] = (at.positions.copy(), np.asarray(at.cell).copy(), dyn.eta.copy(), dyn.zeta, mdl.list_rebuilds() - r0, np.array(G),
+                      at.calc.calls)
+        mdl.close()
+    fast, slow = out[False], out[True]
+    for a, b in zip(fast[:4], slow[:4]):
+        np.testing.assert_array_equal(a, b)
+    assert slow[4] >= steps and fast[4] <= steps // 4, (fast[4], slow[4])
+    assert fast[6] == steps + 1                                  # one evaluation per configuration
+    assert np.abs(fast[1] - cell0).max() > 1e-4                  # the cell has moved
+    assert np.ptp(fast[5]) < 0.05 * max(abs(fast[5][0]), 1.0)
