@@ -395,6 +395,7 @@ struct sgpr_model {
     int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
     int gemm_waves_k = 8;                // waves per K_nm tile (SGPR_GEMM_WAVES=4: the four-wave form)
     bool gemm_k64 = false, gemm_w64 = false;  // 64 x 64 tiles on eight waves for K_nm / for W + covloss: by size
+    int gemm_wgs64 = 3;                       // workgroups per CU of those tiles: 2 (six register stage sets) or 3 (three sets); SGPR_GEMM_WGS64
     bool gemm_64_forced = false;              //   (decide_tile_heights) unless SGPR_GEMM_64="k,w" says so
     int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
     bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
@@ -1260,7 +1261,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (!out || !species_z || S < 1 || S > SGPR_MAX_S) return fail(SGPR_E_INVALID, "sgpr_create: bad species table (S=%d)", S);
     if (!(rc > 0.0) || !(eta > 0.0)) return fail(SGPR_E_INVALID, "sgpr_create: rc and eta must be positive");
     const bool in234 = lmax >= 2 && lmax <= 4 && nmax >= 2 && nmax <= 4;
-    const bool ok = (lmax == 3 && nmax == 3) || (lmax == 2 && nmax == 2) || (in234 && S <= 4);
+    const bool ok = in234;   // every (lmax, nmax) of {2,3,4}^2 with up to SGPR_MAX_S species slots (descriptor.hip::DISPATCH_LNS)
     if (!ok) return fail(SGPR_E_UNSUPPORTED, "sgpr_create: (lmax,nmax,S)=(%d,%d,%d) is not compiled in", lmax, nmax, S);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1302,6 +1303,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (const char *e = getenv("SGPR_ZERO_COPY")) h->zero_copy_out = atoi(e) != 0;
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
+    if (const char *e = getenv("SGPR_GEMM_WGS64")) h->gemm_wgs64 = atoi(e) == 3 ? 3 : 2;
     if (const char *e = getenv("SGPR_GEMM_64")) {
         int k = 0, w = 0;
         if (sscanf(e, "%d,%d", &k, &w) == 2) { h->gemm_k64 = k != 0; h->gemm_w64 = w != 0; h->gemm_64_forced = true; }
@@ -1522,14 +1524,20 @@ static size_t count_tiles(const sgpr_model *h, int kind, int bm)
 // Tile heights of the three products of a step.  32 x 64 tiles fill the chip at a few thousand atoms (416 K_nm tiles on
 // 256 CUs at 4096 / 512); once a CU holds several of them, 64 x 64 tiles on eight waves move two thirds of the bytes
 // for the same flops and win: K_nm -5 % at 8000 / 512, -7 % at 15625 / 512, -10 % at 32768 / 1024 (+1..4 % at
-// 4096 / 512: fewer tiles than CUs), W + covloss -5.5 % at 32768 / 1024, -1.5 % at 15625 / 1024, +3 % at 4096 / 512.
-// SGPR_GEMM_64="k,w" (0 / 1 each) overrides.
+// 4096 / 512: fewer tiles than CUs).  Round 6: those tiles on THREE register stage sets, three workgroups per CU
+// (gemm_tile_body8r64<EPI, 3>: a tile's 9k cycles without an MFMA — entry, first arrival, epilogue — are covered by two
+// other tiles instead of one): K_nm -4 % and W + covloss -4.5 % at 16384 / 1024, -8 % at 32768 / 512; and with three
+// workgroups per CU the 64-row form wins for W + covloss from ~1400 32-row tiles on (it took 6144): -10 % at 4096 / 1024,
+// -12 % at 8000 / 512 and 10648 / 512, -7 % at 10648 / 1024, -11 % at 15625 / 1024, -3 % at 5832 / 512; 4096 / 512
+// (1056 tiles) stays on the 32-row form (21.3 against 21.7 us).  Measured and not kept: 128 x 64 tiles (four blocks per
+// wave, 72 KB of LDS, two workgroups per CU): within +-3 % of the three-workgroup 64-row form at every size (tools/ab_sizes.sh).
+// SGPR_GEMM_64="k,w" (0 / 1 each) and SGPR_GEMM_WGS64=2 override.
 static void decide_tile_heights(sgpr_model *h)
 {
     if (h->gemm_64_forced) return;
     const size_t ncu = (size_t)h->cus_per_xcd * 8;
     h->gemm_k64 = count_tiles(h, 0, 32) >= 3 * ncu;
-    h->gemm_w64 = count_tiles(h, 1, 32) + count_tiles(h, 2, 32) >= 24 * ncu;
+    h->gemm_w64 = 2 * (count_tiles(h, 1, 32) + count_tiles(h, 2, 32)) >= 11 * ncu;
 }
 
 // The fused table: the K_nm tiles in their own order (so that their energy partials keep their slots), tagged kind 2,
@@ -1646,7 +1654,7 @@ static int build_tiles(sgpr_model *h, int kind)
         std::vector<std::vector<int4>> extra(8);
         for (int x = 0; x < 8; x++) {
             auto &b = bk[x];
-            balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? 2 : 4, nullptr, chain);
+            balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? h->gemm_wgs64 : 4, nullptr, chain);
             const size_t ncu_x = (size_t)h->cus_per_xcd, cap = 4 * ncu_x;
             if (!chain || b.size() <= cap || b.size() - cap > ncu_x) continue;
             std::vector<long long> load(ncu_x, 0);
@@ -1674,7 +1682,7 @@ static int build_tiles(sgpr_model *h, int kind)
             std::vector<std::vector<int4>> bc(8);
             for (const int4 &t : h->h_t_cov)
                 if (t.w > t.z) bc[t.x % 8].push_back(t);
-            for (auto &b : bc) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? 2 : 4);
+            for (auto &b : bc) balance_xcd_share(b, h->tile_balance ? h->cus_per_xcd : 1, h->gemm_w64 ? h->gemm_wgs64 : 4);
             size_t dc = 0;
             for (auto &b : bc) dc = std::max(dc, b.size());
             std::vector<int4> only(dc * 8, make_int4(0, 0, 0, 0));
@@ -1735,6 +1743,7 @@ static GemmParams knm_params(sgpr_model *h, const double *A, int M, const int *r
     g.bm = (&tiles == &h->t_kmm) ? 64 : h->gemm_bm_k;
     g.kd = h->gemm_kd_k;
     g.waves = &tiles != &h->t_knm ? 4 : h->gemm_k64 ? 8 : (h->gemm_bm_k == 32 && h->gemm_kd_k == 16) ? h->gemm_waves_k : 4;
+    g.wgs = h->gemm_wgs64;
     g.eta = h->eta; g.lone_m1 = h->lone_w - 1.0; g.mu = mu; g.row_nn = row_nn; g.col_nn = h->d_ind_nn.p; g.Aw = Aw; g.Esum = Epart;
     g.row_slot = row_slot; g.col_slot = h->d_ind_slot.p;
     g.stamps = h->d_stamps.p ? h->d_stamps.p : nullptr;
@@ -2363,6 +2372,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     gw.A = h->d_Aw.p; gw.B = h->d_PmT.p; gw.C = h->d_W.p;
     gw.tiles = h->t_w.p; gw.ntiles = (int)h->t_w.n; gw.bm = h->gemm_bm_w; gw.kd = h->gemm_kd_w;
     gw.waves = gc.waves = (h->gemm_w64 && h->gemm_bm_w == 64) ? 8 : 4;
+    gw.wgs = gc.wgs = h->gemm_wgs64;
     gc.M = cnt; gc.N = h->m; gc.K = h->m_pad;
     gc.lda = h->m_pad; gc.ldb = h->m_pad; gc.ldc = 0;
     gc.A = h->d_K.p; gc.B = h->d_choli.p; gc.C = nullptr;

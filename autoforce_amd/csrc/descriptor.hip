@@ -1675,9 +1675,10 @@ static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ?
         if (p.lmax == 4 && p.nmax == 4) {                                                  \
             if (stv <= 2) return FN(4, 4, 2, __VA_ARGS__);                                  \
             if (stv <= 4) return FN(4, 4, 4, __VA_ARGS__);                                  \
+            return FN(4, 4, 8, __VA_ARGS__);                                                \
         }                                                                                  \
         /* the other (lmax, nmax) pairs of {2,3,4}^2 (similarity/sesoap.py:10-24 takes any): */ \
-        /* one instantiation each, four species slots                                      */ \
+        /* two instantiations each, four and eight species slots                           */ \
         if (stv <= 4) {                                                                    \
             if (p.lmax == 2 && p.nmax == 3) return FN(2, 3, 4, __VA_ARGS__);                \
             if (p.lmax == 2 && p.nmax == 4) return FN(2, 4, 4, __VA_ARGS__);                \
@@ -1685,6 +1686,13 @@ static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ?
             if (p.lmax == 3 && p.nmax == 4) return FN(3, 4, 4, __VA_ARGS__);                \
             if (p.lmax == 4 && p.nmax == 2) return FN(4, 2, 4, __VA_ARGS__);                \
             if (p.lmax == 4 && p.nmax == 3) return FN(4, 3, 4, __VA_ARGS__);                \
+        } else {                                                                           \
+            if (p.lmax == 2 && p.nmax == 3) return FN(2, 3, 8, __VA_ARGS__);                \
+            if (p.lmax == 2 && p.nmax == 4) return FN(2, 4, 8, __VA_ARGS__);                \
+            if (p.lmax == 3 && p.nmax == 2) return FN(3, 2, 8, __VA_ARGS__);                \
+            if (p.lmax == 3 && p.nmax == 4) return FN(3, 4, 8, __VA_ARGS__);                \
+            if (p.lmax == 4 && p.nmax == 2) return FN(4, 2, 8, __VA_ARGS__);                \
+            if (p.lmax == 4 && p.nmax == 3) return FN(4, 3, 8, __VA_ARGS__);                \
         }                                                                                  \
         return -6;                                                                         \
     } while (0)

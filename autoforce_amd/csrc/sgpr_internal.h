@@ -203,6 +203,7 @@ struct GemmParams {
     int ntiles;
     int bm;               // rows per tile of the table: 64 (default when 0) or 32
     int kd;               // 32-row tiles: depth of an LDS stage, 32 (default when 0) or 16 (four workgroups per CU)
+    int wgs;              // 64-row eight-wave tiles: 3 = the three-register-set form, three workgroups per CU (default two)
     int waves;            // 32-row tiles with 16-deep stages: 8 = the eight-wave form (EPI_KERNEL / EPI_STORE: one 16 x 16
                           //   block per wave, two waves per SIMD per tile; energy partials: 8 per tile), else four waves
     int tri;              // unused by the kernel (the tile table carries the trimmed k range)

@@ -83,6 +83,31 @@ def test_five_species_uses_the_8_slot_kernels():
     mdl.close()
 
 
+@pytest.mark.parametrize("lmax,nmax,nspec", [(4, 4, 6), (2, 3, 5), (3, 4, 8), (4, 2, 7), (2, 2, 8), (3, 2, 5), (2, 4, 6), (4, 3, 5)])
+def test_more_than_four_species_for_every_lmax_nmax(lmax, nmax, nspec):
+    """The reference's kernels take any species (its table is 120 wide, descriptor/sesoap.py:134) and any (lmax, nmax)
+    (similarity/sesoap.py:10-24).  Here every pair of {2,3,4}^2 is compiled for up to eight species slots: frames with five to
+    eight species against the oracle, K_mm included, and the training rows (the one-column-per-wave form: the sixteen-column
+    kernel is compiled for up to four slots)."""
+    rng = np.random.default_rng(100 * lmax + 10 * nmax + nspec)
+    species = [1, 6, 7, 8, 16, 3, 9, 15][:nspec]
+    numbers, pos, cell = random_frame(rng, 112, 10.0, species)
+    mdl, nl = build(lmax, nmax, 4.0, 5.0, species, numbers, pos, cell, [True] * 3, 24, 2)
+    compare(mdl, lmax, nmax, 4.0, 5.0, numbers, pos, cell, [True] * 3, nl)
+    from oracle import oracle as orc
+    X = mdl.X
+    ind_z = np.array([x.number for x in X], np.int32)
+    ind_ptr = np.concatenate([[0], np.cumsum([len(x._b) for x in X])])
+    Pm, nnm = orc.inducing_descriptors(lmax, nmax, 5.0, np.array(species, np.int32), ind_z, ind_ptr,
+                                       np.concatenate([x._b for x in X]), np.concatenate([x._r for x in X]))
+    Ke, Kf, Kv = mdl.kernel_rows(numbers, pos, cell, [True] * 3)
+    ref = orc.kernel_rows(lmax, nmax, 5.0, 4.0, np.array(species, np.int32), numbers, pos, cell, nl, ind_z, nnm, Pm)
+    np.testing.assert_allclose(Ke, ref[0], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Kf, ref[1], rtol=0, atol=1e-8 * np.abs(ref[1]).max())
+    np.testing.assert_allclose(Kv, ref[2], rtol=0, atol=1e-8 * np.abs(ref[2]).max())
+    mdl.close()
+
+
 def test_non_integer_exponent_and_custom_radii():
     """eta = 2.5 takes the pow() branch of the kernel epilogue (integer exponents use repeated
     multiplication); radii other than the defaults exercise the per-species length unit
@@ -207,25 +232,27 @@ def test_candidate_lists_are_reused_without_changing_anything(name):
     fast.close(); slow.close()
 
 
-@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4", "r64"])
+@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4", "r64", "r64x3"])
 def test_gemm_tile_shapes_agree_bit_for_bit(shape, monkeypatch):
     """The three products of a step (K_nm, W, covloss) run on 32x64 tiles with 16-deep LDS stages; the 64-row form and the
     32-deep stages stay compiled in for K_mm, dense launches and the forked path.  Every form accumulates a dot product
     over k in the same order (one MFMA k-step of 4 after the other), so K_nm, forces, stress and beta must not move
     by a single bit when the tile tables are built for another shape (diagnostic overrides SGPR_GEMM_BM / SGPR_GEMM_KD),
     nor when a K_nm tile is shared by four waves (two 16 x 16 blocks each) instead of eight (SGPR_GEMM_WAVES), nor on the
-    64 x 64 eight-wave tiles that large frames take ("r64": SGPR_GEMM_64 forces them here)."""
+    64 x 64 eight-wave tiles that large frames take ("r64": SGPR_GEMM_64 forces them here; "r64x3": on three register stage
+    sets, three workgroups per CU)."""
     rng = np.random.default_rng(31)
     species = [3, 15, 16]
     numbers, pos, cell = random_frame(rng, 300, 16.0, species)
     pbc = [True] * 3
     outs = []
-    for bm, kd, waves in ((None, None, None), shape.split(";") if shape != "r64" else ("r64", "", "")):
+    for bm, kd, waves in ((None, None, None), shape.split(";") if not shape.startswith("r") else (shape, "", "")):
         if bm is None:
-            for k in ("SGPR_GEMM_BM", "SGPR_GEMM_KD", "SGPR_GEMM_WAVES", "SGPR_GEMM_64"):
+            for k in ("SGPR_GEMM_BM", "SGPR_GEMM_KD", "SGPR_GEMM_WAVES", "SGPR_GEMM_64", "SGPR_GEMM_WGS64"):
                 monkeypatch.delenv(k, raising=False)
-        elif bm == "r64":
+        elif bm.startswith("r"):
             monkeypatch.setenv("SGPR_GEMM_64", "1,1")
+            monkeypatch.setenv("SGPR_GEMM_WGS64", "3" if bm == "r64x3" else "2")   # (three register sets, three workgroups per CU)
         else:
             monkeypatch.setenv("SGPR_GEMM_BM", bm)
             monkeypatch.setenv("SGPR_GEMM_KD", kd)
