@@ -1261,7 +1261,10 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (!out || !species_z || S < 1 || S > SGPR_MAX_S) return fail(SGPR_E_INVALID, "sgpr_create: bad species table (S=%d)", S);
     if (!(rc > 0.0) || !(eta > 0.0)) return fail(SGPR_E_INVALID, "sgpr_create: rc and eta must be positive");
     const bool in234 = lmax >= 2 && lmax <= 4 && nmax >= 2 && nmax <= 4;
-    const bool ok = in234;   // every (lmax, nmax) of {2,3,4}^2 with up to SGPR_MAX_S species slots (descriptor.hip::DISPATCH_LNS)
+    // every (lmax, nmax) of {2,3,4}^2 with up to SGPR_MAX_S = 8 species slots (descriptor.hip::DISPATCH_LNS).  (Sixteen slots were
+    // tried for lmax = nmax = 3: the kernels compile, but the reverse kernel keeps dE/dc and a W row per wave in LDS — 75 KB per
+    // wave at rows of 8320 doubles, four waves per workgroup: no launch.)
+    const bool ok = in234;
     if (!ok) return fail(SGPR_E_UNSUPPORTED, "sgpr_create: (lmax,nmax,S)=(%d,%d,%d) is not compiled in", lmax, nmax, S);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const doub
     // R COLUMN-major: element (i, c) at A[c * ld + i] — the factored matrix itself (its transposed storage), no gathered copy:
     // a thread's row i of the 32-column block is 32 loads that are contiguous ACROSS the threads (the row-major copy made
     // every one of them a cache line of its own: 17 us per block of 32 at m = 1024, 0.54 ms per solve)
-    __shared__ double zs[2048];
+    extern __shared__ double zs[];   // [cols] (dynamic: cols <= QR_MAX_COLS)
     __shared__ double xb[32];
     A += blockIdx.x * bs_mat; y += blockIdx.x * bs_mat; x += (size_t)blockIdx.x * cols;  // (a batch: one workgroup per problem)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -702,6 +702,18 @@ __global__ __launch_bounds__(1024) void qr_backsolve_kernel(int cols, const doub
         }
         if (tid < nbk) x[b0 + tid] = xb[tid];
         __syncthreads();
+    }
+}
+
+// The only thing in the least squares that is sized by the number of columns is the right-hand side the back substitution
+// keeps in LDS: 8192 columns are 64 KB (the reference has no limit on the inducing set; m <= 2048 was this array's size).
+#define QR_MAX_COLS 8192
+static void backsolve_attr()
+{
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void *)qr_backsolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * QR_MAX_COLS));
+        done = true;
     }
 }
 
@@ -915,7 +927,7 @@ static bool band_qr_on()
 int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, double *work, hipStream_t st, int band,
                             double *keep, std::vector<TsqrPanel> *panels, int extra, int band_off)
 {
-    if (cols > 2048 || rows < cols || ldr < rows) return -1;
+    if (cols > QR_MAX_COLS || rows < cols || ldr < rows) return -1;
     // banded problems whose panels fit one workgroup's registers: one launch per panel (bandqr.inc)
     if (band > 0 && !keep && !panels && band_qr_on() &&
         launch_band_qr(rows, cols, At, ldr, x, work, st, band, band_off, extra, 1, 0, 0) == 0)
@@ -963,7 +975,8 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
     if (res && npanel > 0) (void)hipStreamWaitEvent(st, res->far[(npanel - 1) & 1], 0);   // the caller's stream sees the whole result
     if (x) {
         (void)Rc; (void)z;
-        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), 0, st, cols, At, ldr, At + (size_t)cols * ldr, x);
+        backsolve_attr();
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(1), dim3(1024), sizeof(double) * cols, st, cols, At, ldr, At + (size_t)cols * ldr, x);
     }
     return 0;
 }
@@ -975,7 +988,7 @@ int launch_lstsq_qr_blocked(int rows, int cols, double *At, int ldr, double *x, 
 int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_mat, double *x, double *work, int batch,
                             hipStream_t st, int band)
 {
-    if (cols > 2048 || rows < cols || ldr < rows || batch < 1) return -1;
+    if (cols > QR_MAX_COLS || rows < cols || ldr < rows || batch < 1) return -1;
     tsqr_attrs();
     const size_t bs_work = lstsq_qr_blocked_work_doubles(rows, cols);
     if (band > 0 && band_qr_on() && launch_band_qr(rows, cols, At, ldr, x, work, st, band, 0, 0, batch, bs_mat, bs_work) == 0)
@@ -997,7 +1010,8 @@ int launch_lstsq_qr_batched(int rows, int cols, double *At, int ldr, size_t bs_m
         // the back substitutions side by side, one workgroup per problem, straight from the factored matrices (one after
         // the other they were two thirds of a sixteen-problem scan: 16 x 0.4 ms behind 3 ms of shared factorisation launches)
         (void)scratch;
-        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(batch), dim3(1024), 0, st, cols, At, ldr, At + (size_t)cols * ldr, x, bs_mat);
+        backsolve_attr();
+        hipLaunchKernelGGL(qr_backsolve_kernel, dim3(batch), dim3(1024), sizeof(double) * cols, st, cols, At, ldr, At + (size_t)cols * ldr, x, bs_mat);
     }
     return 0;
 }

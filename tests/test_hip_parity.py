@@ -182,6 +182,41 @@ def test_solve_against_oracle():
     mdl.close()
 
 
+def test_solve_beyond_2048_inducing_points():
+    """The reference puts no bound on the inducing set (regression/gppotential.py:1204-1339 is dense linear algebra on whatever
+    m is); the device least squares was bounded by an LDS array of the back substitution (m <= 2048).  m = 2304 real LCEs:
+    K_mm factor, choli, sigma and the weights against a numpy restatement of the same stacked least-squares problem (the C
+    oracle needs minutes at this size; it pins the formula at small m in the test above)."""
+    from autoforce_amd import SGPRModel
+    from autoforce_amd.workloads import inducing_from_frame, lips
+    numbers, pos, cell, pbc = lips(14, seed=0)
+    mdl = SGPRModel(3, 3, 4, 6.0, species=sorted(set(int(z) for z in numbers)))
+    n2, p2, c2, b2 = lips(14, seed=1)
+    m = 2304
+    mdl.set_inducing(inducing_from_frame(mdl, n2, p2, c2, b2, m, seed=1))
+    assert mdl.m == m
+    rng = np.random.default_rng(7)
+    rows = 2500
+    K = rng.normal(size=(rows, m))
+    Y = rng.normal(size=rows)
+    mu = mdl.solve(K, Y, noise=0.01)
+    M = mdl.M
+    sigma = 0.01 * 0.99 * np.mean(np.diag(M))          # gppotential.py:1219-1222, :1245-1247 at the start noise
+    assert abs(mdl.sigma - sigma) <= 1e-12 * sigma
+    L = np.linalg.cholesky(M + mdl.ridge * np.eye(m))
+    np.testing.assert_allclose(mdl.choli @ L, np.eye(m), rtol=0, atol=1e-7)
+    A = np.vstack([K, sigma * L.T])
+    b = np.concatenate([Y, np.zeros(m)])
+    Q, R = np.linalg.qr(A)
+    ref = np.linalg.solve(R, Q.T @ b)
+    np.testing.assert_allclose(mu, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    # ... and the weights predict: one frame through the model with them
+    mdl.set_weights(mu, choli=mdl.choli)
+    out = mdl.predict(numbers[:512], pos[:512], cell, pbc, cov=True)
+    assert np.isfinite(out["energy"]) and np.allclose(out["cov"] @ mu + 0.0, out["cov"] @ ref, atol=1e-6)
+    mdl.close()
+
+
 def test_solve_jitter_ladder_and_failure():
     """Duplicate inducing LCEs make K_mm singular: the ladder must kick in with the reference's
     first rung (1e-6 * mean diag) or a later one, and agree with the oracle's rung."""

@@ -90,7 +90,7 @@ def test_more_than_four_species_for_every_lmax_nmax(lmax, nmax, nspec):
     eight species against the oracle, K_mm included, and the training rows (the one-column-per-wave form: the sixteen-column
     kernel is compiled for up to four slots)."""
     rng = np.random.default_rng(100 * lmax + 10 * nmax + nspec)
-    species = [1, 6, 7, 8, 16, 3, 9, 15][:nspec]
+    species = [1, 6, 7, 8, 16, 3, 9, 15, 11, 12, 13, 14, 17, 19, 20, 29][:nspec]
     numbers, pos, cell = random_frame(rng, 112, 10.0, species)
     mdl, nl = build(lmax, nmax, 4.0, 5.0, species, numbers, pos, cell, [True] * 3, 24, 2)
     compare(mdl, lmax, nmax, 4.0, 5.0, numbers, pos, cell, [True] * 3, nl)
