@@ -453,11 +453,8 @@ class ActiveCalculator(Calculator):
         else:
             covloss_max = float(np.max(self.get_covloss())) if len(self.atoms) else 0.0
             self.covlog = f"{covloss_max}"
-            if HAVE_ASE and self.rank == 0 and covloss_max > self.ediff:  # pragma: no cover  (ediff last: a Switch asks for max |F|)
-                import ase.io
-                tmp = self.atoms.copy()
-                tmp.calc = None
-                ase.io.Trajectory("active_uncertain.traj", "a").write(tmp)
+            if self.rank == 0 and covloss_max > self.ediff:   # (ediff last: a Switch asks for max |F|)
+                self._side_file("active_uncertain", self.atoms, None, "a")
         timings.append(time.time())
         self.post_calculate(timings)
 
@@ -713,10 +710,32 @@ class ActiveCalculator(Calculator):
         if self.tape:
             self._saved_for_tape = self.model.data[-1]
 
+    def _side_file(self, stem, atoms, results, mode):
+        """The trajectory side files of the reference (active.py:495-499 `active_uncertain.traj`, :684-696 `active_FP.traj` /
+        `active_ML.traj`): ase.io.Trajectory when ASE is installed; without it the same frames as extended XYZ (`<stem>.xyz`,
+        ASE's own text format: `ase.io.read` takes it), results as energy / forces / stress of the frame."""
+        if HAVE_ASE:  # pragma: no cover
+            import ase.io
+            tmp = atoms.copy()
+            tmp.calc = None if results is None else SinglePointCalculator(tmp, **results)
+            ase.io.Trajectory(stem + ".traj", mode).write(tmp)
+            return
+        from .sgprio import Frame as XyzFrame, format_extxyz
+        r = results or {}
+        e = r.get("energy")
+        fr = XyzFrame(np.asarray(atoms.numbers), np.asarray(atoms.positions, float), np.asarray(getattr(atoms.cell, "array", atoms.cell), float),
+                      np.asarray(atoms.pbc, bool), None if e is None else float(e), r.get("forces"), r.get("stress"))
+        with open(stem + ".xyz", mode) as f:
+            f.writelines(format_extxyz(fr))
+
     def _test(self):
-        """active.py:678-704 (the trajectory files need ASE; the log line does not)."""
+        """active.py:678-704."""
         energy, forces, stress = self._exact(self.atoms)
         self._ktest += 1
+        if self.rank == 0:
+            mode = "a" if self._ktest > 1 else "w"
+            self._side_file("active_FP", self.atoms, dict(energy=energy, forces=forces, stress=stress), mode)
+            self._side_file("active_ML", self.atoms, {q: self.results[q] for q in ("energy", "forces", "stress")}, mode)
         self.log("testing energy: {}".format(energy))
         dE = self.results["energy"] - energy
         df = np.abs(self.results["forces"] - forces)

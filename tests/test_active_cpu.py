@@ -506,3 +506,28 @@ def test_bcm_one_member_per_rank_world2_gloo(tmp_path):
         assert set(w) == set(ref.bcm_weights) and all(abs(w[k] - ref.bcm_weights[k]) < 1e-12 for k in w)
         # members a, c (indices 0, 2) on rank 0, member b on rank 1: nobody evaluates somebody else's member
         assert [c > 0 for c in calls] == ([True, False, True] if rank == 0 else [False, True, False]), (rank, calls)
+
+
+def test_side_files_of_an_uncertain_frame_and_of_the_test_keyword(tmp_path, monkeypatch):
+    """active.py:495-499: a prediction-only calculator whose largest covloss exceeds ediff appends the frame to
+    `active_uncertain`; active.py:678-704 (`test = n`): every n steps an active calculator writes the frame with the teacher's
+    results to `active_FP` and with the model's to `active_ML` (ase.io.Trajectory with ASE; extended XYZ here) and logs the errors."""
+    from autoforce_amd.cl.md import read_frames
+    monkeypatch.chdir(tmp_path)
+    calc, teacher, trace = ac.run(OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), tmp_path, steps=6, tape=False, test=2)
+    fp, ml = read_frames("active_FP.xyz", ":"), read_frames("active_ML.xyz", ":")
+    assert len(fp) == len(ml) >= 1
+    log = open(tmp_path / "active.log").read()
+    assert log.count("errors (test):") == len(fp) and "testing energy:" in log
+    np.testing.assert_array_equal(fp[-1].positions, ml[-1].positions)
+    assert fp[-1].forces is not None and ml[-1].forces is not None and fp[-1].energy != ml[-1].energy
+    # the same model without a teacher: every frame whose covloss is above the threshold goes to active_uncertain
+    passive = ActiveCalculator(covariance=calc.model, calculator=None, logfile=str(tmp_path / "passive.log"), ediff=1e-6)
+    rng = np.random.default_rng(3)
+    at = trace[-1][5]
+    for k in range(3):
+        at2 = Atoms(at.numbers, at.positions + 0.2 * rng.normal(size=at.positions.shape), at.cell, True)
+        at2.calc = passive
+        at2.get_potential_energy()
+    unc = read_frames("active_uncertain.xyz", ":")
+    assert len(unc) == 3 and unc[0].natoms == len(at.numbers) and unc[0].energy is None
