@@ -395,7 +395,8 @@ struct sgpr_model {
     int gemm_kd_k = 16, gemm_kd_w = 16;  // stage depth of the 32-row form (SGPR_GEMM_KD="k,w" overrides)
     int gemm_waves_k = 8;                // waves per K_nm tile (SGPR_GEMM_WAVES=4: the four-wave form)
     bool gemm_k64 = false, gemm_w64 = false;  // 64 x 64 tiles on eight waves for K_nm / for W + covloss: by size
-    int gemm_wgs64 = 3;                       // workgroups per CU of those tiles: 2 (six register stage sets) or 3 (three sets); SGPR_GEMM_WGS64
+    int gemm_wgs64 = 3;
+    bool gemm_half = true;                    // 16-row half tiles for launches of fewer 32-row tiles than CUs (build_tiles)                       // workgroups per CU of those tiles: 2 (six register stage sets) or 3 (three sets); SGPR_GEMM_WGS64
     bool gemm_64_forced = false;              //   (decide_tile_heights) unless SGPR_GEMM_64="k,w" says so
     int cus_per_xcd = 32;                // CUs behind one XCD's dispatcher (multiProcessorCount / 8)
     bool tile_balance = true;            // SGPR_TILE_BALANCE=0: plain longest-first tile tables
@@ -1307,6 +1308,7 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (const char *e = getenv("SGPR_COV_IN_REV")) h->cov_in_rev = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_WAVES")) h->gemm_waves_k = atoi(e) == 8 ? 8 : 4;
     if (const char *e = getenv("SGPR_GEMM_WGS64")) h->gemm_wgs64 = atoi(e) == 3 ? 3 : 2;
+    if (const char *e = getenv("SGPR_GEMM_HALF")) h->gemm_half = atoi(e) != 0;
     if (const char *e = getenv("SGPR_GEMM_64")) {
         int k = 0, w = 0;
         if (sscanf(e, "%d,%d", &k, &w) == 2) { h->gemm_k64 = k != 0; h->gemm_w64 = w != 0; h->gemm_64_forced = true; }
@@ -1592,6 +1594,16 @@ static int build_tiles(sgpr_model *h, int kind)
     }
     if (kind == 0 && h->gemm_k64) bm = 64;
     if ((kind == 1 || kind == 2) && h->gemm_w64) bm = 64;
+    // Fewer 32-row tiles than HALF the CUs (a rank's share of a sharded frame, frames of a few hundred atoms): a tile alone on its CU
+    // runs at the pace of its own chain of dependent MFMAs, and half tiles — 16 x 64 on four waves, one per SIMD, twice as many
+    // CUs — halve that chain (gemm_tile_body8<EPI, true>; same sums, same bits).  SGPR_GEMM_HALF=0 keeps the 32-row tiles.
+    if (kind != 3 && bm == 32 && h->gemm_half && !getenv("SGPR_GEMM_BM")) {
+        const size_t ncu = (size_t)h->cus_per_xcd * 8;
+        const size_t n32 = kind == 0 ? count_tiles(h, 0, 32) : count_tiles(h, 1, 32) + count_tiles(h, 2, 32);
+        // (while nearly every half tile finds a CU of its own — 132 W + covloss tiles of rank 0's share at world 8: 12.7 -> 10.7 us,
+        // 104 K_nm tiles at world 4: 14.0 -> 12.1; at 208 tiles, world 2, two half tiles per CU are a whole tile again: 14.6 -> 15.8)
+        if (5 * n32 <= 3 * ncu) bm = 16;
+    }
     if (kind == 0) h->gemm_bm_k = bm;
     if (kind == 1 || kind == 2) h->gemm_bm_w = bm;
     const int nrt = (nrows + bm - 1) / bm, nct = (ncols + 63) / 64;

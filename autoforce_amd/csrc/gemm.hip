@@ -57,6 +57,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel8(GemmArgs g)
     gemm_tile_body8<EPI>(g, (int)blockIdx.x, As, Bs);
 }
 
+// the half tile: 16 x 64 on four waves, one per SIMD (gemm_tile_body8<EPI, true>)
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel4h(GemmArgs g)
+{
+    using L = GemmLds<EPI, 1, 16>;
+    __shared__ double As[L::NBUF * L::ASZ];
+    __shared__ double Bs[L::NBUF * L::BSZ];
+    gemm_tile_body8<EPI, true>(g, (int)blockIdx.x, As, Bs);
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel8r64(GemmArgs g)
 {
@@ -85,7 +95,8 @@ void launch_gemm_wcov(const GemmParams &pw, const GemmParams &pc, const int4 *ti
     g.p.ntiles = ntiles;
     g.ieta = -1;
     g.stamps = pw.stamps;
-    if (pw.bm == 64 && pw.waves == 8 && pw.wgs == 3) hipLaunchKernelGGL(gemm_nt_kernel8r64x3<EPI_WCOV>, dim3(ntiles), dim3(512), 0, st, g);
+    if (pw.bm == 16) hipLaunchKernelGGL(gemm_nt_kernel4h<EPI_WCOV>, dim3(ntiles), dim3(256), 0, st, g);
+    else if (pw.bm == 64 && pw.waves == 8 && pw.wgs == 3) hipLaunchKernelGGL(gemm_nt_kernel8r64x3<EPI_WCOV>, dim3(ntiles), dim3(512), 0, st, g);
     else if (pw.bm == 64 && pw.waves == 8) hipLaunchKernelGGL(gemm_nt_kernel8r64<EPI_WCOV>, dim3(ntiles), dim3(512), 0, st, g);
     else if (pw.bm == 32 && pw.kd == 16) hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 1, 16>), dim3(chained ? grid : ntiles), dim3(256), 0, st, g);
     else if (pw.bm == 32) hipLaunchKernelGGL((gemm_nt_kernel<EPI_WCOV, 1>), dim3(ntiles), dim3(256), 0, st, g);
@@ -123,6 +134,12 @@ void launch_gemm_nt(const GemmParams &p, GemmEpilogue epi, hipStream_t st)
     g.rows_pad = (g.row_tiles + 7) / 8 * 8;
     dim3 grid(p.tiles ? p.ntiles : g.rows_pad * g.col_tiles), block(256);
     if (p.tiles && p.ntiles <= 0) return;
+    if (p.bm == 16 && p.tiles && (epi == EPI_KERNEL || epi == EPI_STORE || epi == EPI_ROWSQ)) {
+        if (epi == EPI_KERNEL) hipLaunchKernelGGL(gemm_nt_kernel4h<EPI_KERNEL>, grid, dim3(256), 0, st, g);
+        else if (epi == EPI_STORE) hipLaunchKernelGGL(gemm_nt_kernel4h<EPI_STORE>, grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(gemm_nt_kernel4h<EPI_ROWSQ>, grid, dim3(256), 0, st, g);
+        return;
+    }
     if (p.waves == 8 && p.bm == 64 && p.wgs == 3 && p.tiles && (epi == EPI_KERNEL || epi == EPI_STORE || epi == EPI_ROWSQ)) {
         if (epi == EPI_KERNEL) hipLaunchKernelGGL(gemm_nt_kernel8r64x3<EPI_KERNEL>, grid, dim3(512), 0, st, g);
         else if (epi == EPI_STORE) hipLaunchKernelGGL(gemm_nt_kernel8r64x3<EPI_STORE>, grid, dim3(512), 0, st, g);

@@ -232,7 +232,7 @@ def test_candidate_lists_are_reused_without_changing_anything(name):
     fast.close(); slow.close()
 
 
-@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4", "r64", "r64x3"])
+@pytest.mark.parametrize("shape", ["64,64;32,32;8", "32,32;32,32;8", "32,32;16,16;4", "16,16;16,16;8", "r64", "r64x3"])
 def test_gemm_tile_shapes_agree_bit_for_bit(shape, monkeypatch):
     """The three products of a step (K_nm, W, covloss) run on 32x64 tiles with 16-deep LDS stages; the 64-row form and the
     32-deep stages stay compiled in for K_mm, dense launches and the forked path.  Every form accumulates a dot product
@@ -240,7 +240,8 @@ def test_gemm_tile_shapes_agree_bit_for_bit(shape, monkeypatch):
     by a single bit when the tile tables are built for another shape (diagnostic overrides SGPR_GEMM_BM / SGPR_GEMM_KD),
     nor when a K_nm tile is shared by four waves (two 16 x 16 blocks each) instead of eight (SGPR_GEMM_WAVES), nor on the
     64 x 64 eight-wave tiles that large frames take ("r64": SGPR_GEMM_64 forces them here; "r64x3": on three register stage
-    sets, three workgroups per CU)."""
+    sets, three workgroups per CU), nor on the 16 x 64 half tiles (one wave per SIMD) that launches of fewer tiles than CUs take —
+    this frame's default; the other shapes are forced against it."""
     rng = np.random.default_rng(31)
     species = [3, 15, 16]
     numbers, pos, cell = random_frame(rng, 300, 16.0, species)
@@ -331,7 +332,7 @@ def test_npt_walk_reuses_candidates_under_strain():
 
 
 @pytest.mark.parametrize("side,m", [(8, 48), (16, 512)])
-def test_fused_gemm_launch_equals_the_three_launches(side, m):
+def test_fused_gemm_launch_equals_the_three_launches(side, m, monkeypatch):
     """The K_nm, W and covloss products of a step go out as ONE launch whose W / covloss tiles wait, panel by panel, on
     the K_nm tiles ahead of them in the tile list (gemm_tile.inc, EPI_FUSED).  Against the same handle with the option off
     (K_nm launch, then the grouped W + covloss launch): forces, stress and covloss bit for bit on every frame of a walk —
@@ -341,6 +342,7 @@ def test_fused_gemm_launch_equals_the_three_launches(side, m):
     import torch
     from autoforce_amd import _lib
     from test_hip_md import _model
+    monkeypatch.setenv("SGPR_GEMM_HALF", "0")   # (the fused launch exists for the 32-row forms; a small frame would take half tiles)
     mdl, (numbers, pos, cell, pbc) = _model(side=side, m=m)
     lib, h, N = _lib.load(), mdl.handle, len(numbers)
     rng = np.random.default_rng(8)
