@@ -1602,7 +1602,9 @@ static int build_tiles(sgpr_model *h, int kind)
         const size_t n32 = kind == 0 ? count_tiles(h, 0, 32) : count_tiles(h, 1, 32) + count_tiles(h, 2, 32);
         // (while nearly every half tile finds a CU of its own — 132 W + covloss tiles of rank 0's share at world 8: 12.7 -> 10.7 us,
         // 104 K_nm tiles at world 4: 14.0 -> 12.1; at 208 tiles, world 2, two half tiles per CU are a whole tile again: 14.6 -> 15.8)
-        if (5 * n32 <= 3 * ncu) bm = 16;
+        // (K_nm: only while EVERY half tile is alone — at world 4 the 0.9 us its 104 tiles gain go back to the forward kernel,
+        // whose workgroup-to-atom mapping follows the tile height)
+        if (5 * n32 <= (kind == 0 ? 2 : 3) * ncu) bm = 16;
     }
     if (kind == 0) h->gemm_bm_k = bm;
     if (kind == 1 || kind == 2) h->gemm_bm_w = bm;
