@@ -34,7 +34,7 @@ enum {
     SGPR_E_NOMODEL = -3,   /* inducing set / weights not set ("you forgot to assign a DFT calculator!", calculator/active.py:429-430) */
     SGPR_E_SPECIES = -4,   /* an atomic number is missing from the model's species table */
     SGPR_E_NOT_PD = -5,    /* "cholesky was not successful!" (regression/algebra.py:45-46) */
-    SGPR_E_UNSUPPORTED = -6, /* (lmax,nmax,S) combination not compiled in */
+    SGPR_E_UNSUPPORTED = -6, /* (lmax,nmax,S) not compiled in: lmax, nmax in 2..4, S <= 8; least squares beyond m = 8192 */
     SGPR_E_OVERFLOW = -7   /* internal capacity exceeded after retry */
 };
 
@@ -260,7 +260,8 @@ int sgpr_compute(sgpr_model *h, int N, const int32_t *numbers, const double *pos
 /* sgpr_compute without the copies out: *packed_out points at this call's results where the device wrote them — page-locked
  * host memory owned by the handle, [F 3N | beta N | E | virial 9 (row-major) | overflow word | stress 6 (Voigt)], caller atom
  * order — valid until the call AFTER THE NEXT on this handle (two buffers alternate: the previous call's results stay
- * intact while this one runs).  What ActiveCalculator.results hands out as views (the reference's results are views of
+ * intact while this one runs; a buffer that a larger frame replaces is kept for one more generation).  N >= 1 (an empty
+ * frame has nothing to point at: sgpr_compute returns its zeros).  What ActiveCalculator.results hands out as views (the reference's results are views of
  * tensors the calculator owns, calculator/active.py:572-574; ASE copies what it passes on). */
 int sgpr_compute_view(sgpr_model *h, int N, const int32_t *numbers, const double *positions, const double *cell,
                       const int32_t *pbc, int rank, int world, const double **packed_out);
@@ -397,8 +398,13 @@ int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_ma
  *                      sgpr_md_begin / sgpr_md_run run SHARDED: every rank evaluates its share, and after the exchange
  *                      integrates all atoms from the summed forces (the deviates are counter-based or uploaded alike), so the
  *                      ranks' states stay identical; the covloss gate and capacity overflows halt every rank at the same step.
- * A peer that never arrives is a time-out (SGPR_PEER_TIMEOUT_MS, default 2000) reported by the next synchronising call,
- * not a hang.  Exchanges are collective: every rank issues the same sequence of them.
+ * A peer that never arrives is a time-out (SGPR_PEER_TIMEOUT_MS, default 30000: a rank's first sharded step may grow
+ * capacities and load code objects while its peers already wait), not a hang: the consumer of a timed-out exchange marks the
+ * step's results (poison in the overflow word; NaN in a buffer of sgpr_comm_allreduce), so the call that reads them —
+ * sgpr_compute / sgpr_compute_view on their warm path included, sgpr_sync_check, sgpr_md_run — fails with the time-out's
+ * message.  A time-out is permanent: every later exchange of the handle fails at once until sgpr_peer_export + sgpr_peer_attach
+ * have been called again on every rank.  Exchanges are collective: every rank issues the same sequence of them, one after
+ * the other (an exchange issued on another stream than the one before is ordered behind it).
  */
 #define SGPR_PEER_HANDLE_BYTES 128
 int sgpr_peer_export(sgpr_model *h, int rank, int world, int64_t capacity, void *handle_out);
