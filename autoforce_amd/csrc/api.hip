@@ -518,7 +518,8 @@ struct FinArgs {
                                                     // column, the lists' code words (neighbour species in bits 24..31)
     size_t g_stride, f_stride, v_stride, p_stride;  // batch (blockIdx.y, training rows): doubles between entries of
                                                     // G, [Fnbr | Fself], virpart, packed
-    int xp;                     // scatter form: `packed` has the EXCHANGE layout (peer.inc): [fixed-point sums 3N | own part 3N | beta N | scalars 11]
+    int xp;                     // scatter form: `packed` has the EXCHANGE layout (peer.inc): [fixed-point sums 3N | own part 3C | beta C | scalars 11]
+    int xcmax;                  //   C = ceil(N / world): atoms of the largest share
     size_t scal_off;            // where the eleven scalars start in `packed` (4N; exchange layout: 7N)
     const int *flag;            // this step's rebuild flag: set -> the candidates were rebuilt from `pos`
     int *rebuilds;              // running count of rebuilds
@@ -724,13 +725,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
             for (int k = 0; k < 3; k++) f.pos0[3 * i + k] = f.pos[3 * i + k];
         }
         double *packed = f.packed + by * f.p_stride;
+        const int il = (i - f.first) / f.stride;
+        const bool mine = i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt;
         if (f.xp) {
-            // exchange layout: the fixed-point sums travel as INTEGERS and are added as integers over the ranks (peer.inc):
-            // the total force is then the same bits for every number of ranks
+            // exchange layout (peer.inc): the fixed-point sums travel as INTEGERS and are added as integers over the ranks —
+            // the total force is then the same bits for every number of ranks —; the own part only for this rank's atoms
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                ((long long *)packed)[3 * (size_t)c + k] = ((const long long *)f.Fnbr)[3 * (size_t)i + k];
-                packed[3 * (size_t)f.N + 3 * (size_t)c + k] = f.Fself[3 * (size_t)i + k];
+            for (int k = 0; k < 3; k++) ((long long *)packed)[3 * (size_t)c + k] = ((const long long *)f.Fnbr)[3 * (size_t)i + k];
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) packed[3 * (size_t)f.N + 3 * (size_t)il + k] = f.Fself[3 * (size_t)i + k];
             }
         } else {
             // (the scattered part is a fixed-point integer sum: order-independent, sgpr_internal.h)
@@ -739,14 +743,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinArgs f)
                 packed[3 * c + k] = (double)((const long long *)f.Fnbr)[by * f.f_stride + 3 * i + k] * (1.0 / SGPR_FIX_SCALE) + f.Fself[by * f.f_stride + 3 * i + k];
         }
         double bt = 0.0;
-        const int il = (i - f.first) / f.stride;
-        if (f.has_beta && i >= f.first && (i - f.first) % f.stride == 0 && il < f.cnt) {
+        if (f.has_beta && mine) {
             double cs = 0.0;  // |choli k_i|^2: the tile partials in their fixed order
             for (int k = 0; k < f.csq_slots; k++) cs += f.csq[(size_t)il * f.csq_slots + k];
             const double v = 1.0 - cs;
             bt = sqrt(v > 0.0 ? v : 0.0) * f.vs_sqrt[f.slot[i]];
         }
-        packed[(f.xp ? 6 : 3) * (size_t)f.N + c] = bt;
+        if (!f.xp) packed[3 * (size_t)f.N + c] = bt;
+        else if (mine) packed[3 * (size_t)f.N + 3 * (size_t)f.xcmax + il] = bt;
     }
 }
 
@@ -2257,7 +2261,8 @@ static void launch_finalize(sgpr_model *h, bool gather, int nE, int nV, bool bet
 {
     const int N = h->N;
     FinArgs f = {};
-    f.xp = xp ? 1 : 0; f.scal_off = (xp ? 7 : 4) * (size_t)N;
+    f.xp = xp ? 1 : 0; f.xcmax = (int)peer_cmax(N, h->world);
+    f.scal_off = xp ? 3 * (size_t)N + 4 * (size_t)f.xcmax : 4 * (size_t)N;
     f.N = N; f.cnt = h->cnt; f.first = h->rank; f.stride = h->world; f.maxnn = h->maxnn; f.t_stride = h->t_stride;
     f.has_beta = beta ? 1 : 0; f.nE = nE; f.nV = nV; f.bin_cap = h->bin_cap; f.nbins_clear = 4096;
     f.t_check = (h->world == 1 && h->gather_ok) ? 1 : 0;
@@ -2459,7 +2464,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     const bool fuse = can_next && !shard_next &&
                       ((gather && h->comm == nullptr) || (nx->mode == 1 && !gather && h->world > 1 && !px));
     const bool xp = !gather && (px || shard_next);
-    const size_t xlen = peer_xlen(N);
+    const size_t xlen = peer_xlen(N, h->world);
     if (xp && h->d_xpacked.n < xlen + 1 && h->d_xpacked.alloc(xlen + 1)) return fail(SGPR_E_NODEVICE, "hipMalloc failed (exchange buffer)");
     launch_finalize(h, gather && predict, predict ? (fused3 ? 4 * (int)h->t_knm.n : h->epart_len) : 0, predict ? h->virpart_len : 0, beta, h->mean_energy,
                     xp ? h->d_xpacked.p : packed_dev, st, nullptr, fuse ? nx : nullptr, step, xp);
@@ -2467,7 +2472,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
     if (shard_next) {
         stamp(h, "finalize", st);
         ShardSrc src;
-        src.base = h->d_xpacked.p; src.n = 1; src.stride = 0; src.ctl = nullptr;
+        src.base = h->d_xpacked.p; src.n = 1; src.stride = 0; src.ctl = nullptr; src.cmax = (int)peer_cmax(N, h->world);
         if (px) {
             int parity = 0;
             if (h->peer.world != h->world || h->peer.rank != h->rank)
@@ -2477,6 +2482,7 @@ static int enqueue_step(sgpr_model *h, const double *pos_dev, const double *cell
             const int re = peer_exchange(h, h->d_xpacked.p, xlen, st, &parity, halt, (int)step);
             if (re) return re;
             src = peer_src(h->peer, parity);
+            src.cmax = (int)peer_cmax(N, h->world);
             stamp(h, "exchange", st);
         }
         launch_finalize(h, false, 0, 0, beta, h->mean_energy, packed_dev, st, nullptr, nx, step, false, &src);
@@ -2572,10 +2578,12 @@ static int reduce_packed(sgpr_model *h, double *packed_dev, hipStream_t st)
             return fail(SGPR_E_INVALID, "the bound sharding (rank %d of %d) differs from the exchange's (rank %d of %d)",
                         h->rank, h->world, h->peer.rank, h->peer.world);
         int parity = 0;
-        const int re = peer_exchange(h, h->d_xpacked.p, peer_xlen(h->N), st, &parity);
+        const int re = peer_exchange(h, h->d_xpacked.p, peer_xlen(h->N, h->world), st, &parity);
         if (re) return re;
+        ShardSrc src = peer_src(h->peer, parity);
+        src.cmax = (int)peer_cmax(h->N, h->world);
         hipLaunchKernelGGL(peer_sum_xp_kernel, dim3(std::min(256, (4 * std::max(h->N, 1) + 11 + 255) / 256)), dim3(256), 0, st,
-                           peer_src(h->peer, parity), h->N, packed_dev, (const int *)h->peer.ctl.p);
+                           src, h->N, packed_dev, (const int *)h->peer.ctl.p, (const int *)(h->d_perm.p + h->N));
         return SGPR_OK;
     }
     if (!h->comm) return SGPR_OK;  // no communicator attached: the caller combines the partial sums
@@ -2682,7 +2690,7 @@ static void poison_peers(sgpr_model *h, int N)
     h->reduce_done = false;
     // (the exchange layout has its overflow word at 7N + 10; the all-reduce combines the packed layout itself)
     double *buf = peer_on(h) ? h->d_xpacked.p : h->d_packed.p;
-    const size_t n_buf = peer_on(h) ? peer_xlen(N) : n_out;
+    const size_t n_buf = peer_on(h) ? peer_xlen(N, h->world) : n_out;
     if (peer_on(h) && h->d_xpacked.n < n_buf + 1 && h->d_xpacked.alloc(n_buf + 1)) { memcpy(g_err, keep, sizeof(keep)); return; }
     buf = peer_on(h) ? h->d_xpacked.p : h->d_packed.p;
     if (hipMemsetAsync(buf, 0, sizeof(double) * n_buf, h->stream) == hipSuccess &&

@@ -726,7 +726,7 @@ def main():
                 "host_array_path_atom_steps_per_s": host_rate,
                 "parallelism": f"atoms sharded x{world}, " + (
                     "single rank: no collective" if world == 1 else
-                    f"the library's own exchange per step: all-gather of {7 * N + 11} words of partial sums into hipIpc-mapped "
+                    f"the library's own exchange per step: all-gather of {3 * N + 4 * ((N + world - 1) // world) + 11} words of partial sums into hipIpc-mapped "
                     "peer buffers + local sum in rank order" if backend == "ipc" else
                     f"one RCCL all-reduce of {len(out_host)} doubles per step, issued by libsgpr_hip on the step stream"
                     if backend == "rccl" else f"torch.distributed all-reduce of {len(out_host)} doubles, host staged"),

@@ -390,8 +390,9 @@ int sgpr_comm_allreduce(sgpr_model *h, double *buf_dev, int64_t count, int op_ma
  * calculator/active.py:770-777), released by one flag store per peer, and summed locally in rank order.  The force sums of
  * the sharded reverse pass travel as fixed-point integers and are added as integers: the total force on an atom is the same
  * bits for every number of ranks.
- *   sgpr_peer_export   allocates this rank's buffers for `world` ranks and `capacity` doubles per slice (>= 7 N + 11 for
- *                      frames of N atoms) and writes SGPR_PEER_HANDLE_BYTES bytes for the peers
+ *   sgpr_peer_export   allocates this rank's buffers for `world` ranks and `capacity` doubles per slice (a sharded step of N
+ *                      atoms needs 3 N + 4 ceil(N / world) + 11; 7 N + 11 serves every world size) and writes
+ *                      SGPR_PEER_HANDLE_BYTES bytes for the peers
  *   sgpr_peer_attach   handles[world][SGPR_PEER_HANDLE_BYTES] of all ranks in rank order (the host passes them by any means);
  *                      from then on sgpr_compute / sgpr_step_dev / sgpr_step_dev_next combine a sharded step through this
  *                      exchange (preferred over a communicator of sgpr_comm_init), sgpr_comm_allreduce works over it, and

@@ -24,6 +24,8 @@ LIMITS = {
     r"gemm_nt_kernelILi4ELi1ELi16E": (0, 128),
     r"gemm_nt_kernelILi5ELi1ELi16E": (0, 128),      # (the fused K_nm + W + covloss launch)
     r"tsqr_leaf_wave_kernel": (0, 128),
+    r"gemm_nt_kernel8r64x3ILi[0-4]E": (0, 80),      # (three workgroups of 512 per CU: six waves per SIMD)
+    r"gemm_nt_kernel4hILi[0-4]E": (0, 128),
 }
 
 
