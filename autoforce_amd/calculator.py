@@ -420,8 +420,8 @@ class ActiveCalculator(Calculator):
         new = sorted(set(int(z) for z in numbers) - set(have))
         if new or 0 in self.engine.species:
             table = sorted(set(have) | set(new))
-            if len(table) > 8:
-                raise RuntimeError(f"{len(table)} species: the device kernels hold at most 8 species slots")
+            if len(table) > 16:
+                raise RuntimeError(f"{len(table)} species: the device kernels hold at most 16 species slots")
             self.model.retable(table)
             self._attach_native_comm()
             self.log(f"species table -> {table}")

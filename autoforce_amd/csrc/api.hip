@@ -1266,10 +1266,9 @@ extern "C" int sgpr_create(int lmax, int nmax, double eta, double rc, int S, con
     if (!out || !species_z || S < 1 || S > SGPR_MAX_S) return fail(SGPR_E_INVALID, "sgpr_create: bad species table (S=%d)", S);
     if (!(rc > 0.0) || !(eta > 0.0)) return fail(SGPR_E_INVALID, "sgpr_create: rc and eta must be positive");
     const bool in234 = lmax >= 2 && lmax <= 4 && nmax >= 2 && nmax <= 4;
-    // every (lmax, nmax) of {2,3,4}^2 with up to SGPR_MAX_S = 8 species slots (descriptor.hip::DISPATCH_LNS).  (Sixteen slots were
-    // tried for lmax = nmax = 3: the kernels compile, but the reverse kernel keeps dE/dc and a W row per wave in LDS — 75 KB per
-    // wave at rows of 8320 doubles, four waves per workgroup: no launch.)
-    const bool ok = in234;
+    // every (lmax, nmax) of {2,3,4}^2 with up to eight species slots; nine to sixteen (SGPR_MAX_S) for the reference's default
+    // lmax = nmax = 3 (descriptor.hip::DISPATCH_LNS; the reverse kernel then runs one atom per workgroup: SGPR_REV_WPW)
+    const bool ok = in234 && (S <= 8 || (lmax == 3 && nmax == 3));
     if (!ok) return fail(SGPR_E_UNSUPPORTED, "sgpr_create: (lmax,nmax,S)=(%d,%d,%d) is not compiled in", lmax, nmax, S);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -2084,7 +2083,7 @@ static int alloc_work(sgpr_model *h)
     h->csq_slots = 2 * ((std::max(h->m_pad, 1) + 63) / 64);  // covloss partials: one per (64-column tile, wave column)
     bad |= h->d_csq.alloc((size_t)cr * h->csq_slots);
     bad |= h->d_F.alloc((size_t)6 * h->N);
-    h->virpart_len = (h->cnt + 3) / 4;  // one partial per desc_bwd workgroup
+    h->virpart_len = (h->cnt + SGPR_REV_WPW(h->S) - 1) / SGPR_REV_WPW(h->S);  // one partial per workgroup of the reverse kernel
     bad |= h->d_virpart.alloc((size_t)std::max(h->virpart_len, 1) * 9);
     bad |= h->d_packed.alloc((size_t)4 * h->N + 11);
     if (h->m > 0) {

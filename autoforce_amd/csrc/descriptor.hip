@@ -1207,12 +1207,15 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
     constexpr int N1 = RD::N1, L1 = RD::L1, LL = RD::LL, NSLOT = RD::NSLOT;
     constexpr int KS = RD::KS, CB = RD::CB, CH = RD::CH, RB = RD::RB, SP = RD::SP, FS = RD::FS;
     constexpr int SPL = (NSLOT + 63) / 64;
+    // atoms (waves) per workgroup: four; ONE for the sixteen-slot instantiation, whose per-wave region — dE/dc and a W row of
+    // 8320 doubles — is 83 KB (launched with 64 threads: run_bwd)
+    constexpr int WPW = SGPR_REV_WPW(ST);
     __shared__ double vred[4][9];
     // wave index through readfirstlane: everything derived from it (atom index, LDS bases, row
     // addresses) is then scalar and stays out of the VGPR budget
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qd = xcd_quad(bx, nbx, a.xq);  // (the virial partial below stays at the quad's index: same sums as ever)
-    const int ia = qd * 4 + wave;
+    const int ia = qd * WPW + wave;
     const bool active = ia < a.N;
     const int perwave = ST * NSLOT + a.rsz + CH / 2;
     double *dcl = smem + (size_t)wave * perwave;  // [ST][NSLOT] dE/dc of this atom
@@ -1566,7 +1569,7 @@ __global__ __launch_bounds__(256, 4) void desc_rev_kernel(DescArgs a, GemmArgs g
     }
     __syncthreads();
     if (wave == 0 && lane < 9)
-        vir_b[(size_t)lane * nbx + qd] = vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
+        vir_b[(size_t)lane * nbx + qd] = WPW == 1 ? vred[0][lane] : vred[0][lane] + vred[1][lane] + vred[2][lane] + vred[3][lane];
 }
 
 // =========================================================================== unpack (tests)
@@ -1622,10 +1625,12 @@ static int run_bwd(DescArgs a, hipStream_t st, const GemmParams *cov = nullptr)
     if (a.N <= 0) return 0;
     using RD = RevDims<LMAX, NMAX>;
     a.rsz = rev_region_doubles<LMAX, NMAX, ST>(a.Dpad);
-    size_t lds = sizeof(double) * 4 * (size_t)(ST * RD::NSLOT + a.rsz + RD::CH / 2);
+    constexpr int WPW = SGPR_REV_WPW(ST);
+    if (WPW == 1) a.xq = 0;
+    size_t lds = sizeof(double) * WPW * (size_t)(ST * RD::NSLOT + a.rsz + RD::CH / 2);
     static size_t attr_set[6] = {0, 0, 0, 0, 0, 0};
     const bool gather = a.G != nullptr, rows = a.rows_aw != nullptr;
-    const bool with_cov = cov && !rows && cov->tiles && cov->ntiles > 0 && cov->bm == 32 && cov->kd == 16;
+    const bool with_cov = WPW == 4 && cov && !rows && cov->tiles && cov->ntiles > 0 && cov->bm == 32 && cov->kd == 16;
     GemmArgs gc = {};
     int n_cov = 0;
     if (with_cov) {
@@ -1645,17 +1650,17 @@ static int run_bwd(DescArgs a, hipStream_t st, const GemmParams *cov = nullptr)
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set[which] = lds;
     }
-    const dim3 grid((a.N + 3) / 4 + n_cov, rows ? a.batch : 1);
-    if (with_cov && gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false, true>), grid, dim3(256), lds, st, a, gc, n_cov);
-    else if (with_cov) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false, true>), grid, dim3(256), lds, st, a, gc, n_cov);
-    else if (gather && rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, true>), grid, dim3(256), lds, st, a, gc, n_cov);
-    else if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false>), grid, dim3(256), lds, st, a, gc, n_cov);
-    else if (rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, true>), grid, dim3(256), lds, st, a, gc, n_cov);
-    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false>), grid, dim3(256), lds, st, a, gc, n_cov);
+    const dim3 grid((a.N + WPW - 1) / WPW + n_cov, rows ? a.batch : 1), blk(64 * WPW);
+    if (with_cov && gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false, true>), grid, blk, lds, st, a, gc, n_cov);
+    else if (with_cov) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false, true>), grid, blk, lds, st, a, gc, n_cov);
+    else if (gather && rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, true>), grid, blk, lds, st, a, gc, n_cov);
+    else if (gather) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, true, false>), grid, blk, lds, st, a, gc, n_cov);
+    else if (rows) hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, true>), grid, blk, lds, st, a, gc, n_cov);
+    else hipLaunchKernelGGL((desc_rev_kernel<LMAX, NMAX, ST, false, false>), grid, blk, lds, st, a, gc, n_cov);
     return 0;
 }
 
-static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ? 4 : 8; }
+static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ? 4 : S <= 8 ? 8 : 16; }
 
 #define DISPATCH_LNS(FN, ...)                                                              \
     do {                                                                                   \
@@ -1665,8 +1670,10 @@ static int st_of(int S) { return S <= 1 ? 1 : S <= 2 ? 2 : S <= 3 ? 3 : S <= 4 ?
             if (stv == 2) return FN(3, 3, 2, __VA_ARGS__);                                  \
             if (stv == 3) return FN(3, 3, 3, __VA_ARGS__);                                  \
             if (stv == 4) return FN(3, 3, 4, __VA_ARGS__);                                  \
-            return FN(3, 3, 8, __VA_ARGS__);                                                \
+            if (stv == 8) return FN(3, 3, 8, __VA_ARGS__);                                  \
+            return FN(3, 3, 16, __VA_ARGS__);                                               \
         }                                                                                  \
+        if (stv > 8) return -6;   /* nine to sixteen species: the reference's default (3, 3) only */                                                                                  \
         if (p.lmax == 2 && p.nmax == 2) {                                                  \
             if (stv <= 2) return FN(2, 2, 2, __VA_ARGS__);                                  \
             if (stv <= 4) return FN(2, 2, 4, __VA_ARGS__);                                  \

@@ -6,7 +6,8 @@
 #include <string>
 #include <vector>
 
-#define SGPR_MAX_S 8        // species slots supported by the compiled kernels
+#define SGPR_MAX_S 16       // species slots supported by the compiled kernels (nine to sixteen: lmax = nmax = 3 only)
+#define SGPR_REV_WPW(S) ((S) > 8 ? 1 : 4)   // atoms (waves) per workgroup of the reverse kernel: its LDS region is 83 KB per wave at sixteen slots
 #define SGPR_MAX_L 4        // lmax supported
 #define SGPR_MAX_N 4        // nmax supported
 #define SGPR_EPS 2.220446049250313e-16  // torch.finfo(float64).eps (descriptor/sesoap.py:250)

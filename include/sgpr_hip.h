@@ -34,7 +34,7 @@ enum {
     SGPR_E_NOMODEL = -3,   /* inducing set / weights not set ("you forgot to assign a DFT calculator!", calculator/active.py:429-430) */
     SGPR_E_SPECIES = -4,   /* an atomic number is missing from the model's species table */
     SGPR_E_NOT_PD = -5,    /* "cholesky was not successful!" (regression/algebra.py:45-46) */
-    SGPR_E_UNSUPPORTED = -6, /* (lmax,nmax,S) not compiled in: lmax, nmax in 2..4, S <= 8; least squares beyond m = 8192 */
+    SGPR_E_UNSUPPORTED = -6, /* (lmax,nmax,S) not compiled in: lmax, nmax in 2..4, S <= 8 (<= 16 for lmax = nmax = 3); least squares beyond m = 8192 */
     SGPR_E_OVERFLOW = -7   /* internal capacity exceeded after retry */
 };
 

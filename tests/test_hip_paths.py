@@ -83,12 +83,14 @@ def test_five_species_uses_the_8_slot_kernels():
     mdl.close()
 
 
-@pytest.mark.parametrize("lmax,nmax,nspec", [(4, 4, 6), (2, 3, 5), (3, 4, 8), (4, 2, 7), (2, 2, 8), (3, 2, 5), (2, 4, 6), (4, 3, 5)])
+@pytest.mark.parametrize("lmax,nmax,nspec", [(4, 4, 6), (2, 3, 5), (3, 4, 8), (4, 2, 7), (2, 2, 8), (3, 2, 5), (2, 4, 6), (4, 3, 5),
+                                             (3, 3, 10), (3, 3, 16)])
 def test_more_than_four_species_for_every_lmax_nmax(lmax, nmax, nspec):
     """The reference's kernels take any species (its table is 120 wide, descriptor/sesoap.py:134) and any (lmax, nmax)
     (similarity/sesoap.py:10-24).  Here every pair of {2,3,4}^2 is compiled for up to eight species slots: frames with five to
     eight species against the oracle, K_mm included, and the training rows (the one-column-per-wave form: the sixteen-column
-    kernel is compiled for up to four slots)."""
+    kernel is compiled for up to four slots).  The reference's default pair (3, 3) goes on to sixteen slots (ten and sixteen
+    species here: descriptor rows of 8320 doubles, the reverse kernel one atom per workgroup)."""
     rng = np.random.default_rng(100 * lmax + 10 * nmax + nspec)
     species = [1, 6, 7, 8, 16, 3, 9, 15, 11, 12, 13, 14, 17, 19, 20, 29][:nspec]
     numbers, pos, cell = random_frame(rng, 112, 10.0, species)
