@@ -660,3 +660,39 @@ def test_npt_with_a_moving_cell_around_the_device_calculator():
     assert fast[6] == steps + 1                                  # one evaluation per configuration
     assert np.abs(fast[1] - cell0).max() > 1e-4                  # the cell has moved
     assert np.ptp(fast[5]) < 0.05 * max(abs(fast[5][0]), 1.0)
+
+
+def test_command_line_npt_with_a_bulk_modulus_on_the_device_calculator(tmp_path, monkeypatch):
+    """autoforce_amd.cl.md with `dynamics = 'NPT'` and a `bulk_modulus` (theforce/cl/md.py:131-166 with a moving cell): the
+    restated ASE integrator drives ActiveCalculator.calculate() on the HIP engine once per step — one log line per step, a
+    trajectory whose lattice changes, `iso` keeping the shape, the triclinic start cell rotated to upper-triangular form with
+    the interatomic distances (hence the energy) untouched."""
+    from autoforce_amd.ase_shim import Atoms
+    from autoforce_amd.calculator import ActiveCalculator
+    from autoforce_amd.cl import get_default_args, read_args, update_args
+    from autoforce_amd.cl.md import md, read_frames
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "ARGS").write_text("dynamics = 'NPT'\nbulk_modulus = 25.\nstress = 0.2   # GPa\niso = True\ntem = 500.\npicos = -12\n"
+                                   "loginterval = 4\ntdamp = 25\npdamp = 100\nml_filter = 0.8\nseed = 3\n")
+    mdl, (numbers, pos, cell, pbc) = _model()
+    # a rigidly rotated copy of the frame: the same physics in a cell that is NOT upper triangular
+    th = 0.3
+    R = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]]) @ \
+        np.array([[1.0, 0.0, 0.0], [0.0, np.cos(0.2), -np.sin(0.2)], [0.0, np.sin(0.2), np.cos(0.2)]])
+    calc = ActiveCalculator(covariance=mdl, logfile=str(tmp_path / "active.log"))
+    e0 = mdl.predict(numbers, pos, cell, pbc)["energy"]
+    atoms = Atoms(numbers, pos @ R.T, cell @ R.T, pbc)
+    kw = update_args(get_default_args(md), read_args())
+    kw.pop("calc")
+    md(atoms, calc=calc, **kw)
+    frames = read_frames("md.xyz", ":")
+    assert len(frames) == 4                                      # steps 0, 4, 8, 12
+    c0 = np.asarray(frames[0].cell)
+    assert c0[1, 0] == c0[2, 0] == c0[2, 1] == 0.0 and abs(abs(np.linalg.det(c0)) - abs(np.linalg.det(cell))) < 1e-9 * abs(np.linalg.det(cell))
+    assert abs(frames[0].energy - e0) < 1e-9 * max(1.0, abs(e0))  # the rotation changed nothing the model sees
+    c1 = np.asarray(atoms.cell)
+    assert np.abs(c1 - c0).max() > 1e-6                          # the cell moved ...
+    np.testing.assert_allclose(c1 / c1[2, 2], c0 / c0[2, 2], atol=1e-12)   # ... and kept its shape (iso)
+    log = [ln for ln in open(tmp_path / "active.log").read().splitlines()]
+    assert sum(1 for ln in log if len(ln.split()) == 6 and ln.split()[2].isdigit()) >= 13   # one line per step
+    mdl.close()
