@@ -101,8 +101,9 @@ def npt_dynamics(atoms, calc, dt, tem, bulk_modulus, stress, mask, iso, tdamp, p
     from ..npt import GPA, NPT, FilterDeltas, make_cell_upper_triangular
     from ..workloads import FS
     cell = np.array(getattr(atoms.cell, "array", atoms.cell), float)
-    if np.allclose(cell, 0.0):
-        raise ValueError("NPT needs a cell (the reference puts a cluster into a box with 6 A of vacuum: give the box)")
+    if np.allclose(cell, 0.0) or abs(np.linalg.det(cell)) < 1e-12:
+        raise ValueError("NPT needs a three-dimensional cell (the reference puts a cluster into a box with 6 A of vacuum around it, "
+                         "cl/md.py:169-172: give the box; a slab needs a finite third vector)")
     v = atoms.get_velocities()
     pos, cell_ut, R = make_cell_upper_triangular(atoms.positions, cell)
     if not np.array_equal(cell_ut, cell):
