@@ -713,11 +713,13 @@ class ActiveCalculator(Calculator):
     def _side_file(self, stem, atoms, results, mode):
         """The trajectory side files of the reference (active.py:495-499 `active_uncertain.traj`, :684-696 `active_FP.traj` /
         `active_ML.traj`): ase.io.Trajectory when ASE is installed; without it the same frames as extended XYZ (`<stem>.xyz`,
-        ASE's own text format: `ase.io.read` takes it), results as energy / forces / stress of the frame.  Written into the
-        working directory, as the reference does — by calculators that keep a log: one created with `logfile=None` (a quiet
-        evaluator inside somebody else's loop, the bench's timed calculate()) writes no files at all."""
+        ASE's own text format: `ase.io.read` takes it), results as energy / forces / stress of the frame.  Written beside the
+        log file — the working directory for the reference's default `logfile="active.log"`, where the reference writes them —
+        by calculators that keep a log: one created with `logfile=None` (a quiet evaluator inside somebody else's loop, the
+        bench's timed calculate()) writes no files at all."""
         if not self.logfile:
             return
+        stem = os.path.join(os.path.dirname(os.path.abspath(self.logfile)), stem)
         if HAVE_ASE:  # pragma: no cover
             import ase.io
             tmp = atoms.copy()

@@ -515,7 +515,7 @@ def test_side_files_of_an_uncertain_frame_and_of_the_test_keyword(tmp_path, monk
     from autoforce_amd.cl.md import read_frames
     monkeypatch.chdir(tmp_path)
     calc, teacher, trace = ac.run(OracleModel(3, 3, 4, 4.5, species=ac.SPECIES), tmp_path, steps=6, tape=False, test=2)
-    fp, ml = read_frames("active_FP.xyz", ":"), read_frames("active_ML.xyz", ":")
+    fp, ml = read_frames(str(tmp_path / "active_FP.xyz"), ":"), read_frames(str(tmp_path / "active_ML.xyz"), ":")
     assert len(fp) == len(ml) >= 1
     log = open(tmp_path / "active.log").read()
     assert log.count("errors (test):") == len(fp) and "testing energy:" in log
@@ -529,5 +529,5 @@ def test_side_files_of_an_uncertain_frame_and_of_the_test_keyword(tmp_path, monk
         at2 = Atoms(at.numbers, at.positions + 0.2 * rng.normal(size=at.positions.shape), at.cell, True)
         at2.calc = passive
         at2.get_potential_energy()
-    unc = read_frames("active_uncertain.xyz", ":")
+    unc = read_frames(str(tmp_path / "active_uncertain.xyz"), ":")
     assert len(unc) == 3 and unc[0].natoms == len(at.numbers) and unc[0].energy is None
